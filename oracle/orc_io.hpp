@@ -1,0 +1,135 @@
+// ORACLE (test infrastructure, never shipped in the product path).
+//
+// File boundary of the reference restated for the oracle CLI: FASTQ readers
+// (fasta.cpp:207-270 plain, :272-370 cluster variant), FASTQ writer
+// (fasta.cpp:436-445) and the hps `clusters.out` stream (grammar recovered from
+// the shipped fixtures; hps itself is an absent submodule).
+#pragma once
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "orc_cluster.hpp"
+
+namespace orc {
+
+inline void chomp_cr(std::string &s, bool dos) { if (dos && !s.empty()) s.erase(s.size() - 1); }
+
+// fasta.cpp:207-270: every 4-line record, file order, header += sample_id.
+inline read_set_t read_fastq_plain(const std::string &file, const std::string &sample_id) {
+    read_set_t out;
+    std::ifstream in(file);
+    std::string line, header, seq, ann;
+    if (!std::getline(in, line)) return out;
+    bool dos = !line.empty() && line[line.size() - 1] == '\r';
+    chomp_cr(line, dos);
+    header = line + sample_id;
+    int id = 1;
+    while (std::getline(in, line)) {
+        chomp_cr(line, dos);
+        if (id == 0) { header = line + sample_id; id = 1; }
+        else if (id == 1) { seq = line; id = 2; }
+        else if (id == 2) { ann = line; id = 3; }
+        else { out.push_back(read_t{header, seq, ann, line}); id = 0; }
+    }
+    return out;
+}
+
+// fasta.cpp:272-370: ann = running record index (filtered records consume an index),
+// quality dropped, length filter unless raw, reads containing 'N' skipped.
+// `index` is updated to the next free index (the reference smuggles it out through
+// result.back().quality, fasta.cpp:363 / main.cpp:47).
+inline read_set_t read_fastq_cluster(const std::string &file, const std::string &sample_id, int &index, bool raw,
+                                     int lower_len, int upper_len) {
+    read_set_t out;
+    std::ifstream in(file);
+    std::string line, header, seq, ann;
+    if (!std::getline(in, line)) return out;
+    bool dos = !line.empty() && line[line.size() - 1] == '\r';
+    chomp_cr(line, dos);
+    header = line + sample_id;
+    int id = 1;
+    while (std::getline(in, line)) {
+        chomp_cr(line, dos);
+        if (id == 0) { header = line + sample_id; id = 1; }
+        else if (id == 1) { seq = line; id = 2; }
+        else if (id == 2) { ann = std::to_string(index++); id = 3; }
+        else {
+            id = 0;
+            bool len_ok = raw || ((int)seq.length() >= lower_len && (int)seq.length() <= upper_len);
+            if (len_ok && seq.find('N') == std::string::npos) out.push_back(read_t{header, seq, ann, ""});
+        }
+    }
+    return out;
+}
+
+inline void write_fastq(const read_set_t &reads, const std::string &file) {   // fasta.cpp:436-445
+    std::ofstream f(file);
+    for (auto &r : reads) f << r.header << "\n" << r.seq << "\n" << r.ann << "\n" << r.quality << "\n";
+}
+
+inline void put_uvarint(std::string &o, uint64_t x) {
+    while (x >= 0x80) { o.push_back((char)((x & 0x7F) | 0x80)); x >>= 7; }
+    o.push_back((char)x);
+}
+inline void put_svarint(std::string &o, int32_t x) { put_uvarint(o, (uint32_t)((x << 1) ^ (x >> 31))); }
+
+inline std::string hps_encode(const cluster_set_t &cs) {        // cluster.hpp:15-18,30-33
+    std::string o;
+    put_uvarint(o, cs.size());
+    auto cseq = [&o](const cseq_t &c) { put_svarint(o, c.seq_id); o.push_back(c.rev ? 1 : 0); put_svarint(o, c.gene_id); };
+    for (auto &c : cs) {
+        cseq(c.main_seq);
+        put_uvarint(o, c.seqs.size());
+        for (auto &s : c.seqs) cseq(s);
+    }
+    return o;
+}
+
+inline bool hps_decode(const std::string &b, int fields, cluster_set_t &out) {
+    size_t p = 0;
+    bool ok = true;
+    auto uv = [&]() -> uint64_t {
+        uint64_t x = 0; int s = 0;
+        while (true) {
+            if (p >= b.size() || s > 63) { ok = false; return 0; }
+            uint8_t c = (uint8_t)b[p++];
+            x |= (uint64_t)(c & 0x7F) << s;
+            if (!(c & 0x80)) return x;
+            s += 7;
+        }
+    };
+    auto sv = [&]() -> int32_t { uint32_t z = (uint32_t)uv(); return (int32_t)((z >> 1) ^ (~(z & 1) + 1)); };
+    auto cseq = [&]() -> cseq_t {
+        cseq_t c;
+        c.seq_id = sv();
+        if (p >= b.size()) { ok = false; return c; }
+        uint8_t r = (uint8_t)b[p++];
+        if (r > 1) ok = false;
+        c.rev = r;
+        c.gene_id = fields == 3 ? sv() : -1;
+        return c;
+    };
+    out.clear();
+    uint64_t n = uv();
+    for (uint64_t i = 0; ok && i < n; ++i) {
+        cluster_t c;
+        c.main_seq = cseq();
+        uint64_t m = uv();
+        for (uint64_t j = 0; ok && j < m; ++j) c.seqs.push_back(cseq());
+        out.push_back(c);
+    }
+    return ok && p == b.size();
+}
+
+inline cluster_set_t hps_read_file(const std::string &path) {
+    std::ifstream in(path, std::ifstream::binary);
+    std::string b((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    cluster_set_t cs;
+    if (hps_decode(b, 3, cs)) return cs;
+    if (hps_decode(b, 2, cs)) return cs;
+    throw std::runtime_error("not a clusters.out stream: " + path);
+}
+
+}  // namespace orc
