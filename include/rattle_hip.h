@@ -1,0 +1,146 @@
+/*
+ * rattle_hip.h -- C ABI of librattle_hip.so, the MI355X (gfx950) implementation of
+ * RATTLE's `cluster` + `correct` hot path.
+ *
+ * RATTLE has no FFI / plugin interface: the seams are the C++ functions
+ *   cluster_reads(...)   /root/reference/cluster.hpp:44   (called at main.cpp:258,300,669)
+ *   correct_reads(...)   /root/reference/correct.hpp:44   (called at main.cpp:405,670)
+ * This header is the C boundary a maintainer binds underneath those two functions
+ * (INTEGRATION.md shows the binding).  Plain pointers and sizes only; no C++ or torch
+ * types.  All functions return 0 on success and a negative code on error, with text
+ * available from rattle_hip_last_error().  Nothing throws across the boundary.
+ * Input buffers are caller-owned; result objects are library-owned and released with
+ * the matching *_free function.  One host thread drives one context.
+ *
+ * Every entry point REQUIRES a HIP device: there is no CPU fallback.
+ */
+#ifndef RATTLE_HIP_H
+#define RATTLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RATTLE_OK 0
+#define RATTLE_ERR_HIP (-1)       /* a HIP runtime call failed (no device, OOM, launch error) */
+#define RATTLE_ERR_ARG (-2)       /* invalid argument (bad base in a read, k out of range, ...) */
+#define RATTLE_ERR_STATE (-3)     /* call order violated (e.g. no reads loaded) */
+
+typedef struct rattle_ctx rattle_ctx;
+
+const char *rattle_hip_last_error(void);
+int rattle_hip_abi_version(void);
+
+/* Context = one HIP device + its streams and device-resident read index. */
+int rattle_hip_ctx_create(int device, rattle_ctx **out);
+void rattle_hip_ctx_destroy(rattle_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------
+ * a3  extract_kmers_from_read   /root/reference/kmer.cpp:6-42, kmer.hpp:25-40
+ * Uploads n reads (ASCII A/C/G/T/U, concatenated; offsets has n+1 entries) and builds on
+ * the device, per read: the 4096-bit 6-mer bit-vector(s) (kmer.hpp:14-16), and the
+ * (hash,pos)-sorted k-mer list(s) with L-k entries.  both_strands = !is_rna.
+ * Replaces any previously loaded read set.  Reads must be given in PROCESSING order
+ * (cluster_reads consumes them length-descending, main.cpp:254).
+ */
+int rattle_hip_load_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const uint64_t *offsets, uint32_t n_reads,
+                          int kmer_size, int both_strands);
+
+/* Read back one read's index (tests): hash/pos need max(L-k,0) entries, bv 64 words. */
+int rattle_hip_get_read_index(rattle_ctx *ctx, uint32_t read, int strand, uint32_t *hash_out, int32_t *pos_out,
+                              uint64_t *bv_out, uint32_t *bv_popcount);
+
+/* ------------------------------------------------------------------------------------
+ * a4  bit-vector filter of cluster_together   /root/reference/cluster.cpp:13-19,43
+ * For every (seed s, candidate c) with c >= first_cand[s]:
+ *   common_f = popcount(bv_f[seed] & bv_f[cand]); common_r = popcount(bv_f[seed] & bv_r[cand])
+ *   mmax = max(popcount(bv_f[seed]), popcount(bv_f[cand]))
+ *   bit0 = fwd_bypass || common_f >= min_common_lut[mmax]
+ *   bit1 = both_strands && common_r >= min_common_lut[mmax]
+ * min_common_lut[m] (4097 entries) is the smallest c with double(c)/double(m) >= thr
+ * evaluated by the caller in the reference's own double arithmetic (0xFFFF = never).
+ * out_pass is n_seeds*n_cands bytes, row-major by seed.
+ */
+int rattle_hip_bv_filter(rattle_ctx *ctx, const uint32_t *seed_ids, uint32_t n_seeds, const uint32_t *cand_ids,
+                         uint32_t n_cands, const uint32_t *first_cand, const uint16_t *min_common_lut, int fwd_bypass,
+                         uint8_t *out_pass);
+
+/* ------------------------------------------------------------------------------------
+ * a5+a6+a7  get_common_kmers + calc_similarity + var
+ *           /root/reference/kmer.cpp:45-67, similarity.cpp:4-97, utils.cpp:36-55
+ * For each pair p: read i_ids[p] (forward list) against read j_ids[p] (forward list if
+ * strand[p]==0, reverse-complement list otherwise).  Outputs per pair: bases, hc_bases,
+ * n_dist = distances.size(), variance = var(distances) (IEEE double, same operation order
+ * as the reference; NaN for n_dist==1), n_matches = common.size().
+ */
+int rattle_hip_pair_score(rattle_ctx *ctx, const uint32_t *i_ids, const uint32_t *j_ids, const uint8_t *strand,
+                          uint32_t n_pairs, int32_t *bases, int32_t *hc_bases, int32_t *n_dist, double *variance,
+                          int32_t *n_matches);
+
+/* ------------------------------------------------------------------------------------
+ * a8-a11  cluster_reads   /root/reference/cluster.cpp:93-259 (signature cluster.hpp:44)
+ * Runs on the reads loaded by rattle_hip_load_reads (kmer_size / strands taken from there).
+ * min_reads_cluster, use_hc and verbose of the reference signature are accepted and
+ * ignored exactly as the reference ignores / never sets them (cluster.cpp:242-243).
+ */
+typedef struct {
+    double t_s, t_v;
+    double bv_threshold, min_bv_threshold, bv_falloff;
+    int min_reads_cluster;
+    int use_hc;
+    double repr_percentile;
+    int is_rna;
+} rattle_cluster_params;
+
+typedef struct {
+    uint32_t n_clusters;
+    int32_t *main_id;       /* [n_clusters]   cluster_t::main_seq.seq_id (index into the loaded reads) */
+    uint8_t *main_rev;      /* [n_clusters]   cluster_t::main_seq.rev */
+    uint32_t *offsets;      /* [n_clusters+1] member range of each cluster */
+    int32_t *member_id;     /* [n_members]    cseq_t::seq_id, in the order cluster_t::seqs holds them */
+    uint8_t *member_rev;    /* [n_members]    cseq_t::rev */
+    /* exact work counters: bit-vector pair tests, full comparisons, k-mer matches,
+       seed rounds, kernel launches */
+    uint64_t counters[8];
+} rattle_cluster_set;
+
+int rattle_hip_cluster_reads(rattle_ctx *ctx, const rattle_cluster_params *params, rattle_cluster_set **out);
+/* Same, restricted to a subset of the loaded reads given in processing order (the --iso
+ * second level, main.cpp:281-318).  Ids in the result are positions in `subset`. */
+int rattle_hip_cluster_subset(rattle_ctx *ctx, const rattle_cluster_params *params, const uint32_t *subset,
+                              uint32_t n_subset, rattle_cluster_set **out);
+void rattle_hip_cluster_set_free(rattle_cluster_set *cs);
+
+/* ------------------------------------------------------------------------------------
+ * a15  spoa engine + graph as called from /root/reference/correct.cpp:395-405,428-436,520-532
+ * (createAlignmentEngine(kSW,5,-4,-8,-6); align + add_alignment per sequence;
+ * generate_multiple_sequence_alignment).  Packs are independent; pack p holds sequences
+ * [pack_first[p], pack_first[p+1]) of the concatenated input, aligned in that order.
+ * Result: for each pack its MSA width and rows (one row per sequence, '-' for gaps).
+ */
+typedef struct {
+    uint32_t n_packs;
+    uint32_t *width;        /* [n_packs]  MSA columns */
+    uint64_t *row_offset;   /* [n_seqs+1] byte offset of each sequence's row in `rows` */
+    char *rows;             /* rows of all packs back to back */
+    uint64_t counters[8];   /* DP cells, alignments, graph nodes (sum of final sizes), ... */
+} rattle_msa_set;
+
+int rattle_hip_poa_msa(rattle_ctx *ctx, const uint8_t *seq_concat, const uint64_t *offsets, uint32_t n_seqs,
+                       const uint32_t *pack_first, uint32_t n_packs, rattle_msa_set **out);
+void rattle_hip_msa_set_free(rattle_msa_set *ms);
+
+/* ------------------------------------------------------------------------------------
+ * Per-kernel timing measured with HIP events on the stream the kernels run on.
+ * kernel: 0 kmer_extract, 1 bv_filter, 2 pair_score, 3 poa_align.  Accumulated since
+ * the last reset: total milliseconds, number of launches, algorithmic bytes moved.
+ */
+int rattle_hip_kernel_stats(rattle_ctx *ctx, int kernel, double *total_ms, uint64_t *launches, uint64_t *alg_bytes);
+int rattle_hip_kernel_stats_reset(rattle_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RATTLE_HIP_H */

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference interface over the C ABI.
+
+`Context.cluster_reads` has the argument meaning of cluster_reads
+(/root/reference/cluster.hpp:44); `cluster_command` is the `rattle cluster` flow of
+/root/reference/main.cpp:245-323 (length sort, gene level, optional --iso second level,
+translation to original record indices).  Python is used here because this image has the
+reference's C++ toolchain but the test harness is pytest; the C++ host with the same
+structure is rattle_amd/csrc/rattle_main.cpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ClusterParams, ClusterSet, MsaSet, check
+
+K_KMER, K_FILTER, K_SCORE, K_POA = 0, 1, 2, 3
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def pack_reads(seqs: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    cat = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
+    return cat, off
+
+
+@dataclass
+class Clusters:
+    main_id: np.ndarray
+    main_rev: np.ndarray
+    offsets: np.ndarray
+    member_id: np.ndarray
+    member_rev: np.ndarray
+    counters: np.ndarray
+
+    def as_list(self):
+        """[( (main_id, main_rev, -1), [(id, rev, -1), ...] ), ...] like rattle_amd.hps."""
+        out = []
+        for c in range(len(self.main_id)):
+            a, b = int(self.offsets[c]), int(self.offsets[c + 1])
+            out.append(((int(self.main_id[c]), int(self.main_rev[c]), -1),
+                        [(int(self.member_id[i]), int(self.member_rev[i]), -1) for i in range(a, b)]))
+        return out
+
+
+class Context:
+    """One HIP device + the device-resident read index (rattle_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.rattle_hip_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.n = 0
+        self.both = False
+        self.k = 0
+
+    def close(self):
+        if self.h:
+            self.lib.rattle_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # a3
+    def load_reads(self, seqs: Sequence[bytes], k: int, both_strands: bool):
+        cat, off = pack_reads(seqs)
+        self.load_packed(cat, off, k, both_strands)
+
+    def load_packed(self, cat: np.ndarray, off: np.ndarray, k: int, both_strands: bool):
+        n = len(off) - 1
+        check(self.lib.rattle_hip_load_reads(self.h, _ptr(cat, C.c_uint8), _ptr(off, C.c_uint64), n, k, int(both_strands)))
+        self.n, self.both, self.k = n, bool(both_strands), k
+        self._lens = (off[1:] - off[:-1]).astype(np.int64)
+
+    def read_index(self, r: int, strand: int):
+        nk = max(int(self._lens[r]) - self.k, 0)
+        h = np.zeros(nk, np.uint32)
+        p = np.zeros(nk, np.int32)
+        bv = np.zeros(64, np.uint64)
+        pc = C.c_uint32()
+        check(self.lib.rattle_hip_get_read_index(self.h, r, strand, _ptr(h, C.c_uint32), _ptr(p, C.c_int32),
+                                                 _ptr(bv, C.c_uint64), C.byref(pc)))
+        return h, p, bv, pc.value
+
+    # a4
+    def bv_filter(self, seed_ids, cand_ids, first_cand, lut, fwd_bypass: bool) -> np.ndarray:
+        s = np.ascontiguousarray(seed_ids, np.uint32)
+        c = np.ascontiguousarray(cand_ids, np.uint32)
+        f = np.ascontiguousarray(first_cand, np.uint32)
+        l = np.ascontiguousarray(lut, np.uint16)
+        assert len(l) == 4097 and len(f) == len(s)
+        out = np.zeros((len(s), len(c)), np.uint8)
+        check(self.lib.rattle_hip_bv_filter(self.h, _ptr(s, C.c_uint32), len(s), _ptr(c, C.c_uint32), len(c),
+                                            _ptr(f, C.c_uint32), _ptr(l, C.c_uint16), int(fwd_bypass), _ptr(out, C.c_uint8)))
+        return out
+
+    # a5-a7
+    def pair_score(self, i_ids, j_ids, strand):
+        i = np.ascontiguousarray(i_ids, np.uint32)
+        j = np.ascontiguousarray(j_ids, np.uint32)
+        s = np.ascontiguousarray(strand, np.uint8)
+        n = len(i)
+        bases = np.zeros(n, np.int32); hc = np.zeros(n, np.int32); nd = np.zeros(n, np.int32)
+        nm = np.zeros(n, np.int32); var = np.zeros(n, np.float64)
+        check(self.lib.rattle_hip_pair_score(self.h, _ptr(i, C.c_uint32), _ptr(j, C.c_uint32), _ptr(s, C.c_uint8), n,
+                                             _ptr(bases, C.c_int32), _ptr(hc, C.c_int32), _ptr(nd, C.c_int32),
+                                             _ptr(var, C.c_double), _ptr(nm, C.c_int32)))
+        return bases, hc, nd, var, nm
+
+    # a8-a11
+    def cluster_reads(self, t_s=0.2, t_v=1000000.0, bv_threshold=0.4, min_bv_threshold=0.2, bv_falloff=0.05,
+                      min_reads_cluster=0, use_hc=False, repr_percentile=0.15, is_rna=False,
+                      subset: Optional[np.ndarray] = None) -> Clusters:
+        P = ClusterParams(t_s, t_v, bv_threshold, min_bv_threshold, bv_falloff, min_reads_cluster, int(use_hc),
+                          repr_percentile, int(is_rna))
+        out = C.POINTER(ClusterSet)()
+        if subset is None:
+            check(self.lib.rattle_hip_cluster_reads(self.h, C.byref(P), C.byref(out)))
+        else:
+            sub = np.ascontiguousarray(subset, np.uint32)
+            check(self.lib.rattle_hip_cluster_subset(self.h, C.byref(P), _ptr(sub, C.c_uint32), len(sub), C.byref(out)))
+        cs = out.contents
+        nc = cs.n_clusters
+        offsets = np.ctypeslib.as_array(cs.offsets, (nc + 1,)).copy()
+        nm = int(offsets[nc])
+        res = Clusters(np.ctypeslib.as_array(cs.main_id, (max(nc, 1),))[:nc].copy(),
+                       np.ctypeslib.as_array(cs.main_rev, (max(nc, 1),))[:nc].copy(), offsets,
+                       np.ctypeslib.as_array(cs.member_id, (max(nm, 1),))[:nm].copy(),
+                       np.ctypeslib.as_array(cs.member_rev, (max(nm, 1),))[:nm].copy(),
+                       np.array(list(cs.counters), dtype=np.uint64))
+        self.lib.rattle_hip_cluster_set_free(out)
+        return res
+
+    # a15
+    def poa_msa(self, packs: Sequence[Sequence[bytes]]):
+        """MSA rows (list of bytes) for each pack of sequences."""
+        flat = [s for p in packs for s in p]
+        cat, off = pack_reads(flat)
+        first = np.zeros(len(packs) + 1, np.uint32)
+        first[1:] = np.cumsum([len(p) for p in packs])
+        out = C.POINTER(MsaSet)()
+        check(self.lib.rattle_hip_poa_msa(self.h, _ptr(cat, C.c_uint8), _ptr(off, C.c_uint64), len(flat),
+                                          _ptr(first, C.c_uint32), len(packs), C.byref(out)))
+        ms = out.contents
+        ro = np.ctypeslib.as_array(ms.row_offset, (len(flat) + 1,)).copy()
+        width = np.ctypeslib.as_array(ms.width, (max(len(packs), 1),))[:len(packs)].copy()
+        total = int(ro[len(flat)])
+        raw = C.string_at(ms.rows, total) if total else b""
+        counters = np.array(list(ms.counters), dtype=np.uint64)
+        self.lib.rattle_hip_msa_set_free(out)
+        res = []
+        q = 0
+        for pi, p in enumerate(packs):
+            rows = []
+            for _ in p:
+                rows.append(raw[int(ro[q]):int(ro[q + 1])])
+                q += 1
+            res.append(rows)
+        return res, width, counters
+
+    def kernel_stats(self, kernel: int):
+        ms = C.c_double(); n = C.c_uint64(); b = C.c_uint64()
+        check(self.lib.rattle_hip_kernel_stats(self.h, kernel, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+    def reset_stats(self):
+        check(self.lib.rattle_hip_kernel_stats_reset(self.h))
+
+
+def min_common_lut(thr: float) -> np.ndarray:
+    """min_common_lut[m] = smallest c with float(c)/float(m) >= thr (cluster.cpp:19,43); 0xFFFF = never."""
+    lut = np.full(4097, 0xFFFF, np.uint16)
+    for m in range(1, 4097):
+        c = np.arange(0, 4097, dtype=np.float64) / float(m)
+        idx = np.nonzero(c >= thr)[0]
+        if len(idx):
+            lut[m] = idx[0]
+    return lut
+
+
+def cluster_command(ctx: Context, seqs: Sequence[bytes], ann: Sequence[int], *, k=10, t_s=0.2, t_v=1000000.0,
+                    iso=False, iso_k=11, iso_t_s=0.3, iso_t_v=25.0, bv_threshold=0.4, bv_min_threshold=0.2,
+                    bv_falloff=0.05, repr_percentile=0.15, is_rna=False):
+    """`rattle cluster` after input parsing (main.cpp:254-323).  `seqs`/`ann` are the filtered reads
+    and their original record indices.  Returns clusters in rattle_amd.hps list form."""
+    order = sorted(range(len(seqs)), key=lambda i: -len(seqs[i]))       # stable, length desc (fasta.cpp:462)
+    sseqs = [seqs[i] for i in order]
+    sann = [ann[i] for i in order]
+    ctx.load_reads(sseqs, k, not is_rna)
+    gene = ctx.cluster_reads(t_s, t_v, bv_threshold, bv_min_threshold, bv_falloff, 0, False, repr_percentile, is_rna)
+    gl = gene.as_list()
+    if not iso:
+        return [((sann[m[0]], m[1], -1), [(sann[s[0]], s[1], -1) for s in mem]) for m, mem in gl], gene.counters
+    ctx.load_reads(sseqs, iso_k, not is_rna)
+    out = []
+    counters = gene.counters.copy()
+    for gi, (m, mem) in enumerate(gl):
+        ids = [s[0] for s in mem]
+        ids.sort(key=lambda x: -x)                                       # main.cpp:285-291
+        ids.sort(key=lambda x: -len(sseqs[x]))
+        sub = ctx.cluster_reads(iso_t_s, iso_t_v, bv_threshold, bv_min_threshold, bv_falloff, 0, False,
+                                repr_percentile, is_rna, subset=np.array(ids, np.uint32))
+        counters += sub.counters
+        for im, imem in sub.as_list():
+            out.append(((sann[ids[im[0]]], im[1], gi), [(sann[ids[s[0]]], s[1], gi) for s in imem]))
+    return out, counters

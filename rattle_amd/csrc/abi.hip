@@ -1,0 +1,207 @@
+// extern "C" surface of librattle_hip.so (include/rattle_hip.h).
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+namespace rattle {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+int launch_pair_score_oversize(rattle_ctx *ctx, const std::vector<uint32_t> &slots, uint32_t max_matches);
+int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n_seqs, const uint32_t *pack_first,
+                uint32_t n_packs, rattle_msa_set **out);
+
+}  // namespace rattle
+
+using namespace rattle;
+
+extern "C" {
+
+const char *rattle_hip_last_error(void) { return g_err.c_str(); }
+int rattle_hip_abi_version(void) { return 1; }
+
+int rattle_hip_ctx_create(int device, rattle_ctx **out) {
+    if (!out) { set_error("out is null"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_error(std::string("no HIP device available (librattle_hip has no CPU fallback): ") + hipGetErrorString(e));
+        return RATTLE_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { set_error("device index out of range"); return RATTLE_ERR_ARG; }
+    RT_HIP(hipSetDevice(device));
+    rattle_ctx *c = new rattle_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess) {
+        set_error("stream/event creation failed");
+        delete c;
+        return RATTLE_ERR_HIP;
+    }
+    if (getenv("RATTLE_NO_KERNEL_TIMING")) c->timing = false;
+    *out = c;
+    return 0;
+}
+
+void rattle_hip_ctx_destroy(rattle_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    read_index &X = c->idx;
+    X.seq.release(); X.off.release(); X.koff.release(); X.len.release(); X.uh.release();
+    for (int s = 0; s < 2; ++s) { X.kh[s].release(); X.kp[s].release(); X.bv[s].release(); X.pc[s].release(); }
+    c->d_seed.release(); c->d_cand.release(); c->d_first.release(); c->d_lut.release(); c->d_pass.release();
+    c->d_surv.release(); c->d_counter.release(); c->d_pi.release(); c->d_pj.release(); c->d_ps.release();
+    c->d_res.release(); c->d_var.release(); c->d_scratch.release();
+    c->h_surv.release(); c->h_res.release(); c->h_var.release(); c->h_counter.release();
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rattle_hip_load_reads(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k, int both) {
+    if (!c || !off || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    RT_HIP(hipSetDevice(c->device));
+    return build_index(c, seq, off, n, k, both);
+}
+
+int rattle_hip_get_read_index(rattle_ctx *c, uint32_t r, int strand, uint32_t *hash_out, int32_t *pos_out, uint64_t *bv_out,
+                              uint32_t *pc_out) {
+    if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
+    read_index &X = c->idx;
+    if (r >= X.n) { set_error("read out of range"); return RATTLE_ERR_ARG; }
+    if (strand < 0 || strand > 1 || (strand == 1 && !X.both)) { set_error("strand not indexed"); return RATTLE_ERR_ARG; }
+    RT_HIP(hipSetDevice(c->device));
+    uint64_t ko = X.h_koff[r], nk = X.h_koff[r + 1] - ko;
+    if (nk && hash_out) RT_HIP(hipMemcpy(hash_out, X.kh[strand].p + ko, nk * 4, hipMemcpyDeviceToHost));
+    if (nk && pos_out) RT_HIP(hipMemcpy(pos_out, X.kp[strand].p + ko, nk * 4, hipMemcpyDeviceToHost));
+    if (bv_out) RT_HIP(hipMemcpy(bv_out, X.bv[strand].p + (uint64_t)r * 64, 512, hipMemcpyDeviceToHost));
+    if (pc_out) RT_HIP(hipMemcpy(pc_out, X.pc[strand].p + r, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rattle_hip_bv_filter(rattle_ctx *c, const uint32_t *seed_ids, uint32_t n_seeds, const uint32_t *cand_ids, uint32_t n_cands,
+                         const uint32_t *first_cand, const uint16_t *lut, int fwd_bypass, uint8_t *out_pass) {
+    if (!c || !seed_ids || !cand_ids || !first_cand || !lut || !out_pass) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    if (c->idx.n == 0) { set_error("no reads loaded"); return RATTLE_ERR_STATE; }
+    for (uint32_t i = 0; i < n_seeds; ++i) if (seed_ids[i] >= c->idx.n) { set_error("seed id out of range"); return RATTLE_ERR_ARG; }
+    for (uint32_t i = 0; i < n_cands; ++i) if (cand_ids[i] >= c->idx.n) { set_error("cand id out of range"); return RATTLE_ERR_ARG; }
+    if (n_seeds == 0 || n_cands == 0) return 0;
+    RT_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    RT_TRY(c->d_seed.reserve(n_seeds)); RT_TRY(c->d_first.reserve(n_seeds)); RT_TRY(c->d_cand.reserve(n_cands));
+    RT_TRY(c->d_lut.reserve(4097)); RT_TRY(c->d_pass.reserve((size_t)n_seeds * n_cands)); RT_TRY(c->d_counter.reserve(4));
+    RT_HIP(hipMemcpyAsync(c->d_seed.p, seed_ids, n_seeds * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(c->d_first.p, first_cand, n_seeds * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(c->d_cand.p, cand_ids, (size_t)n_cands * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(c->d_lut.p, lut, 4097 * 2, hipMemcpyHostToDevice, st));
+    RT_TRY(launch_bv_filter(c, n_seeds, n_cands, fwd_bypass, true, false, 0));
+    RT_HIP(hipMemcpyAsync(out_pass, c->d_pass.p, (size_t)n_seeds * n_cands, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int rattle_hip_pair_score(rattle_ctx *c, const uint32_t *i_ids, const uint32_t *j_ids, const uint8_t *strand, uint32_t n,
+                          int32_t *bases, int32_t *hc_bases, int32_t *n_dist, double *variance, int32_t *n_matches) {
+    if (!c || !i_ids || !j_ids || !strand) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    read_index &X = c->idx;
+    if (X.n == 0) { set_error("no reads loaded"); return RATTLE_ERR_STATE; }
+    for (uint32_t p = 0; p < n; ++p) {
+        if (i_ids[p] >= X.n || j_ids[p] >= X.n) { set_error("read id out of range"); return RATTLE_ERR_ARG; }
+        if (strand[p] > 1 || (strand[p] == 1 && !X.both)) { set_error("strand not indexed"); return RATTLE_ERR_ARG; }
+    }
+    if (n == 0) return 0;
+    RT_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    RT_TRY(c->d_pi.reserve(n)); RT_TRY(c->d_pj.reserve(n)); RT_TRY(c->d_ps.reserve(n));
+    RT_TRY(c->d_res.reserve((size_t)n * 4)); RT_TRY(c->d_var.reserve(n));
+    RT_HIP(hipMemcpyAsync(c->d_pi.p, i_ids, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(c->d_pj.p, j_ids, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(c->d_ps.p, strand, n, hipMemcpyHostToDevice, st));
+    RT_TRY(launch_pair_score(c, n));
+    std::vector<int32_t> res((size_t)n * 4);
+    std::vector<double> var(n);
+    RT_HIP(hipMemcpyAsync(res.data(), c->d_res.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipMemcpyAsync(var.data(), c->d_var.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    std::vector<uint32_t> big;
+    uint32_t big_m = 0;
+    for (uint32_t p = 0; p < n; ++p)
+        if (res[4 * (size_t)p] == INT32_MIN) { big.push_back(p); big_m = std::max(big_m, (uint32_t)res[4 * (size_t)p + 3]); }
+    if (!big.empty()) {
+        RT_TRY(launch_pair_score_oversize(c, big, big_m));
+        RT_HIP(hipMemcpy(res.data(), c->d_res.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(var.data(), c->d_var.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    uint64_t bytes = 0;
+    for (uint32_t p = 0; p < n; ++p) {
+        if (bases) bases[p] = res[4 * (size_t)p];
+        if (hc_bases) hc_bases[p] = res[4 * (size_t)p + 1];
+        if (n_dist) n_dist[p] = res[4 * (size_t)p + 2];
+        if (n_matches) n_matches[p] = res[4 * (size_t)p + 3];
+        if (variance) variance[p] = var[p];
+        bytes += 8ull * ((X.h_koff[i_ids[p] + 1] - X.h_koff[i_ids[p]]) + (X.h_koff[j_ids[p] + 1] - X.h_koff[j_ids[p]]));
+    }
+    c->stats[K_SCORE].bytes += bytes;
+    return 0;
+}
+
+int rattle_hip_cluster_reads(rattle_ctx *c, const rattle_cluster_params *P, rattle_cluster_set **out) {
+    if (!c || !P || !out) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    RT_HIP(hipSetDevice(c->device));
+    if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
+    return cluster_driver(c, P, nullptr, 0, out);
+}
+
+int rattle_hip_cluster_subset(rattle_ctx *c, const rattle_cluster_params *P, const uint32_t *subset, uint32_t n_subset,
+                              rattle_cluster_set **out) {
+    if (!c || !P || !out || (n_subset && !subset)) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    for (uint32_t i = 0; i < n_subset; ++i) if (subset[i] >= c->idx.n) { set_error("subset id out of range"); return RATTLE_ERR_ARG; }
+    RT_HIP(hipSetDevice(c->device));
+    if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
+    static const uint32_t none = 0;
+    return cluster_driver(c, P, n_subset ? subset : &none, n_subset, out);
+}
+
+void rattle_hip_cluster_set_free(rattle_cluster_set *cs) {
+    if (!cs) return;
+    free(cs->main_id); free(cs->main_rev); free(cs->offsets); free(cs->member_id); free(cs->member_rev);
+    free(cs);
+}
+
+int rattle_hip_poa_msa(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n_seqs, const uint32_t *pack_first,
+                       uint32_t n_packs, rattle_msa_set **out) {
+    if (!c || !off || !pack_first || !out) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    RT_HIP(hipSetDevice(c->device));
+    return poa_msa_run(c, seq, off, n_seqs, pack_first, n_packs, out);
+}
+
+void rattle_hip_msa_set_free(rattle_msa_set *ms) {
+    if (!ms) return;
+    free(ms->width); free(ms->row_offset); free(ms->rows);
+    free(ms);
+}
+
+int rattle_hip_kernel_stats(rattle_ctx *c, int kernel, double *ms, uint64_t *launches, uint64_t *bytes) {
+    if (!c || kernel < 0 || kernel >= K_COUNT) { set_error("bad kernel id"); return RATTLE_ERR_ARG; }
+    if (ms) *ms = c->stats[kernel].ms;
+    if (launches) *launches = c->stats[kernel].launches;
+    if (bytes) *bytes = c->stats[kernel].bytes;
+    return 0;
+}
+
+int rattle_hip_kernel_stats_reset(rattle_ctx *c) {
+    if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
+    for (int i = 0; i < K_COUNT; ++i) c->stats[i] = kstat();
+    return 0;
+}
+
+}  // extern "C"

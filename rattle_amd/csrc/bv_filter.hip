@@ -1,0 +1,142 @@
+// Kernel A: bit-vector pair filter.  Replaces the first lines of cluster_together,
+// /root/reference/cluster.cpp:13-19 (forward) and :43 (reverse strand).
+//
+// Tile = 32 seeds x 256 candidates per 256-thread workgroup.  Seed bit-vectors (32 x 512 B)
+// sit in LDS and are read as wave-uniform broadcasts; every lane owns one candidate and
+// holds its 4096-bit vector in registers (64 x u64), so each candidate vector is fetched
+// from HBM once per seed tile and reused 32 times.  Work per pair and strand: 64 x
+// (v_and_b32 x2 + v_bcnt_u32_b32 x2).  Decisions are integer-only: the reference's
+// `double(common)/double(mmax) >= thr` is folded by the host into min_common_lut[mmax].
+//
+// Algorithmic HBM bytes per pair test: 512*(1+both_strands)+2, i.e. the
+// un-tiled streaming figure; the tile reuse makes actual traffic ~1/32 of that.
+#include "common.h"
+
+namespace rattle {
+
+#define BVF_TS 32
+#define BVF_TC 256
+
+template <bool BOTH>
+__global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restrict__ bvf, const uint64_t *__restrict__ bvr,
+                                                        const uint32_t *__restrict__ pcf, const uint32_t *__restrict__ seed_ids,
+                                                        uint32_t n_seeds, const uint32_t *__restrict__ cand_ids, uint32_t n_cands,
+                                                        const uint32_t *__restrict__ first_cand, const uint16_t *__restrict__ lut,
+                                                        int fwd_bypass, uint8_t *__restrict__ dense, uint32_t *__restrict__ list,
+                                                        uint32_t list_cap, uint32_t *__restrict__ list_count) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_bv[BVF_TS][64];
+    __shared__ uint32_t s_pc[BVF_TS];
+    __shared__ uint32_t s_first[BVF_TS];
+    __shared__ uint32_t s_minfirst;
+    __shared__ uint16_t s_cf[BOTH ? BVF_TS : 1][BVF_TC];     // forward counts parked while the reverse vector is in registers
+
+    const uint32_t s0 = blockIdx.y * BVF_TS;
+    const uint32_t ns = min((uint32_t)BVF_TS, n_seeds - s0);
+    const uint32_t c0 = blockIdx.x * BVF_TC;
+    const uint32_t c = c0 + threadIdx.x;
+
+    if (threadIdx.x == 0) s_minfirst = 0xFFFFFFFFu;
+    __syncthreads();
+    if (threadIdx.x < ns) {
+        uint32_t f = first_cand[s0 + threadIdx.x];
+        s_first[threadIdx.x] = f;
+        s_pc[threadIdx.x] = pcf[seed_ids[s0 + threadIdx.x]];
+        atomicMin(&s_minfirst, f);
+    }
+    __syncthreads();
+    // whole candidate tile lies before every seed's first candidate: nothing to do
+    if (c0 + BVF_TC <= s_minfirst) {
+        if (dense && c < n_cands)
+            for (uint32_t s = 0; s < ns; ++s) dense[(uint64_t)(s0 + s) * n_cands + c] = 0;
+        return;
+    }
+    for (uint32_t t = threadIdx.x; t < ns * 64; t += blockDim.x) {
+        uint32_t s = t >> 6, w = t & 63;
+        s_bv[s][w] = bvf[(uint64_t)seed_ids[s0 + s] * 64 + w];
+    }
+    __syncthreads();
+
+    const bool live = c < n_cands;
+    const uint32_t cid = live ? cand_ids[c] : 0;
+    const uint32_t cpc = live ? pcf[cid] : 0;
+
+    // one (seed, candidate) verdict; res bit0 = forward passes, bit1 = reverse passes
+    auto emit = [&](uint32_t s, uint32_t common_f, uint32_t common_r) {
+        uint32_t res = 0;
+        if (c >= s_first[s]) {
+            uint32_t mmax = max(s_pc[s], cpc);                 // cluster.cpp:16 forward counts only
+            uint32_t need = lut[mmax];
+            if (fwd_bypass || common_f >= need) res |= 1u;     // cluster.cpp:19
+            if (BOTH && common_r >= need) res |= 2u;           // cluster.cpp:43
+        }
+        if (dense) dense[(uint64_t)(s0 + s) * n_cands + c] = (uint8_t)res;
+        if (list && res) {
+            uint32_t cnt = (res & 1u) + ((res >> 1) & 1u);
+            uint32_t at = atomicAdd(list_count, cnt);
+            if (res & 1u) {
+                if (at < list_cap) { list[2 * (uint64_t)at] = ((s0 + s) << 1); list[2 * (uint64_t)at + 1] = c; }
+                ++at;
+            }
+            if (res & 2u) {
+                if (at < list_cap) { list[2 * (uint64_t)at] = ((s0 + s) << 1) | 1u; list[2 * (uint64_t)at + 1] = c; }
+            }
+        }
+    };
+
+    {
+        uint64_t v[64];
+        const uint4 *src = (const uint4 *)(bvf + (uint64_t)cid * 64);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            uint4 x = live ? src[q] : make_uint4(0, 0, 0, 0);
+            v[2 * q] = (uint64_t)x.x | ((uint64_t)x.y << 32);
+            v[2 * q + 1] = (uint64_t)x.z | ((uint64_t)x.w << 32);
+        }
+        for (uint32_t s = 0; s < ns; ++s) {
+            uint32_t a = 0;
+#pragma unroll
+            for (int w = 0; w < 64; ++w) a += __popcll(v[w] & s_bv[s][w]);
+            if (BOTH) s_cf[s][threadIdx.x] = (uint16_t)a;
+            else if (live) emit(s, a, 0);
+        }
+    }
+    if (BOTH) {
+        uint64_t v[64];
+        const uint4 *src = (const uint4 *)(bvr + (uint64_t)cid * 64);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            uint4 x = live ? src[q] : make_uint4(0, 0, 0, 0);
+            v[2 * q] = (uint64_t)x.x | ((uint64_t)x.y << 32);
+            v[2 * q + 1] = (uint64_t)x.z | ((uint64_t)x.w << 32);
+        }
+        for (uint32_t s = 0; s < ns; ++s) {
+            uint32_t a = 0;
+#pragma unroll
+            for (int w = 0; w < 64; ++w) a += __popcll(v[w] & s_bv[s][w]);
+            if (live) emit(s, s_cf[s][threadIdx.x], a);
+        }
+    }
+}
+
+int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fwd_bypass, bool dense, bool list,
+                     uint32_t list_cap) {
+    if (n_seeds == 0 || n_cands == 0) return 0;
+    read_index &X = ctx->idx;
+    dim3 grid((n_cands + BVF_TC - 1) / BVF_TC, (n_seeds + BVF_TS - 1) / BVF_TS);
+    uint64_t pairs = (uint64_t)n_seeds * n_cands;
+    ktimer T(ctx, K_FILTER, pairs * (512ull * (1 + X.both) + 2));
+    if (X.both)
+        hipLaunchKernelGGL(bv_filter_kernel<true>, grid, dim3(256), 0, ctx->stream, X.bv[0].p, X.bv[1].p, X.pc[0].p,
+                           ctx->d_seed.p, n_seeds, ctx->d_cand.p, n_cands, ctx->d_first.p, ctx->d_lut.p, fwd_bypass,
+                           dense ? ctx->d_pass.p : nullptr, list ? ctx->d_surv.p : nullptr, list_cap, ctx->d_counter.p);
+    else
+        hipLaunchKernelGGL(bv_filter_kernel<false>, grid, dim3(256), 0, ctx->stream, X.bv[0].p, (const uint64_t *)nullptr,
+                           X.pc[0].p, ctx->d_seed.p, n_seeds, ctx->d_cand.p, n_cands, ctx->d_first.p, ctx->d_lut.p,
+                           fwd_bypass, dense ? ctx->d_pass.p : nullptr, list ? ctx->d_surv.p : nullptr, list_cap,
+                           ctx->d_counter.p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("bv_filter launch: ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
+    return 0;
+}
+
+}  // namespace rattle

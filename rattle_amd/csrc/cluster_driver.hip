@@ -1,0 +1,328 @@
+// Host orchestration of the greedy clustering, /root/reference/cluster.cpp:93-259, over the
+// device kernels A (bv_filter) and B (pair_score).
+//
+// The reference walks seeds one at a time and, per seed, spawns n_threads tasks over the
+// remaining reads (cluster.cpp:138-158).  cluster_together(i,j) is a pure function of
+// (i, j, threshold), and read j joins seed i iff j is still un-clustered when i is
+// processed.  So a BATCH of the next B un-clustered items can be evaluated in one launch
+// and resolved afterwards in index order with an identical result:
+//   level 1: seeds x seeds  -> which seeds are absorbed by an earlier seed (exact founders)
+//   level 2: founders x all remaining items -> each item joins the FIRST founder that accepts it
+// The merge passes (cluster.cpp:171-256) are the same procedure over cluster representatives.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+
+namespace rattle {
+
+int launch_pair_score_oversize(rattle_ctx *ctx, const std::vector<uint32_t> &slots, uint32_t max_matches);
+
+// survivor list (seed_slot<<1|strand, cand_slot) -> explicit (read i, read j, strand) pairs
+__global__ void expand_pairs_kernel(const uint32_t *__restrict__ surv, uint32_t n, const uint32_t *__restrict__ seed_ids,
+                                    const uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ pi, uint32_t *__restrict__ pj,
+                                    uint8_t *__restrict__ ps) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t a = surv[2 * (uint64_t)t], c = surv[2 * (uint64_t)t + 1];
+    pi[t] = seed_ids[a >> 1];
+    pj[t] = cand_ids[c];
+    ps[t] = (uint8_t)(a & 1u);
+}
+
+struct hit_t { uint32_t seed, cand; uint8_t rev; };
+
+struct cseq { int32_t id; uint8_t rev; };
+
+struct driver {
+    rattle_ctx *ctx;
+    const rattle_cluster_params *P;
+    const uint32_t *subset;          // local id -> loaded read id (nullptr = identity)
+    uint32_t n;
+    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint16_t lut[4097];
+    double lut_thr = -1.0;
+    std::vector<uint32_t> tmp_seed, tmp_cand, tmp_first;
+
+    uint32_t rid(uint32_t local) const { return subset ? subset[local] : local; }
+    uint32_t rlen(uint32_t local) const { return ctx->idx.h_len[rid(local)]; }
+
+    // min_common_lut[m] = smallest c with double(c)/double(m) >= thr  (cluster.cpp:19,43)
+    int set_threshold(double thr) {
+        if (thr == lut_thr) return 0;
+        for (int m = 0; m <= 4096; ++m) {
+            double mmax = (double)m;
+            int need = 0xFFFF;
+            int lo = 0, hi = 4096;               // predicate is monotone in c for m > 0
+            if (m > 0 && (double)(size_t)hi / mmax >= thr) {
+                while (lo < hi) {
+                    int mid = (lo + hi) / 2;
+                    if ((double)(size_t)mid / mmax >= thr) hi = mid; else lo = mid + 1;
+                }
+                need = lo;
+            }
+            lut[m] = (uint16_t)need;
+        }
+        lut_thr = thr;
+        RT_TRY(ctx->d_lut.reserve(4097));
+        RT_HIP(hipMemcpyAsync(ctx->d_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(hipStreamSynchronize(ctx->stream));   // lut[] may be rewritten by the next call
+        return 0;
+    }
+
+    // Evaluate cluster_together for every (seed s, cand c >= first[s]); seeds/cands are LOCAL ids.
+    int eval(const std::vector<uint32_t> &seeds, const uint32_t *cands, uint32_t n_cands, const std::vector<uint32_t> &first,
+             double thr, std::vector<hit_t> &hits) {
+        hits.clear();
+        uint32_t ns = (uint32_t)seeds.size();
+        if (ns == 0 || n_cands == 0) return 0;
+        hipStream_t st = ctx->stream;
+        tmp_seed.resize(ns);
+        for (uint32_t i = 0; i < ns; ++i) tmp_seed[i] = rid(seeds[i]);
+        const uint32_t *cand_rids = cands;
+        if (subset) {
+            tmp_cand.resize(n_cands);
+            for (uint32_t i = 0; i < n_cands; ++i) tmp_cand[i] = subset[cands[i]];
+            cand_rids = tmp_cand.data();
+        }
+        RT_TRY(ctx->d_seed.reserve(ns));
+        RT_TRY(ctx->d_first.reserve(ns));
+        RT_TRY(ctx->d_cand.reserve(n_cands));
+        RT_TRY(ctx->d_counter.reserve(4));
+        RT_TRY(ctx->h_counter.reserve(4));
+        RT_HIP(hipMemcpyAsync(ctx->d_seed.p, tmp_seed.data(), ns * 4, hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(ctx->d_first.p, first.data(), ns * 4, hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(ctx->d_cand.p, cand_rids, (size_t)n_cands * 4, hipMemcpyHostToDevice, st));
+        uint64_t npairs = 0;
+        for (uint32_t i = 0; i < ns; ++i) npairs += n_cands > first[i] ? n_cands - first[i] : 0;
+        counters[0] += npairs;
+
+        // survivor capacity: grow and retry on overflow (count is exact even when truncated)
+        size_t cap = std::max<size_t>(ctx->d_surv.cap / 2, 1u << 20);
+        uint32_t nsurv = 0;
+        while (true) {
+            RT_TRY(ctx->d_surv.reserve(cap * 2));
+            cap = ctx->d_surv.cap / 2;
+            RT_HIP(hipMemsetAsync(ctx->d_counter.p, 0, 16, st));
+            RT_TRY(launch_bv_filter(ctx, ns, n_cands, thr == 0.0 ? 1 : 0, false, true, (uint32_t)std::min<size_t>(cap, 0xFFFFFFF0u)));
+            counters[4]++;
+            RT_HIP(hipMemcpyAsync(ctx->h_counter.p, ctx->d_counter.p, 4, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+            nsurv = ctx->h_counter.p[0];
+            if (nsurv <= cap) break;
+            cap = (size_t)nsurv + nsurv / 8;
+        }
+        if (nsurv == 0) return 0;
+        counters[1] += nsurv;
+
+        RT_TRY(ctx->d_pi.reserve(nsurv));
+        RT_TRY(ctx->d_pj.reserve(nsurv));
+        RT_TRY(ctx->d_ps.reserve(nsurv));
+        RT_TRY(ctx->d_res.reserve((size_t)nsurv * 4));
+        RT_TRY(ctx->d_var.reserve(nsurv));
+        RT_TRY(ctx->h_surv.reserve((size_t)nsurv * 2));
+        RT_TRY(ctx->h_res.reserve((size_t)nsurv * 4));
+        RT_TRY(ctx->h_var.reserve(nsurv));
+        hipLaunchKernelGGL(expand_pairs_kernel, dim3((nsurv + 255) / 256), dim3(256), 0, st, ctx->d_surv.p, nsurv,
+                           ctx->d_seed.p, ctx->d_cand.p, ctx->d_pi.p, ctx->d_pj.p, ctx->d_ps.p);
+        RT_HIP(hipMemcpyAsync(ctx->h_surv.p, ctx->d_surv.p, (size_t)nsurv * 8, hipMemcpyDeviceToHost, st));
+        RT_TRY(launch_pair_score(ctx, nsurv));
+        counters[4] += 2;
+        RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 16, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)nsurv * 8, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+
+        // pairs whose match list did not fit LDS: rerun through the global-scratch variant
+        std::vector<uint32_t> big;
+        uint32_t big_m = 0;
+        for (uint32_t p = 0; p < nsurv; ++p)
+            if (ctx->h_res.p[4 * (size_t)p] == INT32_MIN) {
+                big.push_back(p);
+                big_m = std::max(big_m, (uint32_t)ctx->h_res.p[4 * (size_t)p + 3]);
+            }
+        if (!big.empty()) {
+            RT_TRY(launch_pair_score_oversize(ctx, big, big_m));
+            counters[4]++;
+            RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 16, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)nsurv * 8, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+        }
+
+        // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic
+        const double t_s = P->t_s, t_v = P->t_v;
+        uint64_t alg_bytes = 0;
+        for (uint32_t p = 0; p < nsurv; ++p) {
+            uint32_t a = ctx->h_surv.p[2 * (size_t)p], c = ctx->h_surv.p[2 * (size_t)p + 1];
+            uint32_t s = a >> 1;
+            const int32_t *r = ctx->h_res.p + 4 * (size_t)p;
+            counters[2] += (uint64_t)r[3];
+            uint32_t li = rlen(seeds[s]), lj = rlen(cands[c]);
+            alg_bytes += 8ull * ((li > (uint32_t)ctx->idx.k ? li - ctx->idx.k : 0) + (lj > (uint32_t)ctx->idx.k ? lj - ctx->idx.k : 0));
+            double mn = (double)std::min<size_t>(li, lj);
+            double score = P->use_hc ? double(r[1]) / mn : double(r[0]) / mn;
+            if (score >= t_s) {
+                if (ctx->h_var.p[p] < t_v) hits.push_back(hit_t{s, c, (uint8_t)(a & 1u)});
+            }
+        }
+        ctx->stats[K_SCORE].bytes += alg_bytes;
+        return 0;
+    }
+
+    // cluster.cpp:67-91
+    cseq get_main_seq(std::vector<cseq> &seqs, double repr_percentile) const {
+        cseq old = seqs[0];
+        std::stable_sort(seqs.begin(), seqs.end(), [](const cseq &a, const cseq &b) { return a.id > b.id; });
+        std::stable_sort(seqs.begin(), seqs.end(), [this](const cseq &a, const cseq &b) { return rlen(a.id) > rlen(b.id); });
+        int nsid = seqs.size() * repr_percentile;
+        cseq ns = seqs[nsid];
+        while (ns.rev != old.rev && (size_t)nsid < seqs.size() - 1) { nsid++; ns = seqs[nsid]; }
+        if ((size_t)nsid == seqs.size() - 1) return old;
+        return ns;
+    }
+
+    // One greedy pass over `items` (local read id compared for each item).  owner[i] = index of
+    // the founder item that absorbed i (owner[i]==i for founders); rev[i] = strand of the match.
+    int greedy_pass(const std::vector<uint32_t> &items, double thr, std::vector<uint32_t> &owner, std::vector<uint8_t> &rev) {
+        RT_TRY(set_threshold(thr));
+        uint32_t m = (uint32_t)items.size();
+        owner.resize(m);
+        rev.assign(m, 0);
+        for (uint32_t i = 0; i < m; ++i) owner[i] = i;
+        static const uint32_t batch = getenv("RATTLE_SEED_BATCH") ? (uint32_t)atoi(getenv("RATTLE_SEED_BATCH")) : 256;
+        std::vector<uint32_t> remaining(m), next, seeds_local, first, cands_local, founders, ffirst;
+        for (uint32_t i = 0; i < m; ++i) remaining[i] = i;
+        std::vector<uint8_t> taken;
+        std::vector<hit_t> hits;
+        while (!remaining.empty()) {
+            counters[3]++;
+            uint32_t B = (uint32_t)std::min<size_t>(batch, remaining.size());
+            // ---- level 1: seeds x seeds
+            seeds_local.resize(B);
+            first.resize(B);
+            for (uint32_t s = 0; s < B; ++s) { seeds_local[s] = items[remaining[s]]; first[s] = s + 1; }
+            founders.clear();
+            taken.assign(B, 0);
+            if (B > 1) {
+                RT_TRY(eval(seeds_local, seeds_local.data(), B, first, thr, hits));
+                // group hits by seed; forward verdict wins over reverse (cluster.cpp:19-40 before :43)
+                std::sort(hits.begin(), hits.end(), [](const hit_t &a, const hit_t &b) {
+                    return a.seed != b.seed ? a.seed < b.seed : (a.cand != b.cand ? a.cand < b.cand : a.rev < b.rev);
+                });
+                size_t h = 0;
+                for (uint32_t s = 0; s < B; ++s) {
+                    while (h < hits.size() && hits[h].seed < s) ++h;
+                    if (taken[s]) continue;
+                    for (size_t q = h; q < hits.size() && hits[q].seed == s; ++q) {
+                        uint32_t c = hits[q].cand;
+                        if (taken[c]) continue;
+                        taken[c] = 1;
+                        owner[remaining[c]] = remaining[s];
+                        rev[remaining[c]] = hits[q].rev;
+                    }
+                }
+            }
+            for (uint32_t s = 0; s < B; ++s) if (!taken[s]) founders.push_back(s);
+            // ---- level 2: founders x rest
+            uint32_t nrest = (uint32_t)remaining.size() - B;
+            next.clear();
+            if (nrest > 0) {
+                cands_local.resize(nrest);
+                for (uint32_t c = 0; c < nrest; ++c) cands_local[c] = items[remaining[B + c]];
+                std::vector<uint32_t> fl(founders.size());
+                ffirst.assign(founders.size(), 0);
+                for (size_t f = 0; f < founders.size(); ++f) fl[f] = seeds_local[founders[f]];
+                RT_TRY(eval(fl, cands_local.data(), nrest, ffirst, thr, hits));
+                std::sort(hits.begin(), hits.end(), [](const hit_t &a, const hit_t &b) {
+                    return a.seed != b.seed ? a.seed < b.seed : (a.cand != b.cand ? a.cand < b.cand : a.rev < b.rev);
+                });
+                taken.assign(nrest, 0);
+                for (const hit_t &q : hits) {          // founders in order; first accepting founder wins
+                    if (taken[q.cand]) continue;
+                    taken[q.cand] = 1;
+                    owner[remaining[B + q.cand]] = remaining[founders[q.seed]];
+                    rev[remaining[B + q.cand]] = q.rev;
+                }
+                for (uint32_t c = 0; c < nrest; ++c) if (!taken[c]) next.push_back(remaining[B + c]);
+            }
+            remaining.swap(next);
+        }
+        return 0;
+    }
+};
+
+int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32_t *subset, uint32_t n_subset,
+                   rattle_cluster_set **out) {
+    driver D;
+    D.ctx = ctx; D.P = P; D.subset = subset;
+    D.n = subset ? n_subset : ctx->idx.n;
+    const uint32_t n = D.n;
+    struct cl { cseq main; std::vector<cseq> seqs; };
+    std::vector<cl> clusters;
+    std::vector<uint32_t> owner;
+    std::vector<uint8_t> rev;
+
+    // ---- initial pass, cluster.cpp:124-166
+    {
+        std::vector<uint32_t> items(n);
+        for (uint32_t i = 0; i < n; ++i) items[i] = i;
+        RT_TRY(D.greedy_pass(items, P->bv_threshold, owner, rev));
+        std::vector<int32_t> slot(n, -1);
+        for (uint32_t i = 0; i < n; ++i)
+            if (owner[i] == i) { slot[i] = (int32_t)clusters.size(); clusters.push_back(cl{{(int32_t)i, 0}, {cseq{(int32_t)i, 0}}}); }
+        for (uint32_t i = 0; i < n; ++i)
+            if (owner[i] != i) clusters[slot[owner[i]]].seqs.push_back(cseq{(int32_t)i, rev[i]});
+        for (auto &c : clusters) c.main = D.get_main_seq(c.seqs, P->repr_percentile);
+    }
+    // ---- merge passes, cluster.cpp:171-256
+    double thr = P->bv_threshold - P->bv_falloff;
+    bool last = false;
+    while (thr >= P->min_bv_threshold || last) {
+        uint32_t nc = (uint32_t)clusters.size();
+        std::vector<uint32_t> items(nc);
+        for (uint32_t i = 0; i < nc; ++i) items[i] = (uint32_t)clusters[i].main.id;     // main_seq.rev ignored (:197)
+        RT_TRY(D.greedy_pass(items, thr, owner, rev));
+        std::vector<cl> merged;
+        std::vector<int32_t> slot(nc, -1);
+        for (uint32_t i = 0; i < nc; ++i)
+            if (owner[i] == i) { slot[i] = (int32_t)merged.size(); merged.push_back(cl{{0, 0}, {}}); merged.back().seqs = clusters[i].seqs; }
+        for (uint32_t i = 0; i < nc; ++i) {
+            if (owner[i] == i) continue;
+            cl &dst = merged[slot[owner[i]]];
+            for (cseq s : clusters[i].seqs) {            // :227-238
+                if (rev[i]) s.rev = !s.rev;
+                dst.seqs.push_back(s);
+            }
+        }
+        for (auto &c : merged) c.main = D.get_main_seq(c.seqs, P->repr_percentile);
+        clusters.swap(merged);
+        if (last) break;
+        thr -= P->bv_falloff;                             // :251-255
+        if (thr < P->min_bv_threshold && !last) { last = true; thr = 0.0; }
+    }
+
+    // ---- flatten
+    rattle_cluster_set *R = (rattle_cluster_set *)calloc(1, sizeof(rattle_cluster_set));
+    size_t nm = 0;
+    for (auto &c : clusters) nm += c.seqs.size();
+    R->n_clusters = (uint32_t)clusters.size();
+    R->main_id = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, clusters.size()));
+    R->main_rev = (uint8_t *)malloc(std::max<size_t>(1, clusters.size()));
+    R->offsets = (uint32_t *)malloc(sizeof(uint32_t) * (clusters.size() + 1));
+    R->member_id = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, nm));
+    R->member_rev = (uint8_t *)malloc(std::max<size_t>(1, nm));
+    uint32_t p = 0;
+    for (size_t c = 0; c < clusters.size(); ++c) {
+        R->main_id[c] = clusters[c].main.id;
+        R->main_rev[c] = clusters[c].main.rev;
+        R->offsets[c] = p;
+        for (auto &s : clusters[c].seqs) { R->member_id[p] = s.id; R->member_rev[p] = s.rev; ++p; }
+    }
+    R->offsets[clusters.size()] = p;
+    memcpy(R->counters, D.counters, sizeof(D.counters));
+    *out = R;
+    return 0;
+}
+
+}  // namespace rattle

@@ -1,0 +1,162 @@
+// Internal declarations shared by the HIP translation units of librattle_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rattle_hip.h"
+
+namespace rattle {
+
+void set_error(const std::string &msg);
+
+#define RT_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            ::rattle::set_error(std::string(#call) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + \
+                                ":" + std::to_string(__LINE__) + ")");                                 \
+            return RATTLE_ERR_HIP;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+#define RT_TRY(call)            \
+    do {                        \
+        int r__ = (call);       \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+// Growable device buffer (never shrinks; contents are not preserved across grow()).
+template <typename T>
+struct dbuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        RT_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Pinned host buffer for D2H results.
+template <typename T>
+struct hbuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        RT_HIP(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+enum { K_KMER = 0, K_FILTER = 1, K_SCORE = 2, K_POA = 3, K_COUNT = 4 };
+
+struct kstat {
+    double ms = 0;
+    uint64_t launches = 0, bytes = 0;
+};
+
+// Device-resident read index (output of kernel K).
+struct read_index {
+    uint32_t n = 0;
+    int k = 0;
+    int both = 0;
+    uint64_t total_bases = 0, total_kmers = 0;
+    std::vector<uint64_t> h_off;      // [n+1] base offsets
+    std::vector<uint64_t> h_koff;     // [n+1] k-mer list offsets (entries)
+    std::vector<uint32_t> h_len;      // [n]
+    dbuf<uint8_t> seq;                // ASCII bases
+    dbuf<uint64_t> off, koff;         // device copies
+    dbuf<uint32_t> len;
+    dbuf<uint32_t> uh;                // forward hashes in POSITION order          [total_kmers]
+    dbuf<uint32_t> kh[2];             // hashes sorted by (hash,pos), per strand     [total_kmers]
+    dbuf<uint32_t> kp[2];             // positions in that order                     [total_kmers]
+    dbuf<uint64_t> bv[2];             // bit-vectors, 64 words per read              [n*64]
+    dbuf<uint32_t> pc[2];             // popcount of each bit-vector                 [n]
+};
+
+}  // namespace rattle
+
+struct rattle_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = true;
+    rattle::kstat stats[rattle::K_COUNT];
+    rattle::read_index idx;
+    // scratch for the filter / score kernels
+    rattle::dbuf<uint32_t> d_seed, d_cand, d_first;
+    rattle::dbuf<uint16_t> d_lut;
+    rattle::dbuf<uint8_t> d_pass;
+    rattle::dbuf<uint32_t> d_surv;          // survivor list (2 words per entry)
+    rattle::dbuf<uint32_t> d_counter;
+    rattle::dbuf<uint32_t> d_pi, d_pj;
+    rattle::dbuf<uint8_t> d_ps;
+    rattle::dbuf<int32_t> d_res;            // per pair: bases, hc, n_dist, n_matches
+    rattle::dbuf<double> d_var;
+    rattle::dbuf<uint32_t> d_scratch;       // global scratch for oversize pairs
+    rattle::hbuf<uint32_t> h_surv;
+    rattle::hbuf<int32_t> h_res;
+    rattle::hbuf<double> h_var;
+    rattle::hbuf<uint32_t> h_counter;
+};
+
+namespace rattle {
+
+// Event-timed launch bracket: records into ctx->stats[which].
+struct ktimer {
+    rattle_ctx *c;
+    int which;
+    uint64_t bytes;
+    ktimer(rattle_ctx *c_, int w, uint64_t b) : c(c_), which(w), bytes(b) {
+        if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~ktimer() {
+        c->stats[which].launches++;
+        c->stats[which].bytes += bytes;
+        if (c->timing) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->stats[which].ms += ms;
+        }
+    }
+};
+
+// kmer_extract.hip
+int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n, int k, int both);
+// bv_filter.hip : device-side seeds/cands already uploaded in ctx->d_seed/d_cand/d_first/d_lut.
+// Writes dense pass bytes (if dense) and/or appends survivors (seed_slot<<1|strand, cand_slot).
+int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fwd_bypass, bool dense, bool list,
+                     uint32_t list_cap);
+// pair_score.hip : pairs in ctx->d_pi/d_pj/d_ps; results in ctx->d_res (4 ints per pair) + ctx->d_var.
+int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs);
+// cluster_driver.cpp
+int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32_t *subset, uint32_t n_subset,
+                   rattle_cluster_set **out);
+
+}  // namespace rattle

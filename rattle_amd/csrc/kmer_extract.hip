@@ -1,0 +1,247 @@
+// Kernel K: per-read k-mer index.  Replaces extract_kmers_from_read,
+// /root/reference/kmer.cpp:6-42 (hash: kmer.hpp:25-40; reverse strand: utils.cpp:15-24).
+//
+// One 256-thread workgroup per (read, strand).  The read is staged in LDS as 2-bit codes,
+// every thread hashes its positions, the (hash<<32|pos) keys are bitonic-sorted in LDS and
+// written back as two coalesced SoA streams (hash, pos).  The 4096-bit 6-mer bit-vector is
+// built with LDS atomics and written as 64 u64 words.
+//
+// HBM traffic per read (algorithmic): L bytes read; per strand (L-k)*8 B list + 512 B
+// bit-vector written, + (L-k)*4 B position-ordered hashes for the forward strand.
+#include "common.h"
+
+namespace rattle {
+
+__device__ __forceinline__ uint32_t base_code(uint8_t c) {
+    // kmer.hpp:25-31: A=0 C=1 T=2 U=2 G=3; anything else is invalid (flagged).
+    switch (c) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'T': case 'U': return 2;
+        case 'G': return 3;
+    }
+    return 4;
+}
+
+// Bitonic sort of P (power of two) u64 keys in LDS by a 256-thread block.
+__device__ void bitonic_sort_lds(uint64_t *key, uint32_t P) {
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                uint32_t lo = 2 * t - (t & (stride - 1));      // index with bit `stride` clear
+                uint32_t hi = lo + stride;
+                bool up = (lo & size) == 0;
+                uint64_t a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Global-memory variant for reads whose list does not fit LDS (one block per read/strand).
+__device__ void bitonic_sort_global(uint64_t *key, uint64_t P) {
+    for (uint64_t size = 2; size <= P; size <<= 1) {
+        for (uint64_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint64_t t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                uint64_t lo = 2 * t - (t & (stride - 1));
+                uint64_t hi = lo + stride;
+                bool up = (lo & size) == 0;
+                uint64_t a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __threadfence_block();
+        }
+    }
+    __syncthreads();
+}
+
+// items: read ids handled by this launch; grid = (n_items, strands).
+// P = padded key count (power of two >= max list length in this launch), keys in dynamic LDS
+// unless gscratch != nullptr (then keys live at gscratch + blockLinear*P).
+__global__ __launch_bounds__(256) void kmer_extract_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                           const uint64_t *__restrict__ koff, const uint32_t *__restrict__ items,
+                                                           int k, uint32_t P, uint32_t Lmax, uint32_t *__restrict__ uh,
+                                                           uint32_t *__restrict__ kh0, uint32_t *__restrict__ kp0,
+                                                           uint32_t *__restrict__ kh1, uint32_t *__restrict__ kp1,
+                                                           uint64_t *__restrict__ bv0, uint64_t *__restrict__ bv1,
+                                                           uint32_t *__restrict__ pc0, uint32_t *__restrict__ pc1,
+                                                           uint64_t *gscratch, uint32_t *__restrict__ bad_flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t r = items[blockIdx.x];
+    const int strand = blockIdx.y;
+    const uint64_t o = off[r];
+    const uint32_t L = (uint32_t)(off[r + 1] - o);
+    const uint32_t nk = L > (uint32_t)k ? L - k : 0;
+    const uint32_t nb = L > 6 ? L - 6 : 0;
+
+    // LDS carve: [bitset 128 u32][codes Lmax bytes, padded to 16][keys P u64 (if in LDS)]
+    uint32_t *bits = (uint32_t *)smem;
+    uint8_t *code = smem + 512;
+    uint64_t *key = gscratch ? gscratch + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * P
+                             : (uint64_t *)(smem + 512 + ((Lmax + 15u) & ~15u));
+
+    for (uint32_t t = threadIdx.x; t < 128; t += blockDim.x) bits[t] = 0;
+    bool bad = false;
+    for (uint32_t p = threadIdx.x; p < L; p += blockDim.x) {
+        // forward: code of seq[p]; reverse strand (reverse_complement): complement of seq[L-1-p],
+        // complement code = code ^ 2 (A<->T, C<->G, U->A).
+        uint32_t c = strand == 0 ? base_code(seq[o + p]) : base_code(seq[o + (L - 1 - p)]);
+        if (c > 3) { bad = true; c = 0; }
+        code[p] = (uint8_t)(strand == 0 ? c : (c ^ 2u));
+    }
+    if (bad) atomicOr(bad_flag, 1u);
+    __syncthreads();
+
+    // hashes: rolling would serialise; each thread packs k codes (k <= 16).
+    const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+        uint64_t kv = ~0ull;
+        if (p < nk) {
+            uint32_t h = 0;
+            for (int i = 0; i < k; ++i) h = (h << 2) | code[p + i];
+            h &= kmask;
+            kv = ((uint64_t)h << 32) | p;
+            if (strand == 0) uh[koff[r] + p] = h;
+        }
+        key[p] = kv;
+    }
+    for (uint32_t p = threadIdx.x; p < nb; p += blockDim.x) {       // kmer.cpp:28-36, always 6-mers
+        uint32_t h = 0;
+        for (int i = 0; i < 6; ++i) h = (h << 2) | code[p + i];
+        atomicOr(&bits[h >> 5], 1u << (h & 31));
+    }
+    if (gscratch) { __threadfence_block(); bitonic_sort_global(key, P); }
+    else bitonic_sort_lds(key, P);
+
+    uint32_t *kh = strand == 0 ? kh0 : kh1;
+    uint32_t *kp = strand == 0 ? kp0 : kp1;
+    const uint64_t ko = koff[r];
+    for (uint32_t p = threadIdx.x; p < nk; p += blockDim.x) {
+        uint64_t kv = key[p];
+        kh[ko + p] = (uint32_t)(kv >> 32);
+        kp[ko + p] = (uint32_t)kv;
+    }
+    uint64_t *bv = strand == 0 ? bv0 : bv1;
+    uint32_t *pc = strand == 0 ? pc0 : pc1;
+    if (threadIdx.x < 64) {
+        uint64_t w = (uint64_t)bits[2 * threadIdx.x] | ((uint64_t)bits[2 * threadIdx.x + 1] << 32);
+        bv[(uint64_t)r * 64 + threadIdx.x] = w;
+        uint32_t c = __popcll(w);
+        for (int s = 32; s > 0; s >>= 1) c += __shfl_xor(c, s, 64);
+        if (threadIdx.x == 0) pc[r] = c;
+    }
+}
+
+static uint32_t pow2ceil(uint32_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n, int k, int both) {
+    if (k < 1 || k > 16) { set_error("kmer size must be in [1,16] (main.cpp:223)"); return RATTLE_ERR_ARG; }
+    read_index &X = ctx->idx;
+    X.n = n; X.k = k; X.both = both ? 1 : 0;
+    X.h_off.assign(off, off + n + 1);
+    X.h_koff.resize(n + 1);
+    X.h_len.resize(n);
+    uint64_t ko = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t L = off[i + 1] - off[i];
+        if (L > 0x7FFFFFF0ull) { set_error("read too long"); return RATTLE_ERR_ARG; }
+        X.h_len[i] = (uint32_t)L;
+        X.h_koff[i] = ko;
+        ko += L > (uint64_t)k ? L - k : 0;
+    }
+    X.h_koff[n] = ko;
+    X.total_bases = off[n] - off[0];
+    X.total_kmers = ko;
+    if (n == 0) return 0;
+    if (off[0] != 0) { set_error("offsets[0] must be 0"); return RATTLE_ERR_ARG; }
+
+    RT_TRY(X.seq.reserve(X.total_bases + 16));
+    RT_TRY(X.off.reserve(n + 1));
+    RT_TRY(X.koff.reserve(n + 1));
+    RT_TRY(X.len.reserve(n));
+    RT_TRY(X.uh.reserve(ko + 1));
+    const int ns = both ? 2 : 1;
+    for (int s = 0; s < ns; ++s) {
+        RT_TRY(X.kh[s].reserve(ko + 1));
+        RT_TRY(X.kp[s].reserve(ko + 1));
+        RT_TRY(X.bv[s].reserve((size_t)n * 64));
+        RT_TRY(X.pc[s].reserve(n));
+    }
+    hipStream_t st = ctx->stream;
+    RT_HIP(hipMemcpyAsync(X.seq.p, seq, X.total_bases, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(X.off.p, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(X.koff.p, X.h_koff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(X.len.p, X.h_len.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+
+    // Size classes by padded list length; LDS holds keys up to 8192 entries (64 KiB + codes).
+    const uint32_t LDS_MAX_P = 8192;
+    std::vector<std::vector<uint32_t>> cls(33);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t nk = X.h_len[i] > (uint32_t)k ? X.h_len[i] - k : 0;
+        uint32_t P = pow2ceil(nk < 64 ? 64 : nk);
+        int c = 0;
+        while ((1u << c) < P) ++c;
+        cls[c].push_back(i);
+    }
+    dbuf<uint32_t> d_items;
+    dbuf<uint32_t> d_bad;
+    dbuf<uint64_t> d_gs;
+    RT_TRY(d_items.reserve(n));
+    RT_TRY(d_bad.reserve(1));
+    RT_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), st));
+    int rc = 0;
+    {
+        uint64_t bytes = X.total_bases + (uint64_t)ns * (ko * 8 + (uint64_t)n * 512) + ko * 4;
+        ktimer T(ctx, K_KMER, bytes);
+        size_t done = 0;
+        for (int c = 0; c <= 32 && rc == 0; ++c) {
+            if (cls[c].empty()) continue;
+            uint32_t P = 1u << c;
+            uint32_t cnt = (uint32_t)cls[c].size();
+            uint32_t Lmax = 0;
+            for (uint32_t r : cls[c]) Lmax = X.h_len[r] > Lmax ? X.h_len[r] : Lmax;
+            hipError_t e = hipMemcpyAsync(d_items.p + done, cls[c].data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
+            bool in_lds = P <= LDS_MAX_P;
+            size_t shm = 512 + ((Lmax + 15u) & ~15u) + (in_lds ? (size_t)P * 8 : 0);
+            if (shm > 160 * 1024) { set_error("read too long for the LDS code buffer"); rc = RATTLE_ERR_ARG; break; }
+            // chunk launches so the global scratch for oversize reads stays bounded
+            uint32_t chunk = in_lds ? cnt : (uint32_t)std::max<uint64_t>(1, (1ull << 28) / ((uint64_t)P * ns));
+            for (uint32_t b = 0; b < cnt && rc == 0; b += chunk) {
+                uint32_t m = std::min(chunk, cnt - b);
+                uint64_t *gs = nullptr;
+                if (!in_lds) {
+                    rc = d_gs.reserve((size_t)m * ns * P);
+                    if (rc) break;
+                    gs = d_gs.p;
+                }
+                if (shm > 64 * 1024)
+                    (void)hipFuncSetAttribute((const void *)kmer_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                hipLaunchKernelGGL(kmer_extract_kernel, dim3(m, ns), dim3(256), shm, st, X.seq.p, X.off.p, X.koff.p,
+                                   d_items.p + done + b, k, P, Lmax, X.uh.p, X.kh[0].p, X.kp[0].p, X.kh[1].p, X.kp[1].p,
+                                   X.bv[0].p, X.bv[1].p, X.pc[0].p, X.pc[1].p, gs, d_bad.p);
+                e = hipGetLastError();
+                if (e != hipSuccess) { set_error(std::string("kmer_extract launch: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
+                if (!in_lds) (void)hipStreamSynchronize(st);     // scratch is reused by the next chunk
+            }
+            done += cnt;
+        }
+    }
+    uint32_t bad = 0;
+    hipError_t e = hipMemcpyAsync(&bad, d_bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    d_items.release(); d_bad.release(); d_gs.release();
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error(std::string("kmer_extract: ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
+    if (bad) { set_error("read contains a base outside A/C/G/T/U (undefined in the reference, kmer.hpp:36)"); return RATTLE_ERR_ARG; }
+    return 0;
+}
+
+}  // namespace rattle

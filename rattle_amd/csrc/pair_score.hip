@@ -1,0 +1,227 @@
+// Kernel B: full pair comparison.  Replaces get_common_kmers (/root/reference/kmer.cpp:45-67),
+// calc_similarity (/root/reference/similarity.cpp:4-97) and var (/root/reference/utils.cpp:36-55)
+// as called from cluster_together (/root/reference/cluster.cpp:20-34,44-58).
+//
+// One wavefront per (read i, read j, strand) pair.
+//  stage 1 (64 lanes): the reference merge-joins two (hash,pos)-sorted lists and then sorts
+//    the matches by (pos1,pos2).  Here read i's hashes are walked in POSITION order (64
+//    positions per step) and each lane binary-searches read j's sorted hash list (staged in
+//    LDS); equal-hash entries of j are already pos-ascending, so a wave prefix-sum over the
+//    per-lane hit counts emits the matches directly in (pos1,pos2) order -- same multiset
+//    (full cross product on repeated hashes, kmer.cpp:56-61), same order, no sort.
+//  stage 2 (lane 0): the reference's patience LIS with ceil-mid search, chain
+//    reconstruction, co-linearity walk, and the two-pass variance in IEEE double with the
+//    reference's operation order (compiled with -ffp-contract=off).
+//
+// Algorithmic HBM bytes per comparison: 8*(nK_i + nK_j).
+#include "common.h"
+
+namespace rattle {
+
+struct ps_args {
+    const uint32_t *uh;          // forward hashes, position order
+    const uint64_t *koff;
+    const uint32_t *kh[2];
+    const uint32_t *kp[2];
+    const uint32_t *pi, *pj;
+    const uint8_t *ps;
+    uint32_t n_pairs;
+    int k;
+    uint32_t bcap, mcap;         // LDS capacities (entries)
+    int32_t *res;                // [n_pairs][4] bases, hc_bases, n_dist, n_matches
+    double *var;
+    uint32_t *gscratch;          // oversize path: 5*gstride words per pair, or nullptr
+    uint64_t gstride;
+    const uint32_t *remap;       // oversize path: launch slot -> pair index, or nullptr
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t pr = A.remap ? A.remap[slot] : slot;
+    const uint32_t ri = A.pi[pr], rj = A.pj[pr];
+    const int strand = A.ps[pr];
+    const uint32_t nA = (uint32_t)(A.koff[ri + 1] - A.koff[ri]);
+    const uint32_t nB = (uint32_t)(A.koff[rj + 1] - A.koff[rj]);
+    const uint32_t *__restrict__ ah = A.uh + A.koff[ri];
+    const uint32_t *__restrict__ bh_g = A.kh[strand] + A.koff[rj];
+    const uint32_t *__restrict__ bp_g = A.kp[strand] + A.koff[rj];
+
+    // LDS carve: [B hashes bcap][pos1 mcap][pos2 mcap][m mcap+1 (+pad)][tv mcap+1 (+pad)][p mcap]
+    uint32_t *s_bh = lds;
+    uint32_t cap;
+    uint32_t *pos1, *pos2, *m, *tv, *pp;
+    if (A.gscratch) {
+        cap = (uint32_t)A.gstride;
+        uint32_t *g = A.gscratch + (uint64_t)slot * 5 * (A.gstride + 2);
+        pos1 = g; pos2 = pos1 + cap + 2; m = pos2 + cap + 2; tv = m + cap + 2; pp = tv + cap + 2;
+    } else {
+        cap = A.mcap;
+        pos1 = lds + A.bcap; pos2 = pos1 + cap; m = pos2 + cap; tv = m + cap + 2; pp = tv + cap + 2;
+    }
+    const bool b_lds = nB <= A.bcap;
+    if (b_lds) {
+        for (uint32_t t = lane; t < nB; t += 64) s_bh[t] = bh_g[t];
+        __syncthreads();
+    }
+    const uint32_t *bh = b_lds ? (const uint32_t *)s_bh : bh_g;
+
+    // ---- stage 1: matches in (pos1,pos2) order --------------------------------------
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < nA; base += 64) {
+        uint32_t p1 = base + lane;
+        uint32_t cnt = 0, lo = 0;
+        if (p1 < nA && nB > 0) {
+            uint32_t h = ah[p1];
+            uint32_t a = 0, b = nB;                    // lower_bound
+            while (a < b) {
+                uint32_t mid = (a + b) >> 1;
+                if (bh[mid] < h) a = mid + 1; else b = mid;
+            }
+            lo = a;
+            uint32_t hi = lo;
+            while (hi < nB && bh[hi] == h) ++hi;
+            cnt = hi - lo;
+        }
+        uint32_t incl = wave_incl_scan(cnt, lane);
+        uint32_t tot = __shfl(incl, 63, 64);
+        if (total + tot <= cap) {
+            uint32_t at = total + incl - cnt;
+            for (uint32_t t = 0; t < cnt; ++t) { pos1[at + t] = p1; pos2[at + t] = bp_g[lo + t]; }
+        }
+        total += tot;
+    }
+    int32_t *out = A.res + (uint64_t)pr * 4;
+    if (total > cap) {                                  // oversize: host reruns with global scratch
+        if (lane == 0) { out[0] = INT32_MIN; out[1] = 0; out[2] = 0; out[3] = (int32_t)total; A.var[pr] = 0.0; }
+        return;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+
+    // ---- stage 2: similarity.cpp:10-31 patience LIS (strict on pos2, ceil-mid search) ---
+    const int M = (int)total;
+    const int k = A.k;
+    int l = 0;
+    m[0] = 0;
+    for (int i = 0; i < M; ++i) {
+        uint32_t x = pos2[i];
+        int lo = 1, hi = l;
+        while (lo <= hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (tv[mid] < x) lo = mid + 1; else hi = mid - 1;     // tv[mid] == pos2[m[mid]]
+        }
+        pp[i] = m[lo - 1];
+        m[lo] = (uint32_t)i;
+        tv[lo] = x;
+        if (lo > l) l = lo;
+    }
+    int bases = 0, hc = 0, nd = 0;
+    double variance = 0.0;
+    if (l > 0) {
+        // :37-44 chain reconstruction; chain indices overwrite m[0..l-1] (m[l] is read first)
+        uint32_t cur = m[l];
+        for (int i = l - 1; i >= 0; --i) { uint32_t nx = pp[cur]; m[i] = cur; cur = nx; }
+        // :52-85 walk; distances go to tv[] (free now)
+        int kf = (int)pos1[m[0]], ks = (int)pos2[m[0]];          // last KEPT element
+        int prev_s = ks;                                         // previous CHAIN element (.second)
+        bases = k; hc = k;
+        double sum = 0.0;
+        for (int i = 1; i < l; ++i) {
+            int f = (int)pos1[m[i]], s = (int)pos2[m[i]];
+            int d1 = f - kf, d2 = s - ks;
+            if ((d1 < k && d2 < k) || (d1 >= k && d2 >= k)) {
+                bases += k;
+                int ex = k - (s - prev_s);
+                if (ex > 0) bases -= ex;
+                int dist = d2 - d1;
+                tv[nd++] = (uint32_t)dist;
+                sum += (double)dist;
+                if (dist < 10) { hc += k; if (ex > 0) hc -= ex; }
+                kf = f; ks = s;
+            }
+            prev_s = s;
+        }
+        // utils.cpp:36-55
+        if (nd > 0) {
+            double mean = sum / (double)nd;
+            double ss = 0.0, comp = 0.0;
+            for (int i = 0; i < nd; ++i) {
+                double d = (double)(int)tv[i] - mean;
+                ss += d * d;
+                comp += d;
+            }
+            variance = (ss - comp * comp / (double)nd) / (double)(nd - 1);
+        }
+    }
+    out[0] = bases; out[1] = hc; out[2] = nd; out[3] = M;
+    A.var[pr] = variance;
+}
+
+int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs) {
+    if (n_pairs == 0) return 0;
+    read_index &X = ctx->idx;
+    ps_args A;
+    A.uh = X.uh.p; A.koff = X.koff.p;
+    A.kh[0] = X.kh[0].p; A.kp[0] = X.kp[0].p; A.kh[1] = X.kh[1].p; A.kp[1] = X.kp[1].p;
+    A.pi = ctx->d_pi.p; A.pj = ctx->d_pj.p; A.ps = ctx->d_ps.p;
+    A.n_pairs = n_pairs; A.k = X.k;
+    A.bcap = 2048; A.mcap = 512;
+    A.res = ctx->d_res.p; A.var = ctx->d_var.p;
+    A.gscratch = nullptr; A.gstride = 0; A.remap = nullptr;
+    size_t shm = (A.bcap + 5 * (size_t)A.mcap + 8) * 4;
+    // algorithmic bytes are accounted by the caller (needs the pair list on the host)
+    ktimer T(ctx, K_SCORE, 0);
+    hipLaunchKernelGGL(pair_score_kernel, dim3(n_pairs), dim3(64), shm, ctx->stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("pair_score launch: ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
+    return 0;
+}
+
+// Second pass for pairs whose match count exceeded the LDS capacity: same kernel, arrays
+// in a global scratch slab sized for the largest count.  `slots` (host) lists pair indices.
+int launch_pair_score_oversize(rattle_ctx *ctx, const std::vector<uint32_t> &slots, uint32_t max_matches) {
+    if (slots.empty()) return 0;
+    read_index &X = ctx->idx;
+    dbuf<uint32_t> d_remap;
+    RT_TRY(d_remap.reserve(slots.size()));
+    RT_HIP(hipMemcpyAsync(d_remap.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t stride = max_matches;
+    // bound the slab: process in chunks of at most ~2 GiB
+    uint64_t per = 5 * (stride + 2) * 4;
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (2ull << 30) / per);
+    RT_TRY(ctx->d_scratch.reserve((size_t)std::min<uint64_t>(chunk, slots.size()) * 5 * (stride + 2)));
+    int rc = 0;
+    for (size_t b = 0; b < slots.size() && rc == 0; b += chunk) {
+        uint32_t m = (uint32_t)std::min<size_t>(chunk, slots.size() - b);
+        ps_args A;
+        A.uh = X.uh.p; A.koff = X.koff.p;
+        A.kh[0] = X.kh[0].p; A.kp[0] = X.kp[0].p; A.kh[1] = X.kh[1].p; A.kp[1] = X.kp[1].p;
+        A.pi = ctx->d_pi.p; A.pj = ctx->d_pj.p; A.ps = ctx->d_ps.p;
+        A.n_pairs = m; A.k = X.k;
+        A.bcap = 2048; A.mcap = 0;
+        A.res = ctx->d_res.p; A.var = ctx->d_var.p;
+        A.gscratch = ctx->d_scratch.p; A.gstride = stride; A.remap = d_remap.p + b;
+        ktimer T(ctx, K_SCORE, 0);
+        hipLaunchKernelGGL(pair_score_kernel, dim3(m), dim3(64), (A.bcap + 8) * 4, ctx->stream, A);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error(std::string("pair_score(oversize) launch: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    d_remap.release();
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error(std::string("pair_score(oversize): ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
+    return 0;
+}
+
+}  // namespace rattle
