@@ -132,6 +132,49 @@ int rattle_hip_poa_msa(rattle_ctx *ctx, const uint8_t *seq_concat, const uint64_
                        const uint32_t *pack_first, uint32_t n_packs, rattle_msa_set **out);
 void rattle_hip_msa_set_free(rattle_msa_set *ms);
 
+
+/* ------------------------------------------------------------------------------------
+ * a14-a20  correct_reads   /root/reference/correct.cpp:311-563 (signature correct.hpp:44)
+ * Pack building (strided split, in-place reverse complement of `rev` members), POA #1 over
+ * the raw reads of every pack, fix_msa_ends, column vote + per-read correction, POA #2 over
+ * the corrected reads, pack consensus, POA #3 over the pack consensi of multi-pack clusters.
+ * All POAs of one stage run in a single device launch; the post-MSA logic (correct.cpp:32-309)
+ * runs on host threads, one pack per task, in the reference's double arithmetic.
+ * Reads are given in FILE order with qualities (main.cpp:386); clusters index them by seq_id.
+ * Outputs follow the reference's single-thread order: packs in queue order, pack consensi
+ * collected in pack order (the reference's multi-thread run uses completion order).
+ * Headers are not handled here: the caller derives them from read_id / cluster_id / gene_id.
+ */
+typedef struct {
+    double min_occ, gap_occ, err_ratio;   /* 0.3, 0.3, 30.0 */
+    int split, min_reads;                 /* 200, 5 */
+    int n_threads;                        /* host threads for the post-MSA logic; 0 = all cores */
+    char vote_order[8];                   /* column-vote tie order, 6 symbols; "" = "U-GTCA", the
+                                             iteration order of the reference's unordered_map
+                                             (correct.cpp:105-110,174) under libstdc++ */
+} rattle_correct_params;
+
+typedef struct {
+    uint32_t n;
+    int32_t *read_id;       /* original read index, or -1 for a consensus */
+    int32_t *cluster_id;    /* index of the cluster in the input cluster set */
+    int32_t *n_reads;       /* consensi: reads summed over the cluster's packs; else 0 */
+    uint64_t *off;          /* [n+1] */
+    char *seq;
+    char *qual;
+} rattle_read_set;
+
+typedef struct {
+    rattle_read_set corrected, uncorrected, consensi;
+    uint64_t counters[8];   /* DP cells, alignments, packs, ... */
+} rattle_correction;
+
+int rattle_hip_correct_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const uint8_t *qual_concat,
+                             const uint64_t *offsets, uint32_t n_reads, uint32_t n_clusters,
+                             const uint32_t *cluster_offsets, const int32_t *member_id, const uint8_t *member_rev,
+                             const rattle_correct_params *params, rattle_correction **out);
+void rattle_hip_correction_free(rattle_correction *c);
+
 /* ------------------------------------------------------------------------------------
  * Per-kernel timing measured with HIP events on the stream the kernels run on.
  * kernel: 0 kmer_extract, 1 bv_filter, 2 pair_score, 3 poa_align.  Accumulated since

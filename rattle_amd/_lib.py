@@ -25,6 +25,21 @@ class ClusterSet(C.Structure):
                 ("member_rev", C.POINTER(C.c_uint8)), ("counters", C.c_uint64 * 8)]
 
 
+class CorrectParams(C.Structure):
+    _fields_ = [("min_occ", C.c_double), ("gap_occ", C.c_double), ("err_ratio", C.c_double), ("split", C.c_int),
+                ("min_reads", C.c_int), ("n_threads", C.c_int), ("vote_order", C.c_char * 8)]
+
+
+class ReadSet(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("read_id", C.POINTER(C.c_int32)), ("cluster_id", C.POINTER(C.c_int32)),
+                ("n_reads", C.POINTER(C.c_int32)), ("off", C.POINTER(C.c_uint64)), ("seq", C.POINTER(C.c_char)),
+                ("qual", C.POINTER(C.c_char))]
+
+
+class Correction(C.Structure):
+    _fields_ = [("corrected", ReadSet), ("uncorrected", ReadSet), ("consensi", ReadSet), ("counters", C.c_uint64 * 8)]
+
+
 class MsaSet(C.Structure):
     _fields_ = [("n_packs", C.c_uint32), ("width", C.POINTER(C.c_uint32)), ("row_offset", C.POINTER(C.c_uint64)),
                 ("rows", C.POINTER(C.c_char)), ("counters", C.c_uint64 * 8)]
@@ -49,6 +64,9 @@ SIGNATURES = {
     "rattle_hip_cluster_set_free": (None, [_P(ClusterSet)]),
     "rattle_hip_poa_msa": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint32, _u32p, C.c_uint32, _P(_P(MsaSet))]),
     "rattle_hip_msa_set_free": (None, [_P(MsaSet)]),
+    "rattle_hip_correct_reads": (C.c_int, [C.c_void_p, _u8p, _u8p, _u64p, C.c_uint32, C.c_uint32, _u32p, _i32p, _u8p,
+                                           _P(CorrectParams), _P(_P(Correction))]),
+    "rattle_hip_correction_free": (None, [_P(Correction)]),
     "rattle_hip_kernel_stats": (C.c_int, [C.c_void_p, C.c_int, _f64p, _u64p, _u64p]),
     "rattle_hip_kernel_stats_reset": (C.c_int, [C.c_void_p]),
 }

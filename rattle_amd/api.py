@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import ClusterParams, ClusterSet, MsaSet, check
+from ._lib import ClusterParams, ClusterSet, Correction, CorrectParams, MsaSet, check
 
 K_KMER, K_FILTER, K_SCORE, K_POA = 0, 1, 2, 3
 
@@ -172,6 +172,43 @@ class Context:
             res.append(rows)
         return res, width, counters
 
+    # a14-a20
+    def correct_reads(self, seqs: Sequence[bytes], quals: Sequence[bytes], clusters, min_occ=0.3, gap_occ=0.3,
+                      err_ratio=30.0, split=200, min_reads=5, n_threads=0, vote_order: bytes = b""):
+        """correct_reads (correct.hpp:44).  `clusters` in rattle_amd.hps list form (ids index `seqs`).
+        Returns dict of three record lists: (read_id, cluster_id, n_reads, seq, qual)."""
+        cat, off = pack_reads(seqs)
+        qcat, qoff = pack_reads(quals)
+        assert np.array_equal(off, qoff), "sequence and quality lengths differ"
+        coff = np.zeros(len(clusters) + 1, np.uint32)
+        coff[1:] = np.cumsum([len(m) for _, m in clusters])
+        mid = np.array([s[0] for _, m in clusters for s in m], np.int32)
+        mrev = np.array([s[1] for _, m in clusters for s in m], np.uint8)
+        if len(mid) == 0:
+            mid = np.zeros(1, np.int32); mrev = np.zeros(1, np.uint8)
+        P = CorrectParams(min_occ, gap_occ, err_ratio, split, min_reads, n_threads, vote_order)
+        out = C.POINTER(Correction)()
+        check(self.lib.rattle_hip_correct_reads(self.h, _ptr(cat, C.c_uint8), _ptr(qcat, C.c_uint8), _ptr(off, C.c_uint64),
+                                                len(seqs), len(clusters), _ptr(coff, C.c_uint32), _ptr(mid, C.c_int32),
+                                                _ptr(mrev, C.c_uint8), C.byref(P), C.byref(out)))
+        R = out.contents
+
+        def unpack(S):
+            n = S.n
+            o = np.ctypeslib.as_array(S.off, (n + 1,)).copy()
+            tot = int(o[n])
+            sq = C.string_at(S.seq, tot); ql = C.string_at(S.qual, tot)
+            rid = np.ctypeslib.as_array(S.read_id, (max(n, 1),))[:n]
+            cid = np.ctypeslib.as_array(S.cluster_id, (max(n, 1),))[:n]
+            nr = np.ctypeslib.as_array(S.n_reads, (max(n, 1),))[:n]
+            return [(int(rid[i]), int(cid[i]), int(nr[i]), sq[int(o[i]):int(o[i + 1])], ql[int(o[i]):int(o[i + 1])])
+                    for i in range(n)]
+
+        res = {"corrected": unpack(R.corrected), "uncorrected": unpack(R.uncorrected), "consensi": unpack(R.consensi),
+               "counters": np.array(list(R.counters), dtype=np.uint64)}
+        self.lib.rattle_hip_correction_free(out)
+        return res
+
     def kernel_stats(self, kernel: int):
         ms = C.c_double(); n = C.c_uint64(); b = C.c_uint64()
         check(self.lib.rattle_hip_kernel_stats(self.h, kernel, C.byref(ms), C.byref(n), C.byref(b)))
@@ -218,3 +255,30 @@ def cluster_command(ctx: Context, seqs: Sequence[bytes], ann: Sequence[int], *, 
         for im, imem in sub.as_list():
             out.append(((sann[ids[im[0]]], im[1], gi), [(sann[ids[s[0]]], s[1], gi) for s in imem]))
     return out, counters
+
+
+def correct_command(ctx: Context, headers: Sequence[bytes], seqs: Sequence[bytes], quals: Sequence[bytes], clusters, *,
+                    min_occ=0.3, gap_occ=0.3, split=200, min_reads=5, n_threads=0, vote_order=b""):
+    """`rattle correct` after input parsing (main.cpp:396-408): returns the three FASTQ texts
+    (corrected, uncorrected, consensi) with the headers correct.cpp:348-353,540-549 builds
+    (no -l labels: `labels=` is empty)."""
+    res = ctx.correct_reads(seqs, quals, clusters, min_occ, gap_occ, 30.0, split, min_reads, n_threads, vote_order)
+    gene_mode = len(clusters) == 0 or clusters[0][0][2] == -1
+
+    def tag(cid):
+        gid = clusters[cid][0][2]
+        if gid == -1:
+            return b",gene_cluster_%d" % cid
+        return b",gene_cluster_%d,transcript_cluster_%d" % (gid, cid)
+
+    def fq(recs):
+        return b"".join(b"%s%s\n%s\n+\n%s\n" % (headers[r[0]], tag(r[1]), r[3], r[4]) for r in recs)
+
+    cons = []
+    for rid, cid, nr, s, q in res["consensi"]:
+        if gene_mode:
+            h = b"@gene_cluster_%d reads=%d labels=" % (cid, nr)
+        else:
+            h = b"@transcript_cluster_%d gene_cluster_%d reads=%d labels=" % (cid, clusters[cid][0][2], nr)
+        cons.append(b"%s\n%s\n+\n%s\n" % (h, s, q))
+    return fq(res["corrected"]), fq(res["uncorrected"]), b"".join(cons), res["counters"]

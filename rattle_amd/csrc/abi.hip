@@ -14,6 +14,10 @@ int launch_pair_score_oversize(rattle_ctx *ctx, const std::vector<uint32_t> &slo
 int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n_seqs, const uint32_t *pack_first,
                 uint32_t n_packs, rattle_msa_set **out);
 
+int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n_reads,
+                   uint32_t n_clusters, const uint32_t *coff, const int32_t *mid, const uint8_t *mrev,
+                   const rattle_correct_params *P, rattle_correction **out);
+
 }  // namespace rattle
 
 using namespace rattle;
@@ -188,6 +192,30 @@ void rattle_hip_msa_set_free(rattle_msa_set *ms) {
     if (!ms) return;
     free(ms->width); free(ms->row_offset); free(ms->rows);
     free(ms);
+}
+
+int rattle_hip_correct_reads(rattle_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n_reads,
+                             uint32_t n_clusters, const uint32_t *coff, const int32_t *mid, const uint8_t *mrev,
+                             const rattle_correct_params *P, rattle_correction **out) {
+    if (!c || !off || !P || !out || (n_clusters && (!coff || !mid || !mrev)) || (n_reads && (!seq || !qual))) {
+        set_error("null argument");
+        return RATTLE_ERR_ARG;
+    }
+    *out = nullptr;
+    RT_HIP(hipSetDevice(c->device));
+    int rc = correct_driver(c, seq, qual, off, n_reads, n_clusters, coff, mid, mrev, P, out);
+    if (rc != 0 && *out) { rattle_hip_correction_free(*out); *out = nullptr; }
+    return rc;
+}
+
+static void free_set(rattle_read_set &s) {
+    free(s.read_id); free(s.cluster_id); free(s.n_reads); free(s.off); free(s.seq); free(s.qual);
+}
+
+void rattle_hip_correction_free(rattle_correction *r) {
+    if (!r) return;
+    free_set(r->corrected); free_set(r->uncorrected); free_set(r->consensi);
+    free(r);
 }
 
 int rattle_hip_kernel_stats(rattle_ctx *c, int kernel, double *ms, uint64_t *launches, uint64_t *bytes) {

@@ -1,0 +1,48 @@
+"""Parity of the HIP `correct` path (pack builder + kernel C x3 + post-MSA host logic) with the
+oracle and with the reference's shipped consensi fixture."""
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from rattle_amd import hps, synth
+from rattle_amd.api import cluster_command, correct_command
+
+pytestmark = pytest.mark.gpu
+
+
+def test_correct_synthetic_cdna_matches_oracle(gpu_ctx, oracle):
+    """cluster (both strands) then correct on 700 synthetic reads; split=40 forces multi-pack
+    clusters (POA #3) and reverse-strand members exercise the in-place reverse complement."""
+    seqs, quals, _, _ = synth.reads(700, 5, 1, True, seed=8)
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    assert any(s[1] for _, mem in clusters for s in mem)
+    assert any(len(mem) > 40 for _, mem in clusters)
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=40)
+    want = oracle.correct(headers, seqs, quals, hps.encode(clusters), split=40)
+    assert got[0] == want[0], "corrected.fq differs"
+    assert got[1] == want[1], "uncorrected.fq differs"
+    assert got[2] == want[2], "consensi.fq differs"
+    assert int(got[3][0]) == int(want[3][0])           # DP cells, exact
+
+
+def test_correct_toyset_subset_matches_reference_fixture(gpu_ctx, toyset, toyset_clusters):
+    """40 toyset clusters (6..200 reads) against toyset/rna/output/consensi.fq, with the old
+    fixture build's vote order (see tests/test_oracle_correct.py)."""
+    lines = gzip.open(os.path.join(GOLDEN, "toyset_rna.consensi.fq.gz"), "rt").read().split("\n")
+    want = {}
+    for i in range(0, len(lines) - 1, 4):
+        want[int(re.match(r"@cluster_(\d+) ", lines[i]).group(1))] = lines[i + 1]
+    sizes = sorted((len(toyset_clusters[c][1]), c) for c in want if len(toyset_clusters[c][1]) <= 200)
+    cids = sorted(c for _, c in sizes[::4])[:40] + [sizes[-1][1]]
+    sub = [toyset_clusters[c] for c in cids]
+    headers = [r[0] for r in toyset]; seqs = [r[1] for r in toyset]; quals = [r[2] for r in toyset]
+    res = gpu_ctx.correct_reads(seqs, quals, sub, vote_order=b"U-GTAC")
+    got = {cids[r[1]]: r[3].decode() for r in res["consensi"]}
+    assert set(got) == set(cids)
+    bad = [c for c in cids if got[c] != want[c]]
+    assert not bad, bad
