@@ -16,11 +16,11 @@ for _a, _b in zip(b"ACGT", b"TGCA"):
     _COMP[_a] = _b
 
 
-def transcriptome(genes: int, isoforms: int, seed: int = 20260928):
+def transcriptome(genes: int, isoforms: int, seed: int = 20260928, exon=(80, 300)):
     rng = np.random.default_rng(seed)
     tx, tx_gene = [], []
     for g in range(genes):
-        exons = [_ACGT[rng.integers(0, 4, rng.integers(80, 301))] for _ in range(8)]
+        exons = [_ACGT[rng.integers(0, 4, rng.integers(exon[0], exon[1] + 1))] for _ in range(8)]
         seen = set()
         tries = 0
         while len(seen) < isoforms and tries < 100:
@@ -38,9 +38,9 @@ def transcriptome(genes: int, isoforms: int, seed: int = 20260928):
 
 
 def reads(n: int, genes: int, isoforms: int = 1, both_strands: bool = True, seed: int = 20260929,
-          tx_seed: int = 20260928, sub=0.04, ins=0.03, dele=0.03):
+          tx_seed: int = 20260928, sub=0.04, ins=0.03, dele=0.03, exon=(80, 300)):
     """Returns (seqs: list[bytes], quals: list[bytes], tx_id: ndarray, strand: ndarray)."""
-    tx, _ = transcriptome(genes, isoforms, tx_seed)
+    tx, _ = transcriptome(genes, isoforms, tx_seed, exon)
     rng = np.random.default_rng(seed)
     w = 1.0 / np.arange(1, len(tx) + 1)
     perm = rng.permutation(len(tx))
