@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librattle_hip.so")
+LIB_PATH = os.environ.get("RATTLE_HIP_LIB", os.path.join(_HERE, "csrc", "librattle_hip.so"))
 
 
 class ClusterParams(C.Structure):
