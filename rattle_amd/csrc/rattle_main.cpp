@@ -1,0 +1,472 @@
+// `rattle` command line: drop-in for `rattle cluster` (/root/reference/main.cpp:133-324) and
+// `rattle correct` (/root/reference/main.cpp:325-412) over librattle_hip.so's C ABI.
+// Same flags and defaults, same `clusters.out` (hps stream) and FASTQ outputs.  Host C++ only:
+// every compute step goes through include/rattle_hip.h.
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/rattle_hip.h"
+
+namespace {
+
+struct read_t { std::string header, seq, ann, quality; };      // fasta.hpp:7-12
+typedef std::vector<read_t> read_set_t;
+struct cseq_t { int seq_id; bool rev; int gene_id; };            // cluster.hpp:10-13
+struct cluster_t { cseq_t main_seq; std::vector<cseq_t> seqs; };
+typedef std::vector<cluster_t> cluster_set_t;
+
+[[noreturn]] void die(const std::string &m) { std::cerr << m << std::endl; exit(EXIT_FAILURE); }
+void chk(int rc) { if (rc != 0) die(std::string("\nError: ") + rattle_hip_last_error()); }
+
+// ---- argument parsing: --name v, --name=v, -n v, -nv, flags (argagg behaviour used by main.cpp) ----
+struct opt_def { const char *key; std::vector<std::string> names; bool has_arg; };
+struct args_t {
+    std::map<std::string, std::string> v;
+    bool has(const std::string &k) const { return v.count(k) != 0; }
+    std::string str(const std::string &k, const std::string &d) const { auto i = v.find(k); return i == v.end() ? d : i->second; }
+    int i(const std::string &k, int d) const { auto it = v.find(k); return it == v.end() ? d : std::stoi(it->second); }
+    double d(const std::string &k, double dv) const { auto it = v.find(k); return it == v.end() ? dv : std::stod(it->second); }
+};
+
+args_t parse(int argc, char **argv, const std::vector<opt_def> &defs) {
+    args_t a;
+    for (int i = 2; i < argc; ++i) {
+        std::string tok = argv[i], val;
+        bool has_val = false;
+        if (tok.rfind("--", 0) == 0) {
+            size_t eq = tok.find('=');
+            if (eq != std::string::npos) { val = tok.substr(eq + 1); tok = tok.substr(0, eq); has_val = true; }
+        } else if (tok.size() > 2 && tok[0] == '-') {
+            val = tok.substr(2); tok = tok.substr(0, 2); has_val = true;
+        }
+        const opt_def *d = nullptr;
+        for (auto &o : defs) for (auto &n : o.names) if (n == tok) d = &o;
+        if (!d) die("unknown option \"" + tok + "\"");
+        if (!d->has_arg) { a.v[d->key] = "1"; continue; }
+        if (!has_val) { if (i + 1 >= argc) die("option \"" + tok + "\" needs an argument"); val = argv[++i]; }
+        a.v[d->key] = val;
+    }
+    return a;
+}
+
+std::vector<std::string> split_string(const std::string &s, char d) {            // correct.cpp:20-30
+    std::vector<std::string> out;
+    std::stringstream ss(s);
+    std::string t;
+    while (getline(ss, t, d)) out.push_back(t);
+    return out;
+}
+
+// ---- input: fasta.cpp:7-31 (gz), :33-205 (fasta), :207-370 (fastq) ------------------------------
+std::string unzip_file(const std::string &filename, int index) {
+    gzFile in = gzopen(filename.c_str(), "rb");
+    std::cerr << "Start decompressing file" << std::endl;
+    std::string out = filename.substr(0, index);
+    if (!in) die("Error: Failed to decompress the file");
+    FILE *f = fopen(out.c_str(), "wb");
+    if (!f) die("Error: Failed to decompress the file");
+    std::vector<unsigned char> buf(1 << 20);
+    int n;
+    while ((n = gzread(in, buf.data(), (unsigned)buf.size())) > 0) fwrite(buf.data(), 1, n, f);
+    fclose(f);
+    gzclose(in);
+    std::cerr << "Decompressing file Complete" << std::endl;
+    return out;
+}
+
+struct line_reader {
+    std::ifstream in;
+    bool dos = false, first = true;
+    explicit line_reader(const std::string &p) : in(p) {}
+    bool next(std::string &l) {
+        if (!std::getline(in, l)) return false;
+        if (first) { dos = !l.empty() && l[l.size() - 1] == '\r'; first = false; }
+        if (dos && !l.empty()) l.erase(l.size() - 1);
+        return true;
+    }
+};
+
+// Records of a FASTQ (4 lines each) or FASTA (header + joined, upper-cased sequence lines; quality '~').
+void for_each_record(const std::string &file, bool fastq,
+                     const std::function<void(const std::string &, const std::string &, const std::string &, const std::string &)> &f) {
+    line_reader R(file);
+    std::string l;
+    if (fastq) {
+        std::string h, s, a;
+        int id = 0;
+        while (R.next(l)) {
+            if (id == 0) { h = l; id = 1; }
+            else if (id == 1) { s = l; id = 2; }
+            else if (id == 2) { a = l; id = 3; }
+            else { f(h, s, a, l); id = 0; }
+        }
+    } else {
+        std::string h, s;
+        bool have = false;
+        while (R.next(l)) {
+            if (l.empty()) continue;
+            if (l[0] == '>') {
+                if (have) f(h, s, "", std::string(s.size(), '~'));
+                h = l; s.clear(); have = true;
+            } else {
+                for (char &c : l) c = (char)toupper((unsigned char)c);          // fasta.cpp:60,131
+                s += l;
+            }
+        }
+        if (have) f(h, s, "", std::string(s.size(), '~'));
+    }
+}
+
+void resolve_input(std::string &filename, bool &fastq) {                           // main.cpp:35-57
+    if (access(filename.c_str(), F_OK)) die("\nError: Input file not found! \n");
+    int index = (int)filename.find_last_of(".");
+    std::string ext = filename.substr(index + 1);
+    if (ext == "gz") {
+        filename = unzip_file(filename, index);
+        index = (int)filename.find_last_of(".");
+        ext = filename.substr(index + 1);
+    }
+    if (ext == "fq" || ext == "fastq") fastq = true;
+    else if (ext == "fasta" || ext == "fa") fastq = false;
+    else die("\nError: Input file format incorrect! Please use fasta/fastq file. \n");
+}
+
+// main.cpp:16-64 + fasta.cpp:272-370: quality dropped, ann = running record index over ALL
+// records, length filter unless raw, reads containing 'N' skipped.
+read_set_t read_inputs_cluster(const std::vector<std::string> &files, const std::vector<std::string> &labels, bool raw, int lo, int hi) {
+    if (!labels.empty() && labels.size() != files.size()) die("\nError: Number of input files and number of label files do not match\n");
+    read_set_t reads;
+    int index = 0, sample = 0;
+    for (std::string fn : files) {
+        bool fastq;
+        resolve_input(fn, fastq);
+        std::string lab = labels.empty() ? "" : "," + labels[sample];
+        int n_skipped = 0;
+        for_each_record(fn, fastq, [&](const std::string &h, const std::string &s, const std::string &, const std::string &) {
+            int my = index++;
+            bool len_ok = raw || ((int)s.length() >= lo && (int)s.length() <= hi);
+            if (!len_ok) return;
+            if (s.find('N') != std::string::npos) { ++n_skipped; return; }
+            reads.push_back(read_t{h + lab, s, std::to_string(my), ""});
+        });
+        if (n_skipped) std::cerr << "\n" << n_skipped << "  reads contains N are skipped!" << std::endl;
+        ++sample;
+    }
+    return reads;
+}
+
+// main.cpp:66-112 + fasta.cpp:207-270: everything, file order, with qualities.
+read_set_t read_inputs(const std::vector<std::string> &files, const std::vector<std::string> &labels) {
+    if (!labels.empty() && labels.size() != files.size()) die("\nError: Number of input files and number of label files do not match\n");
+    read_set_t reads;
+    int sample = 0;
+    for (std::string fn : files) {
+        bool fastq;
+        resolve_input(fn, fastq);
+        std::string lab = labels.empty() ? "" : "," + labels[sample];
+        for_each_record(fn, fastq, [&](const std::string &h, const std::string &s, const std::string &a, const std::string &q) {
+            reads.push_back(read_t{h + lab, s, a, q});
+        });
+        ++sample;
+    }
+    return reads;
+}
+
+void write_fastq_file(const read_set_t &reads, const std::string &file) {        // fasta.cpp:436-445
+    std::ofstream f(file);
+    for (auto &r : reads) f << r.header << "\n" << r.seq << "\n" << r.ann << "\n" << r.quality << "\n";
+}
+
+// ---- clusters.out: hps stream of cluster_set_t (cluster.hpp:15-18,30-33; grammar SURVEY 5) ---------
+void put_uvarint(std::string &o, uint64_t x) { while (x >= 0x80) { o.push_back((char)((x & 0x7F) | 0x80)); x >>= 7; } o.push_back((char)x); }
+void put_svarint(std::string &o, int32_t x) { put_uvarint(o, (uint32_t)((x << 1) ^ (x >> 31))); }
+
+void write_clusters(const cluster_set_t &cs, const std::string &path) {
+    std::string o;
+    put_uvarint(o, cs.size());
+    auto cseq = [&o](const cseq_t &c) { put_svarint(o, c.seq_id); o.push_back(c.rev ? 1 : 0); put_svarint(o, c.gene_id); };
+    for (auto &c : cs) { cseq(c.main_seq); put_uvarint(o, c.seqs.size()); for (auto &s : c.seqs) cseq(s); }
+    std::ofstream f(path, std::ofstream::binary);
+    f.write(o.data(), (std::streamsize)o.size());
+}
+
+bool decode_clusters(const std::string &b, int fields, cluster_set_t &out) {
+    size_t p = 0;
+    bool ok = true;
+    auto uv = [&]() -> uint64_t {
+        uint64_t x = 0; int s = 0;
+        while (true) {
+            if (p >= b.size() || s > 63) { ok = false; return 0; }
+            uint8_t c = (uint8_t)b[p++];
+            x |= (uint64_t)(c & 0x7F) << s;
+            if (!(c & 0x80)) return x;
+            s += 7;
+        }
+    };
+    auto sv = [&]() -> int32_t { uint32_t z = (uint32_t)uv(); return (int32_t)((z >> 1) ^ (~(z & 1) + 1)); };
+    auto cseq = [&]() -> cseq_t {
+        cseq_t c{0, false, -1};
+        c.seq_id = sv();
+        if (p >= b.size()) { ok = false; return c; }
+        uint8_t r = (uint8_t)b[p++];
+        if (r > 1) ok = false;
+        c.rev = r != 0;
+        if (fields == 3) c.gene_id = sv();
+        return c;
+    };
+    out.clear();
+    uint64_t n = uv();
+    for (uint64_t i = 0; ok && i < n; ++i) {
+        cluster_t c;
+        c.main_seq = cseq();
+        uint64_t m = uv();
+        for (uint64_t j = 0; ok && j < m; ++j) c.seqs.push_back(cseq());
+        out.push_back(c);
+    }
+    return ok && p == b.size();
+}
+
+cluster_set_t read_clusters(const std::string &path) {            // current 3-field layout, else the old 2-field one
+    std::ifstream in(path, std::ifstream::binary);
+    if (!in) die("\nError: clusters file not found! \n");
+    std::string b((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    cluster_set_t cs;
+    if (decode_clusters(b, 3, cs) || decode_clusters(b, 2, cs)) return cs;
+    die("\nError: clusters file is not an hps cluster stream\n");
+}
+
+// ---- device calls --------------------------------------------------------------------------------
+void load(rattle_ctx *ctx, const read_set_t &reads, int k, bool both) {
+    std::string cat;
+    std::vector<uint64_t> off(1, 0);
+    for (auto &r : reads) { cat += r.seq; off.push_back(cat.size()); }
+    chk(rattle_hip_load_reads(ctx, (const uint8_t *)cat.data(), off.data(), (uint32_t)reads.size(), k, both ? 1 : 0));
+}
+
+cluster_set_t to_set(rattle_cluster_set *cs) {
+    cluster_set_t out(cs->n_clusters);
+    for (uint32_t c = 0; c < cs->n_clusters; ++c) {
+        out[c].main_seq = cseq_t{cs->main_id[c], cs->main_rev[c] != 0, -1};
+        for (uint32_t i = cs->offsets[c]; i < cs->offsets[c + 1]; ++i) out[c].seqs.push_back(cseq_t{cs->member_id[i], cs->member_rev[i] != 0, -1});
+    }
+    rattle_hip_cluster_set_free(cs);
+    return out;
+}
+
+int mode_cluster(int argc, char **argv) {
+    std::vector<opt_def> defs = {
+        {"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"label", {"-l", "--label"}, true},
+        {"output", {"-o", "--output"}, true}, {"threads", {"-t", "--threads"}, true}, {"kmer_size", {"-k", "--kmer-size"}, true},
+        {"t_s", {"-s", "--score-threshold"}, true}, {"t_v", {"-v", "--max-variance"}, true}, {"iso", {"--iso"}, false},
+        {"iso_kmer_size", {"--iso-kmer-size"}, true}, {"iso_t_s", {"--iso-score-threshold"}, true},
+        {"iso_t_v", {"--iso-max-variance"}, true}, {"bv_threshold", {"-B", "--bv-start-threshold"}, true},
+        {"bv_min_threshold", {"-b", "--bv-end-threshold"}, true}, {"bv_falloff", {"-f", "--bv-falloff"}, true},
+        {"min_reads_cluster", {"-r", "--min-reads-cluster"}, true}, {"repr_percentile", {"-p", "--repr-percentile"}, true},
+        {"rna", {"--rna"}, false}, {"verbose", {"--verbose"}, false}, {"raw", {"--raw"}, false},
+        {"lower_len", {"--lower-length"}, true}, {"upper_len", {"--upper-length"}, true}, {"device", {"--device"}, true}};
+    args_t a = parse(argc, argv, defs);
+    if (a.has("help")) { std::cerr << "rattle cluster -i reads.fq [-o dir] [--rna] [--iso] ... (flags of RATTLE's cluster mode)\n"; return EXIT_SUCCESS; }
+    if (!a.has("input")) die("ERROR: No input file provided");
+    int k = a.i("kmer_size", 10), iso_k = a.i("iso_kmer_size", 11);
+    if (k > 16 || iso_k > 16) die("\nError: maximum kmer size = 16 \n");
+    std::string outdir = a.str("output", ".");
+    if (a.has("output") && access(outdir.c_str(), F_OK)) die("\nOutput folder doesn't exit. Please create it first. \n");
+    bool is_rna = a.has("rna");
+    std::cerr << "RNA mode: " << std::boolalpha << is_rna << std::endl;
+    std::cerr << "Reading fasta file... " << std::endl;
+    read_set_t reads = read_inputs_cluster(split_string(a.str("input", ""), ','), split_string(a.str("label", ""), ','), a.has("raw"),
+                                           a.i("lower_len", 150), a.i("upper_len", 100000));
+    std::cout << "Reads: " << reads.size() << std::endl;
+    std::stable_sort(reads.begin(), reads.end(), [](const read_t &x, const read_t &y) { return x.seq.size() > y.seq.size(); });
+    std::cerr << "Done" << std::endl;
+
+    rattle_ctx *ctx = nullptr;
+    chk(rattle_hip_ctx_create(a.i("device", 0), &ctx));
+    rattle_cluster_params P;
+    P.t_s = a.d("t_s", 0.2); P.t_v = a.d("t_v", 1000000); P.bv_threshold = a.d("bv_threshold", 0.4);
+    P.min_bv_threshold = a.d("bv_min_threshold", 0.2); P.bv_falloff = a.d("bv_falloff", 0.05);
+    P.min_reads_cluster = a.i("min_reads_cluster", 0); P.use_hc = 0; P.repr_percentile = a.d("repr_percentile", 0.15);
+    P.is_rna = is_rna ? 1 : 0;
+    load(ctx, reads, k, !is_rna);
+    rattle_cluster_set *raw = nullptr;
+    chk(rattle_hip_cluster_reads(ctx, &P, &raw));
+    cluster_set_t gene = to_set(raw);
+    std::cerr << "Gene clustering done" << std::endl;
+    std::cerr << gene.size() << " gene clusters found" << std::endl;
+    const std::string out_path = outdir + "/clusters.out";
+    if (!a.has("iso")) {                                                         // main.cpp:264-277
+        for (auto &c : gene) {
+            c.main_seq.seq_id = std::stoi(reads[c.main_seq.seq_id].ann);
+            for (auto &s : c.seqs) s.seq_id = std::stoi(reads[s.seq_id].ann);
+        }
+        write_clusters(gene, out_path);
+        rattle_hip_ctx_destroy(ctx);
+        return EXIT_SUCCESS;
+    }
+    // main.cpp:281-323: second level per gene cluster with the iso parameters
+    load(ctx, reads, iso_k, !is_rna);
+    P.t_s = a.d("iso_t_s", 0.3); P.t_v = a.d("iso_t_v", 25);
+    cluster_set_t iso;
+    int gi = 0;
+    for (auto &c : gene) {
+        std::stable_sort(c.seqs.begin(), c.seqs.end(), [](const cseq_t &x, const cseq_t &y) { return x.seq_id > y.seq_id; });
+        std::stable_sort(c.seqs.begin(), c.seqs.end(), [&reads](const cseq_t &x, const cseq_t &y) {
+            return reads[x.seq_id].seq.size() > reads[y.seq_id].seq.size();
+        });
+        std::vector<uint32_t> subset;
+        for (auto &s : c.seqs) subset.push_back((uint32_t)s.seq_id);
+        rattle_cluster_set *sub = nullptr;
+        chk(rattle_hip_cluster_subset(ctx, &P, subset.data(), (uint32_t)subset.size(), &sub));
+        for (auto &ic : to_set(sub)) {
+            cluster_t o;
+            o.main_seq = cseq_t{std::stoi(reads[c.seqs[ic.main_seq.seq_id].seq_id].ann), ic.main_seq.rev, gi};
+            for (auto &s : ic.seqs) o.seqs.push_back(cseq_t{std::stoi(reads[c.seqs[s.seq_id].seq_id].ann), s.rev, gi});
+            iso.push_back(o);
+        }
+        ++gi;
+    }
+    std::cerr << "Isoform clustering done" << std::endl;
+    std::cerr << iso.size() << " isoform clusters found" << std::endl;
+    write_clusters(iso, out_path);
+    rattle_hip_ctx_destroy(ctx);
+    return EXIT_SUCCESS;
+}
+
+int mode_correct(int argc, char **argv) {
+    std::vector<opt_def> defs = {
+        {"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"label", {"-l", "--label"}, true},
+        {"clusters", {"-c", "--clusters"}, true}, {"output", {"-o", "--output"}, true}, {"gap-occ", {"-g", "--gap-occ"}, true},
+        {"min-occ", {"-m", "--min-occ"}, true}, {"split", {"-s", "--split"}, true}, {"min-reads", {"-r", "--min-reads"}, true},
+        {"threads", {"-t", "--threads"}, true}, {"verbose", {"--verbose"}, false}, {"device", {"--device"}, true},
+        {"vote-order", {"--vote-order"}, true}};
+    args_t a = parse(argc, argv, defs);
+    if (a.has("help")) { std::cerr << "rattle correct -i reads.fq -c clusters.out [-o dir] ... (flags of RATTLE's correct mode)\n"; return EXIT_SUCCESS; }
+    if (!a.has("input")) die("ERROR: No input file provided");
+    if (!a.has("clusters")) die("ERROR: No clusters file provided");
+    std::cerr << "Reading fasta file... ";
+    std::vector<std::string> labels = split_string(a.str("label", ""), ',');
+    read_set_t reads = read_inputs(split_string(a.str("input", ""), ','), labels);
+    std::cerr << "Done" << std::endl;
+    cluster_set_t clusters = read_clusters(a.str("clusters", ""));
+    if (clusters.empty()) die("\nError: empty clusters file\n");
+    const bool gene_mode = clusters[0].main_seq.gene_id == -1;                   // correct.cpp:322
+
+    std::string cat, qcat;
+    std::vector<uint64_t> off(1, 0);
+    for (auto &r : reads) {
+        cat += r.seq;
+        std::string q = r.quality;
+        q.resize(r.seq.size(), '!');
+        qcat += q;
+        off.push_back(cat.size());
+    }
+    std::vector<uint32_t> coff(1, 0);
+    std::vector<int32_t> mid;
+    std::vector<uint8_t> mrev;
+    for (auto &c : clusters) {
+        for (auto &s : c.seqs) { mid.push_back(s.seq_id); mrev.push_back(s.rev ? 1 : 0); }
+        coff.push_back((uint32_t)mid.size());
+    }
+    rattle_correct_params P;
+    memset(&P, 0, sizeof(P));
+    P.min_occ = a.d("min-occ", 0.3); P.gap_occ = a.d("gap-occ", 0.3); P.err_ratio = 30.0;
+    P.split = a.i("split", 200); P.min_reads = a.i("min-reads", 5); P.n_threads = 0;
+    std::string vo = a.str("vote-order", "");
+    if (vo.size() == 6) memcpy(P.vote_order, vo.data(), 6);
+    rattle_ctx *ctx = nullptr;
+    chk(rattle_hip_ctx_create(a.i("device", 0), &ctx));
+    rattle_correction *R = nullptr;
+    chk(rattle_hip_correct_reads(ctx, (const uint8_t *)cat.data(), (const uint8_t *)qcat.data(), off.data(), (uint32_t)reads.size(),
+                                 (uint32_t)clusters.size(), coff.data(), mid.data(), mrev.data(), &P, &R));
+    auto tag = [&](int cid) {                                                    // correct.cpp:348-353
+        int gid = clusters[cid].main_seq.gene_id;
+        if (gid == -1) return ",gene_cluster_" + std::to_string(cid);
+        return ",gene_cluster_" + std::to_string(gid) + ",transcript_cluster_" + std::to_string(cid);
+    };
+    auto to_reads = [&](const rattle_read_set &S, bool corrected) {
+        read_set_t out;
+        for (uint32_t i = 0; i < S.n; ++i) {
+            read_t r;
+            r.header = reads[S.read_id[i]].header + tag(S.cluster_id[i]);
+            r.seq.assign(S.seq + S.off[i], S.seq + S.off[i + 1]);
+            r.quality.assign(S.qual + S.off[i], S.qual + S.off[i + 1]);
+            r.ann = corrected ? "+" : reads[S.read_id[i]].ann;
+            out.push_back(r);
+        }
+        return out;
+    };
+    read_set_t corrected = to_reads(R->corrected, true), uncorrected = to_reads(R->uncorrected, false), consensi;
+    // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's packs
+    std::vector<std::vector<int>> label_counts(clusters.size(), std::vector<int>(labels.size(), 0));
+    if (!labels.empty()) {
+        std::vector<char> in_pack(reads.size(), 0);
+        (void)in_pack;
+        for (size_t c = 0; c < clusters.size(); ++c) {
+            int n = (int)clusters[c].seqs.size();
+            int n_files = (n - 1) / P.split + 1;
+            for (int nf = 0; nf < n_files; ++nf) {
+                int sz = (n - 1 - nf) / n_files + 1;
+                if (sz <= P.min_reads) continue;
+                for (int j = nf; j < n; j += n_files) {
+                    const std::string &h = reads[clusters[c].seqs[j].seq_id].header;
+                    size_t p = h.find_first_of(",");
+                    std::string rest = p == std::string::npos ? "" : h.substr(p + 1);
+                    std::string lab = rest.substr(0, rest.find_first_of(","));
+                    for (size_t l = 0; l < labels.size(); ++l) if (labels[l] == lab) label_counts[c][l]++;
+                }
+            }
+        }
+    }
+    for (uint32_t i = 0; i < R->consensi.n; ++i) {
+        int cid = R->consensi.cluster_id[i];
+        std::string lr;
+        for (size_t l = 0; l < labels.size(); ++l) lr += labels[l] + ":" + std::to_string(label_counts[cid][l]) + ",";
+        read_t r;
+        if (gene_mode) r.header = "@gene_cluster_" + std::to_string(cid) + " reads=" + std::to_string(R->consensi.n_reads[i]) + " labels=" + lr;
+        else r.header = "@transcript_cluster_" + std::to_string(cid) + " gene_cluster_" + std::to_string(clusters[cid].main_seq.gene_id) +
+                        " reads=" + std::to_string(R->consensi.n_reads[i]) + " labels=" + lr;
+        r.seq.assign(R->consensi.seq + R->consensi.off[i], R->consensi.seq + R->consensi.off[i + 1]);
+        r.quality.assign(R->consensi.qual + R->consensi.off[i], R->consensi.qual + R->consensi.off[i + 1]);
+        r.ann = "+";
+        consensi.push_back(r);
+    }
+    std::cerr << std::endl << "Generating consensi..." << std::endl;
+    std::string outdir = a.str("output", ".");
+    write_fastq_file(corrected, outdir + "/corrected.fq");
+    write_fastq_file(uncorrected, outdir + "/uncorrected.fq");
+    write_fastq_file(consensi, outdir + "/consensi.fq");
+    rattle_hip_correction_free(R);
+    rattle_hip_ctx_destroy(ctx);
+    std::cerr << "Done" << std::endl;
+    return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        std::cout << "Run with mode: ./rattle <cluster|correct>" << std::endl;
+        return EXIT_FAILURE;
+    }
+    try {
+        if (!strcmp(argv[1], "cluster")) return mode_cluster(argc, argv);
+        if (!strcmp(argv[1], "correct")) return mode_correct(argc, argv);
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return EXIT_FAILURE;
+    }
+    std::cout << "Run with mode: ./rattle <cluster|correct>" << std::endl;
+    return EXIT_FAILURE;
+}

@@ -1,0 +1,55 @@
+"""The drop-in CLI (`rattle cluster` / `rattle correct`) against the reference fixture and against
+the oracle CLI, comparing output FILES."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+from rattle_amd import hps, synth
+
+pytestmark = pytest.mark.gpu
+RATTLE = os.path.join(ROOT, "rattle_amd", "csrc", "rattle")
+ORACLE = os.path.join(ROOT, "oracle", "oracle_cli")
+
+
+@pytest.fixture(scope="module")
+def built(oracle):
+    if not os.path.exists(RATTLE):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.dirname(RATTLE)])
+    assert os.path.exists(ORACLE)
+
+
+def test_cluster_cli_reproduces_toyset_fixture(built, tmp_path):
+    fq = tmp_path / "sample.fastq"
+    fq.write_bytes(gzip.open(os.path.join(GOLDEN, "toyset_rna.fastq.gz")).read())
+    out = subprocess.run([RATTLE, "cluster", "-i", str(fq), "-o", str(tmp_path), "--rna", "--lower-length", "0", "-t", "4"],
+                         capture_output=True, text=True, check=True)
+    assert "Reads: 8306" in out.stdout
+    got = hps.decode((tmp_path / "clusters.out").read_bytes(), fields=3)
+    want = hps.decode(open(os.path.join(GOLDEN, "toyset_rna.clusters.out"), "rb").read(), fields=2)
+    assert got == want
+
+
+def test_cluster_and_correct_cli_match_oracle_cli(built, tmp_path):
+    """gz input, length filter (150..100000 drops short reads and shifts nothing: ids are record
+    indices), --iso two-level clustering, then correct; every output file byte-identical."""
+    seqs, quals, _, _ = synth.reads(500, 4, 2, True, seed=17)
+    seqs[5] = seqs[5][:100]; quals[5] = quals[5][:100]              # filtered out by --lower-length 150
+    seqs[9] = seqs[9][:40] + b"N" + seqs[9][41:]                    # skipped: contains N
+    text = synth.fastq_text(seqs, quals)
+    (tmp_path / "in.fastq.gz").write_bytes(gzip.compress(text))
+    (tmp_path / "in2.fastq").write_bytes(text)
+    a = tmp_path / "a"; b = tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    subprocess.run([RATTLE, "cluster", "-i", str(tmp_path / "in.fastq.gz"), "-o", str(a), "--iso"], check=True, capture_output=True)
+    subprocess.run([ORACLE, "cluster", "-i", str(tmp_path / "in2.fastq"), "-o", str(b), "--iso"], check=True, capture_output=True)
+    assert (a / "clusters.out").read_bytes() == (b / "clusters.out").read_bytes()
+    subprocess.run([RATTLE, "correct", "-i", str(tmp_path / "in2.fastq"), "-c", str(a / "clusters.out"), "-o", str(a), "-s", "30"],
+                   check=True, capture_output=True)
+    subprocess.run([ORACLE, "correct", "-i", str(tmp_path / "in2.fastq"), "-c", str(b / "clusters.out"), "-o", str(b), "-s", "30"],
+                   check=True, capture_output=True)
+    for f in ("corrected.fq", "uncorrected.fq", "consensi.fq"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    assert (a / "consensi.fq").read_bytes().startswith(b"@transcript_cluster_0 gene_cluster_0 reads=")
