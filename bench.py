@@ -26,25 +26,21 @@ from rattle_amd.api import K_FILTER, K_KMER, K_POA, K_SCORE, Context  # noqa: E4
 
 
 def make_workload(n_reads, genes, seed):
-    # mean ~1 kb transcripts (8 exons of U[50,210]), 10 % error, both strands (cDNA)
-    return synth.reads(n_reads, genes, 1, True, seed=seed, exon=(50, 210))
+    # mean ~1 kb transcripts (8 exons of U[50,210]), 10 % error, both strands (cDNA); packed arrays
+    return synth.reads_packed(n_reads, genes, 1, True, seed=seed, exon=(50, 210))
 
 
-def run_step(ctx, seqs, quals, k=10):
-    order = sorted(range(len(seqs)), key=lambda i: -len(seqs[i]))          # sort_read_set, main.cpp:254
-    sseqs = [seqs[i] for i in order]
-    ctx.load_reads(sseqs, k, True)
-    cl = ctx.cluster_reads()
-    clusters = [((order[m[0]], m[1], -1), [(order[s[0]], s[1], -1) for s in mem]) for m, mem in cl.as_list()]
-    res = ctx.correct_reads(seqs, quals, clusters)
-    assign = np.full(len(seqs), -1, np.int32)
-    for cid, (_, mem) in enumerate(clusters):
-        for s in mem:
-            assign[s[0]] = cid
+def run_step(ctx, cat, qcat, off, k=10):
+    """`rattle cluster` (sort + index + gene-level cluster_reads + id translation, main.cpp:254-277)
+    then `rattle correct` (correct_reads, main.cpp:405) on the same reads."""
+    cl = ctx.cluster_unsorted_packed(cat, off, k=k)
+    res = ctx.correct_packed(cat, qcat, off, cl)
+    assign = np.full(len(off) - 1, -1, np.int32)
+    assign[cl.member_id] = np.repeat(np.arange(len(cl.main_id), dtype=np.int32), np.diff(cl.offsets.astype(np.int64)))
     return cl, res, assign
 
 
-def cpu_baseline(seqs, quals, tid, target_reads=600):
+def cpu_baseline(cat, qcat, off, tid, target_reads=600):
     """Oracle (CPU restatement, 1 thread) on a bounded sample: all reads of randomly chosen
     transcripts until ~target_reads, so per-cluster depth matches the full workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -57,8 +53,8 @@ def cpu_baseline(seqs, quals, tid, target_reads=600):
         ids += [i for i in np.nonzero(tid == g)[0]]
         if len(ids) >= target_reads:
             break
-    s = [seqs[i] for i in ids]
-    q = [quals[i] for i in ids]
+    s = [cat[int(off[i]):int(off[i + 1])].tobytes() for i in ids]
+    q = [qcat[int(off[i]):int(off[i + 1])].tobytes() for i in ids]
     t0 = time.time()
     order = sorted(range(len(s)), key=lambda i: -len(s[i]))
     cl, _ = orc.cluster_reads([s[i] for i in order], k=10)
@@ -92,7 +88,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     genes = a.genes or max(5, a.reads // 200)
-    seqs, quals, tid, _ = make_workload(a.reads, genes, seed=20260929 + rank)
+    cat, qcat, off, tid, _ = make_workload(a.reads, genes, seed=20260929 + rank)
     ctx = Context(local)
 
     def barrier():
@@ -102,7 +98,7 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        cl, res, assign = run_step(ctx, seqs, quals)
+        cl, res, assign = run_step(ctx, cat, qcat, off)
         if world > 1:     # reassemble cluster assignments on every rank (RCCL all-gather over xGMI)
             mine = torch.from_numpy(assign).cuda()
             parts = [torch.empty_like(mine) for _ in range(world)]
@@ -131,7 +127,7 @@ def main():
         kst = {names[k]: ctx.kernel_stats(k) for k in names}
         ms, launches, alg = kst["poa_align"]
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        cells = int(res["counters"][0])
+        cells = int(res[3][0])
         out = {
             "metric": "reads/sec for cluster+correct on synthetic ONT cDNA reads (mean 1 kb, 10% error)",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -148,7 +144,7 @@ def main():
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seqs, quals, tid)
+            out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -111,6 +111,11 @@ int rattle_hip_cluster_reads(rattle_ctx *ctx, const rattle_cluster_params *param
  * second level, main.cpp:281-318).  Ids in the result are positions in `subset`. */
 int rattle_hip_cluster_subset(rattle_ctx *ctx, const rattle_cluster_params *params, const uint32_t *subset,
                               uint32_t n_subset, rattle_cluster_set **out);
+/* The `rattle cluster` flow around cluster_reads for reads in FILE order (main.cpp:254-277):
+ * stable length-descending sort (sort_read_set, fasta.cpp:458-464), index, gene-level
+ * cluster_reads, then ids translated back to positions in the caller's order. */
+int rattle_hip_cluster_unsorted(rattle_ctx *ctx, const uint8_t *seq_concat, const uint64_t *offsets, uint32_t n_reads,
+                                int kmer_size, const rattle_cluster_params *params, rattle_cluster_set **out);
 void rattle_hip_cluster_set_free(rattle_cluster_set *cs);
 
 /* ------------------------------------------------------------------------------------

@@ -145,6 +145,44 @@ class Context:
         self.lib.rattle_hip_cluster_set_free(out)
         return res
 
+    def _take_clusters(self, out) -> Clusters:
+        cs = out.contents
+        nc = cs.n_clusters
+        offsets = np.ctypeslib.as_array(cs.offsets, (nc + 1,)).copy()
+        nm = int(offsets[nc])
+        res = Clusters(np.ctypeslib.as_array(cs.main_id, (max(nc, 1),))[:nc].copy(),
+                       np.ctypeslib.as_array(cs.main_rev, (max(nc, 1),))[:nc].copy(), offsets,
+                       np.ctypeslib.as_array(cs.member_id, (max(nm, 1),))[:nm].copy(),
+                       np.ctypeslib.as_array(cs.member_rev, (max(nm, 1),))[:nm].copy(),
+                       np.array(list(cs.counters), dtype=np.uint64))
+        self.lib.rattle_hip_cluster_set_free(out)
+        return res
+
+    def cluster_unsorted_packed(self, cat: np.ndarray, off: np.ndarray, k=10, t_s=0.2, t_v=1000000.0, bv_threshold=0.4,
+                                min_bv_threshold=0.2, bv_falloff=0.05, repr_percentile=0.15, is_rna=False) -> Clusters:
+        """main.cpp:254-277 on packed arrays in file order; ids in the result index the caller's order."""
+        P = ClusterParams(t_s, t_v, bv_threshold, min_bv_threshold, bv_falloff, 0, 0, repr_percentile, int(is_rna))
+        out = C.POINTER(ClusterSet)()
+        check(self.lib.rattle_hip_cluster_unsorted(self.h, _ptr(cat, C.c_uint8), _ptr(off, C.c_uint64), len(off) - 1, k,
+                                                   C.byref(P), C.byref(out)))
+        return self._take_clusters(out)
+
+    def correct_packed(self, cat: np.ndarray, qcat: np.ndarray, off: np.ndarray, cl: Clusters, min_occ=0.3, gap_occ=0.3,
+                       split=200, min_reads=5, n_threads=0, vote_order: bytes = b""):
+        """correct_reads on packed arrays; returns (n_corrected, n_uncorrected, n_consensi, counters)
+        without materialising Python objects (the library still builds every output record)."""
+        P = CorrectParams(min_occ, gap_occ, 30.0, split, min_reads, n_threads, vote_order)
+        out = C.POINTER(Correction)()
+        mid = cl.member_id if len(cl.member_id) else np.zeros(1, np.int32)
+        mrev = cl.member_rev if len(cl.member_rev) else np.zeros(1, np.uint8)
+        check(self.lib.rattle_hip_correct_reads(self.h, _ptr(cat, C.c_uint8), _ptr(qcat, C.c_uint8), _ptr(off, C.c_uint64),
+                                                len(off) - 1, len(cl.main_id), _ptr(cl.offsets, C.c_uint32),
+                                                _ptr(mid, C.c_int32), _ptr(mrev, C.c_uint8), C.byref(P), C.byref(out)))
+        R = out.contents
+        res = (R.corrected.n, R.uncorrected.n, R.consensi.n, np.array(list(R.counters), dtype=np.uint64))
+        self.lib.rattle_hip_correction_free(out)
+        return res
+
     # a15
     def poa_msa(self, packs: Sequence[Sequence[bytes]]):
         """MSA rows (list of bytes) for each pack of sequences."""

@@ -1,4 +1,5 @@
 // extern "C" surface of librattle_hip.so (include/rattle_hip.h).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -172,6 +173,33 @@ int rattle_hip_cluster_subset(rattle_ctx *c, const rattle_cluster_params *P, con
     if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
     static const uint32_t none = 0;
     return cluster_driver(c, P, n_subset ? subset : &none, n_subset, out);
+}
+
+int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k,
+                                const rattle_cluster_params *P, rattle_cluster_set **out) {
+    if (!c || !off || !P || !out || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    RT_HIP(hipSetDevice(c->device));
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [off](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+    std::vector<uint8_t> cat(off[n] - off[0]);
+    std::vector<uint64_t> soff(n + 1);
+    uint64_t p = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t a = off[order[i]], L = off[order[i] + 1] - a;
+        soff[i] = p;
+        memcpy(cat.data() + p, seq + a, L);
+        p += L;
+    }
+    soff[n] = p;
+    RT_TRY(build_index(c, cat.data(), soff.data(), n, k, P->is_rna ? 0 : 1));
+    RT_TRY(cluster_driver(c, P, nullptr, 0, out));
+    rattle_cluster_set *cs = *out;
+    const uint32_t nm = cs->offsets[cs->n_clusters];
+    for (uint32_t i = 0; i < cs->n_clusters; ++i) cs->main_id[i] = (int32_t)order[cs->main_id[i]];
+    for (uint32_t i = 0; i < nm; ++i) cs->member_id[i] = (int32_t)order[cs->member_id[i]];
+    return 0;
 }
 
 void rattle_hip_cluster_set_free(rattle_cluster_set *cs) {

@@ -47,8 +47,8 @@ namespace rattle {
 // z = head / w = tail of the list of further in-edges (indices into edges[]).
 // aligned record (uint4): aligned_nodes_ids in insertion order.
 // edge (uint2): x = begin node, y = next edge.
-// plan record (uint4), one per DP row: x = node info, y = first predecessor's row, z = head
-// of further in-edges, w = node id.
+// plan records, one pair per DP row: plan = {node info, node id, edge index of the 5th in-edge
+// (or none), 0}; planb = rows of the first four predecessors.
 
 struct poa_args {
     const uint8_t *seq;
@@ -59,7 +59,7 @@ struct poa_args {
     uint32_t *queue_head;
     uint8_t *arena;                // n_slots * slot_stride bytes
     uint64_t slot_stride;
-    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_plan, o_H, o_F, o_E, o_aln, o_spill;
+    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_plan, o_planb, o_H, o_F, o_E, o_aln, o_spill;
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
@@ -78,7 +78,7 @@ struct poa_args {
 enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_ERR_ALN = 4, POA_ERR_SPILL = 5, POA_ERR_GRAPH = 6 };
 
 struct poa_ws {                    // per-block workspace: global pointers + LDS + wave-uniform state
-    uint4 *nrec, *nal, *plan;
+    uint4 *nrec, *nal, *plan, *planb;
     uint2 *edges;
     int32_t *rank;
     uint32_t *order;
@@ -196,23 +196,57 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
 }
 
 // ---- DP over all rows of one alignment -----------------------------------------------------------
-// Rows are 1..n (rank+1); column j (1..L) is stored at index j-1, rows are Lp wide.
+// Rows are 1..n (rank+1); column j (1..L) is stored at index j-1, rows are Lp wide (Lp is a
+// multiple of CPL).  A lane owns CPL consecutive columns of a 64*CPL-column segment.  With one
+// segment (the usual case) the two previous rows stay in registers (WIN rows).
 // Returns best score and its row (first maximum in rank order).
+template <int CPL>
+__device__ __forceinline__ void load_block(const int16_t *__restrict__ p, int32_t *v) {
+    const uint4 *q = (const uint4 *)p;
+#pragma unroll
+    for (int u = 0; u < CPL / 8; ++u) {
+        const uint4 a = q[u];
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { v[8 * u + 2 * t] = (int16_t)(w[t] & 0xFFFF); v[8 * u + 2 * t + 1] = (int16_t)(w[t] >> 16); }
+    }
+}
+
+template <int CPL>
+__device__ __forceinline__ void store_block(int16_t *__restrict__ p, const int32_t *v) {
+    uint4 *q = (uint4 *)p;
+#pragma unroll
+    for (int u = 0; u < CPL / 8; ++u) {
+        uint32_t w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            w[t] = (uint32_t)(uint16_t)(int16_t)v[8 * u + 2 * t] | ((uint32_t)(uint16_t)(int16_t)v[8 * u + 2 * t + 1] << 16);
+        q[u] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <int CPL, int WIN>
 __device__ void dp_rows(poa_ws &S, const poa_args &A, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
     const int lane = threadIdx.x;
-    const bool one_seg = Lp <= 1024;
+    constexpr uint32_t SEG = 64 * CPL;
+    const bool one_seg = Lp <= SEG;
     best = 0; best_row = 0;
-    int32_t hprev[16], fprev[16];          // previous row (one_seg only)
+    int32_t h1[CPL], f1[CPL], h2[WIN > 1 ? CPL : 1], f2[WIN > 1 ? CPL : 1];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { hprev[t] = 0; fprev[t] = POA_NEG; }
-    uint32_t prev_row = 0xFFFFFFFFu;
+    for (int t = 0; t < CPL; ++t) { h1[t] = 0; f1[t] = POA_NEG; }
+    if (WIN > 1) {
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) { h2[t] = 0; f2[t] = POA_NEG; }
+    }
+    uint32_t row1 = 0xFFFFFFFFu, row2 = 0xFFFFFFFFu;
     for (uint32_t r0 = 0; r0 < n; r0 += 64) {
         const uint32_t nb = min(64u, n - r0);
-        uint4 my = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < nb) my = S.plan[r0 + lane];
+        uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
         for (uint32_t i = 0; i < nb; ++i) {
-            const uint32_t info = __builtin_amdgcn_readlane(my.x, i), prow0 = __builtin_amdgcn_readlane(my.y, i),
-                           more = __builtin_amdgcn_readlane(my.z, i);
+            const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
+            const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
+                                    (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
             const uint32_t row = r0 + i + 1;
             const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
             int16_t *Hr = S.H + (uint64_t)row * Lp;
@@ -221,114 +255,96 @@ __device__ void dp_rows(poa_ws &S, const poa_args &A, uint32_t n, uint32_t L, ui
             int32_t row_max = 0;
             int32_t carry_e = POA_NEG;      // E' prefix max entering the segment
             int32_t carry_hn = 0;           // Hn left of the segment (column 0: H = 0)
-#ifdef POA_SYNC_EACH_ROW
-            __syncthreads();
-#else
             if (!one_seg) __syncthreads();  // rows read below may need another lane's last column
-#endif
-            for (uint32_t seg = 0; seg < Lp; seg += 1024) {
-                const uint32_t c0 = seg + lane * 16;
+            for (uint32_t seg = 0; seg < Lp; seg += SEG) {
+                const uint32_t c0 = seg + lane * CPL;
                 const bool act = c0 < Lp;
-                int32_t hn[16], fr[16], sc[16];
+                int32_t hn[CPL], fr[CPL], hv[CPL], ev[CPL];
+                uint32_t sw[CPL / 4];
                 {
-                    const uint4 sb = act ? *(const uint4 *)(S.sq + c0) : make_uint4(0, 0, 0, 0);
-                    const uint32_t w[4] = {sb.x, sb.y, sb.z, sb.w};
+                    const uint2 *sp = (const uint2 *)(S.sq + (act ? c0 : 0));
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        sc[t] = ((w[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-                        hn[t] = POA_NEG;
-                        fr[t] = POA_NEG;
-                    }
+                    for (int u = 0; u < CPL / 8; ++u) { const uint2 x = sp[u]; sw[2 * u] = x.x; sw[2 * u + 1] = x.y; }
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hn[t] = POA_NEG; fr[t] = POA_NEG; }
                 }
                 uint32_t e = more;
                 for (uint32_t k = 0; k < (n_in ? n_in : 1u); ++k) {
-                    int32_t hp[16], fp[16];
+                    int32_t hp[CPL], fp[CPL];
                     int32_t seg_left = 0;
                     uint32_t prow = 0;
                     if (n_in) {
-                        if (k == 0) prow = prow0;
+                        if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
                         else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
                     }
                     if (n_in == 0) {
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
-#ifndef POA_NO_REG
-                    } else if (one_seg && prow == prev_row) {
+                        for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
+                    } else if (one_seg && prow == row1) {
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) { hp[t] = hprev[t]; fp[t] = fprev[t]; }
-#endif
+                        for (int t = 0; t < CPL; ++t) { hp[t] = h1[t]; fp[t] = f1[t]; }
+                    } else if (WIN > 1 && one_seg && prow == row2) {
+#pragma unroll
+                        for (int t = 0; t < CPL; ++t) { hp[t] = h2[t]; fp[t] = f2[t]; }
                     } else {
                         const int16_t *Hp = S.H + (uint64_t)prow * Lp;
                         const int16_t *Fp = S.F + (uint64_t)prow * Lp;
                         if (act) {
-                            const uint4 *h4 = (const uint4 *)(Hp + c0);
-                            const uint4 *f4 = (const uint4 *)(Fp + c0);
-                            const uint4 a0 = h4[0], a1 = h4[1], b0 = f4[0], b1 = f4[1];
-                            const uint32_t hw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                            const uint32_t fw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                            for (int t = 0; t < 8; ++t) {
-                                hp[2 * t] = (int16_t)(hw[t] & 0xFFFF); hp[2 * t + 1] = (int16_t)(hw[t] >> 16);
-                                fp[2 * t] = (int16_t)(fw[t] & 0xFFFF); fp[2 * t + 1] = (int16_t)(fw[t] >> 16);
-                            }
+                            load_block<CPL>(Hp + c0, hp);
+                            load_block<CPL>(Fp + c0, fp);
                         } else {
 #pragma unroll
-                            for (int t = 0; t < 16; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
+                            for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
                         }
                         if (seg != 0) seg_left = (int32_t)Hp[seg - 1];
                     }
-                    const int32_t hleft = wave_shr1(hp[15], seg_left);    // H[p][j-1] of the lane's first column
+                    const int32_t hleft = wave_shr1(hp[CPL - 1], seg_left);    // H[p][j-1] of the lane's first column
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
+                    for (int t = 0; t < CPL; ++t) {
                         const int32_t hl = t == 0 ? hleft : hp[t - 1];
-                        hn[t] = max(hn[t], hl + sc[t]);
+                        const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                        hn[t] = max(hn[t], hl + sc);
                         fr[t] = max(fr[t], max(hp[t] + POA_G, fp[t] + POA_E));
                     }
                 }
                 // Hn = max(diag, F, 0); t_j = Hn[j-1] + g - j*e; E'[j] = prefix max; E[j] = E'[j] + j*e
 #pragma unroll
-                for (int t = 0; t < 16; ++t) hn[t] = max(max(hn[t], fr[t]), 0);
-                const int32_t left_hn = wave_shr1(hn[15], carry_hn);
-                int32_t ep[16];
+                for (int t = 0; t < CPL; ++t) hn[t] = max(max(hn[t], fr[t]), 0);
+                const int32_t left_hn = wave_shr1(hn[CPL - 1], carry_hn);
                 int32_t run = POA_NEG;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 0; t < CPL; ++t) {
                     const int32_t j = (int32_t)(c0 + t) + 1;
                     const int32_t hl = t == 0 ? left_hn : hn[t - 1];
                     run = max(run, hl + POA_G - j * POA_E);
-                    ep[t] = run;
+                    ev[t] = run;
                 }
                 const int32_t incl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
                 const int32_t excl = max(wave_shr1(incl, POA_NEG), carry_e);
                 int32_t lane_max = 0;
-                uint32_t hw[8], fw[8], ew[8];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 0; t < CPL; ++t) {
                     const int32_t j = (int32_t)(c0 + t) + 1;
-                    const int32_t ev = max(ep[t], excl) + j * POA_E;
-                    const int32_t hv = max(hn[t], ev);
-                    hprev[t] = hv; fprev[t] = fr[t];
-                    if (c0 + t < L) lane_max = max(lane_max, hv);
-                    const uint32_t h16 = (uint32_t)(uint16_t)(int16_t)hv, f16 = (uint32_t)(uint16_t)(int16_t)fr[t],
-                                   e16 = (uint32_t)(uint16_t)(int16_t)ev;
-                    if (t & 1) { hw[t >> 1] |= h16 << 16; fw[t >> 1] |= f16 << 16; ew[t >> 1] |= e16 << 16; }
-                    else { hw[t >> 1] = h16; fw[t >> 1] = f16; ew[t >> 1] = e16; }
+                    ev[t] = max(ev[t], excl) + j * POA_E;
+                    hv[t] = max(hn[t], ev[t]);
+                    if (c0 + t < L) lane_max = max(lane_max, hv[t]);
                 }
-#ifdef POA_NOSTORE
-                if (act && row_max == 12345) {
-#else
                 if (act) {
-#endif
-                    uint4 *h4 = (uint4 *)(Hr + c0), *f4 = (uint4 *)(Fr + c0), *e4 = (uint4 *)(Er + c0);
-                    h4[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]); h4[1] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
-                    f4[0] = make_uint4(fw[0], fw[1], fw[2], fw[3]); f4[1] = make_uint4(fw[4], fw[5], fw[6], fw[7]);
-                    e4[0] = make_uint4(ew[0], ew[1], ew[2], ew[3]); e4[1] = make_uint4(ew[4], ew[5], ew[6], ew[7]);
+                    store_block<CPL>(Hr + c0, hv);
+                    store_block<CPL>(Fr + c0, fr);
+                    store_block<CPL>(Er + c0, ev);
                 }
+                if (WIN > 1) {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { h2[t] = h1[t]; f2[t] = f1[t]; }
+                }
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) { h1[t] = hv[t]; f1[t] = fr[t]; }
                 carry_e = max(wave_last(incl), carry_e);
-                carry_hn = wave_last(hn[15]);
+                carry_hn = wave_last(hn[CPL - 1]);
                 row_max = max(row_max, wave_last(wave_scan_max(lane_max, 0)));
             }
-            prev_row = row;
+            row2 = row1; row1 = row;
             if (row_max > best) { best = row_max; best_row = row; }
         }
     }
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
     {
         uint8_t *base = A.arena + (uint64_t)blockIdx.x * A.slot_stride;
         S.nrec = (uint4 *)(base + A.o_nrec); S.nal = (uint4 *)(base + A.o_nal); S.edges = (uint2 *)(base + A.o_edges);
-        S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.plan = (uint4 *)(base + A.o_plan);
+        S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb);
         S.H = (int16_t *)(base + A.o_H); S.F = (int16_t *)(base + A.o_F); S.E = (int16_t *)(base + A.o_E);
         S.aln = (int32_t *)(base + A.o_aln); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = (A.node_cap + 31) / 32;
@@ -418,7 +434,9 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
             uint32_t n_aln = 0;
             if (S.n_nodes > 0) {
                 const uint32_t n = S.n_nodes;
-                const uint32_t Lp = (L + 15u) & ~15u;
+                // columns per lane: 16 (<= 1024 columns in one segment), 24 (<= 1536), else 16 with segments
+                const uint32_t cpl = (L > 1024 && L <= 1536) ? 24u : 16u;
+                const uint32_t Lp = (L + cpl - 1) / cpl * cpl;
                 if ((uint64_t)(n + 1) * Lp > A.cell_cap) { S.err = POA_ERR_CELLS; break; }
                 // ---- 1. toposort ----
                 unsigned long long t0 = PT_NOW();
@@ -430,8 +448,16 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                 for (uint32_t r = lane; r < n; r += 64) {
                     const uint32_t v = S.order[r];
                     const uint4 rec = S.nrec[v];
-                    const uint32_t prow0 = rd_nin(rec.x) ? (uint32_t)S.rank[rec.y] + 1 : 0;
-                    S.plan[r] = make_uint4(rec.x, prow0, rec.z, v);
+                    const uint32_t n_in = rd_nin(rec.x);
+                    uint4 pr = make_uint4(0, 0, 0, 0);
+                    uint32_t e = rec.z;
+                    for (uint32_t k = 0; k < n_in && k < 4; ++k) {
+                        uint32_t b;
+                        if (k == 0) b = rec.y; else { const uint2 ed = S.edges[e]; e = ed.y; b = ed.x; }
+                        u4_set(pr, k, (uint32_t)S.rank[b] + 1);
+                    }
+                    S.plan[r] = make_uint4(rec.x, v, e, 0);
+                    S.planb[r] = pr;
                 }
                 for (uint32_t t = lane; t < Lp; t += 64) S.sq[t] = t < L ? s[t] : 0;
                 __syncthreads();
@@ -439,7 +465,8 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                 t_topo += t1 - t0;
                 // ---- 3. DP ----
                 int32_t best; uint32_t best_row;
-                dp_rows(S, A, n, L, Lp, best, best_row);
+                if (cpl == 24) dp_rows<24, 1>(S, A, n, L, Lp, best, best_row);
+                else dp_rows<16, 2>(S, A, n, L, Lp, best, best_row);
                 cells += (unsigned long long)n * L;
                 rows += n;
                 unsigned long long t2 = PT_NOW();
@@ -468,8 +495,8 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                             const int32_t Hij = Hat(i, j);
                             bool found = false, ext_left = false, ext_up = false;
                             uint32_t pi = 0, pj = 0;
-                            uint4 pl = make_uint4(0, 0, POA_NONE, 0);
-                            if (i != 0) pl = S.plan[i - 1];
+                            uint4 pl = make_uint4(0, 0, POA_NONE, 0), plb = make_uint4(0, 0, 0, 0);
+                            if (i != 0) { pl = S.plan[i - 1]; plb = S.planb[i - 1]; }
                             const uint32_t n_in = rd_nin(pl.x);
                             const uint32_t npred = n_in ? n_in : 1u;
                             if (i != 0 && j != 0) {
@@ -477,7 +504,7 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                                 uint32_t e = pl.z;
                                 for (uint32_t k = 0; k < npred; ++k) {
                                     uint32_t p = 0;
-                                    if (n_in) { if (k == 0) p = pl.y; else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; } }
+                                    if (n_in) { if (k < 4) p = u4_get(plb, k); else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; } }
                                     if (Hij == Hat(p, j - 1) + mc) { pi = p; pj = j - 1; found = true; break; }
                                 }
                             }
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                                 uint32_t e = pl.z;
                                 for (uint32_t k = 0; k < npred; ++k) {
                                     uint32_t p = 0;
-                                    if (n_in) { if (k == 0) p = pl.y; else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; } }
+                                    if (n_in) { if (k < 4) p = u4_get(plb, k); else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; } }
                                     if ((ext_up = (Hij == Fat(p, j) + POA_E)) || Hij == Hat(p, j) + POA_G) { pi = p; pj = j; found = true; break; }
                                 }
                             }
@@ -493,7 +520,7 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                                 if ((ext_left = (Hij == Eat(i, j - 1) + POA_E)) || Hij == Hat(i, j - 1) + POA_G) { pi = i; pj = j - 1; found = true; }
                             }
                             if (!found) { err = POA_ERR_GRAPH; break; }
-                            put(i == pi ? -1 : (int32_t)pl.w, j == pj ? -1 : (int32_t)(j - 1));
+                            put(i == pi ? -1 : (int32_t)pl.y, j == pj ? -1 : (int32_t)(j - 1));
                             i = pi; j = pj;
                             if (ext_left) {
                                 while (!err) {
@@ -505,16 +532,16 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                                 while (!err) {
                                     bool stop = false;
                                     uint32_t np = 0;
-                                    const uint4 ul = S.plan[i - 1];
+                                    const uint4 ul = S.plan[i - 1], ulb = S.planb[i - 1];
                                     const uint32_t uin = rd_nin(ul.x);
                                     uint32_t e = ul.z;
                                     const int32_t Fij = Fat(i, j);
                                     for (uint32_t k = 0; k < uin; ++k) {
                                         uint32_t p;
-                                        if (k == 0) p = ul.y; else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; }
+                                        if (k < 4) p = u4_get(ulb, k); else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; }
                                         if ((stop = (Fij == Hat(p, j) + POA_G)) || Fij == Fat(p, j) + POA_E) { np = p; break; }
                                     }
-                                    put((int32_t)ul.w, -1);
+                                    put((int32_t)ul.y, -1);
                                     i = np;
                                     if (stop || i == 0) break;
                                 }
@@ -704,13 +731,13 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
         const uint32_t acap = tl + ncap + 16;
         const uint32_t scap = ncap + POA_STACK;
-        const uint32_t qcap = (tl + 15u) & ~15u;
+        const uint32_t qcap = ((tl + 23u) / 24u * 24u + 15u) & ~15u;      // covers both column-per-lane paddings
         const uint64_t ccap = std::min<uint64_t>(cell_cap, (uint64_t)(ncap + 1) * qcap);
         poa_args A;
         uint64_t o = 0;
         auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
         A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
-        A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_plan = take((uint64_t)ncap * 16);
+        A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
         A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
         A.o_aln = take((uint64_t)acap * 8); A.o_spill = take((uint64_t)scap * 4);
         const uint64_t per_slot = o;

@@ -83,3 +83,68 @@ def fastq_text(seqs, quals, prefix="r") -> bytes:
     for i, (s, q) in enumerate(zip(seqs, quals)):
         out.append(b"@%s%d\n%s\n+\n%s\n" % (prefix.encode(), i, s, q))
     return b"".join(out)
+
+
+def reads_packed(n: int, genes: int, isoforms: int = 1, both_strands: bool = True, seed: int = 20260929,
+                 tx_seed: int = 20260928, sub=0.04, ins=0.03, dele=0.03, exon=(80, 300), chunk: int = 500):
+    """Vectorised variant of reads() for large n: same model, returns packed arrays
+    (seq uint8, qual uint8, offsets uint64[n+1], tx_id, strand).  Different random stream than
+    reads() (chunked numpy draws), same distributions."""
+    tx, _ = transcriptome(genes, isoforms, tx_seed, exon)
+    txlen = np.array([len(t) for t in tx], np.int64)
+    txoff = np.zeros(len(tx) + 1, np.int64)
+    txoff[1:] = np.cumsum(txlen)
+    txcat = np.concatenate(tx)
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, len(tx) + 1)
+    perm = rng.permutation(len(tx))
+    p = np.zeros(len(tx))
+    p[perm] = w / w.sum()
+    tid = rng.choice(len(tx), size=n, p=p)
+    flip = (rng.random(n) < 0.5) if both_strands else np.zeros(n, bool)
+    seq_parts, qual_parts, lens_all = [], [], []
+    for c0 in range(0, n, chunk):
+        t = tid[c0:c0 + chunk]
+        m = len(t)
+        cut = (rng.random(m) * (txlen[t] // 10 + 1)).astype(np.int64)
+        L = txlen[t] - cut
+        T = int(L.sum())
+        rstart = np.zeros(m + 1, np.int64)
+        rstart[1:] = np.cumsum(L)
+        rid = np.repeat(np.arange(m), L)
+        within = np.arange(T) - rstart[rid]
+        base = txcat[txoff[t][rid] + cut[rid] + within]
+        r = rng.random(T)
+        is_del = r < dele
+        is_sub = (r >= dele) & (r < dele + sub)
+        idx = np.searchsorted(_ACGT, base)
+        shift = rng.integers(1, 4, T)
+        base = np.where(is_sub, _ACGT[(idx + shift) % 4], base)
+        has_ins = rng.random(T) < ins
+        ins_base = _ACGT[rng.integers(0, 4, T)]
+        keep = ~is_del
+        cnt = keep.astype(np.int64) + has_ins.astype(np.int64)
+        end = np.cumsum(cnt)
+        start = end - cnt
+        total = int(end[-1]) if T else 0
+        out = np.empty(total, np.uint8)
+        out[start[keep]] = base[keep]
+        out[(start + keep)[has_ins]] = ins_base[has_ins]
+        ostart = np.zeros(m + 1, np.int64)
+        ostart[1:] = end[rstart[1:] - 1]
+        olen = ostart[1:] - ostart[:-1]
+        # reverse-complement flipped reads in place via an index map
+        f = flip[c0:c0 + chunk]
+        orid = np.repeat(np.arange(m), olen)
+        owithin = np.arange(total) - ostart[orid]
+        src = np.where(f[orid], ostart[orid] + olen[orid] - 1 - owithin, ostart[orid] + owithin)
+        o2 = out[src]
+        o2 = np.where(f[orid], _COMP[o2], o2)
+        q = np.clip(np.rint(rng.normal(10, 3, total)), 3, 40).astype(np.uint8) + 33
+        seq_parts.append(o2)
+        qual_parts.append(q)
+        lens_all.append(olen)
+    lens = np.concatenate(lens_all)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(lens).astype(np.uint64)
+    return np.concatenate(seq_parts), np.concatenate(qual_parts), off, tid, flip.astype(np.uint8)

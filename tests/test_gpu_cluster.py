@@ -138,3 +138,13 @@ def test_cluster_subset_and_iso_flow(gpu_ctx, oracle):
         for im, imem in sub:
             want.append(((order[ids[im[0]]], im[1], gi), [(order[ids[s[0]]], s[1], gi) for s in imem]))
     assert got == want
+
+
+def test_cluster_unsorted_matches_cluster_command(gpu_ctx, oracle):
+    """rattle_hip_cluster_unsorted == sort + cluster_reads + id translation (main.cpp:254-277)."""
+    from rattle_amd.api import pack_reads
+    seqs, _, _, _ = synth.reads(800, 7, 1, True, seed=44)
+    want, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    cat, off = pack_reads(seqs)
+    got = gpu_ctx.cluster_unsorted_packed(cat, off).as_list()
+    assert got == want
