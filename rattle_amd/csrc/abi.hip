@@ -62,6 +62,7 @@ void rattle_hip_ctx_destroy(rattle_ctx *c) {
     c->d_seed.release(); c->d_cand.release(); c->d_first.release(); c->d_lut.release(); c->d_pass.release();
     c->d_surv.release(); c->d_counter.release(); c->d_pi.release(); c->d_pj.release(); c->d_ps.release();
     c->d_res.release(); c->d_var.release(); c->d_scratch.release();
+    if (c->poa_arena) (void)hipFree(c->poa_arena);
     c->h_surv.release(); c->h_res.release(); c->h_var.release(); c->h_counter.release();
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
@@ -180,6 +181,7 @@ int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_
     if (!c || !off || !P || !out || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
     *out = nullptr;
     RT_HIP(hipSetDevice(c->device));
+    phase_timer T_all("cluster_unsorted: total");
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [off](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
@@ -193,8 +195,8 @@ int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_
         p += L;
     }
     soff[n] = p;
-    RT_TRY(build_index(c, cat.data(), soff.data(), n, k, P->is_rna ? 0 : 1));
-    RT_TRY(cluster_driver(c, P, nullptr, 0, out));
+    { phase_timer T("cluster: build_index"); RT_TRY(build_index(c, cat.data(), soff.data(), n, k, P->is_rna ? 0 : 1)); }
+    { phase_timer T("cluster: greedy driver"); RT_TRY(cluster_driver(c, P, nullptr, 0, out)); }
     rattle_cluster_set *cs = *out;
     const uint32_t nm = cs->offsets[cs->n_clusters];
     for (uint32_t i = 0; i < cs->n_clusters; ++i) cs->main_id[i] = (int32_t)order[cs->main_id[i]];

@@ -8,7 +8,26 @@
 
 #include "../../include/rattle_hip.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace rattle {
+
+// RATTLE_TIMING=1: wall-clock of host phases on stderr
+struct phase_timer {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit phase_timer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {
+        static const bool enabled = getenv("RATTLE_TIMING") != nullptr;
+        on = enabled;
+    }
+    ~phase_timer() {
+        if (on) fprintf(stderr, "[rattle] %-28s %8.1f ms\n", name,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 void set_error(const std::string &msg);
 
@@ -122,6 +141,9 @@ struct rattle_ctx {
     rattle::hbuf<int32_t> h_res;
     rattle::hbuf<double> h_var;
     rattle::hbuf<uint32_t> h_counter;
+    // POA arena: kept across stages and calls (allocating ~100 GB costs seconds)
+    uint8_t *poa_arena = nullptr;
+    size_t poa_arena_bytes = 0;
 };
 
 namespace rattle {

@@ -199,8 +199,10 @@ int poa_stage(rattle_ctx *ctx, const std::vector<const std::vector<hread> *> &gr
         first.push_back((uint32_t)off.size() - 1);
     }
     rattle_msa_set *ms = nullptr;
+    phase_timer T0("  poa_stage: msa_run");
     int rc = poa_msa_run(ctx, (const uint8_t *)cat.data(), off.data(), (uint32_t)off.size() - 1, first.data(),
                          (uint32_t)groups.size(), &ms);
+    phase_timer T1("  poa_stage: copy rows");
     if (rc == 0) {
         uint32_t q = 0;
         for (size_t g = 0; g < groups.size(); ++g) {
@@ -265,6 +267,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     rattle_correction *R = (rattle_correction *)calloc(1, sizeof(rattle_correction));
     *out = R;
 
+    phase_timer T_all("correct: total");
     std::vector<pack_t> packs;
     std::vector<hread> uncorrected;
     std::vector<int32_t> unc_cid;
@@ -307,15 +310,17 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     // ---- POA #1 (correct.cpp:398-405) + fix ends + correction (:407-409)
     std::vector<std::vector<std::string>> msas;
     {
+        phase_timer T("correct: POA#1 stage");
         std::vector<const std::vector<hread> *> groups;
         for (auto &p : packs) groups.push_back(&p.reads);
         RT_TRY(poa_stage(ctx, groups, msas, counters));
     }
+    { phase_timer T("correct: vote+correct host");
     parallel_for(packs.size(), P->n_threads, [&](size_t i) {
         fix_msa_ends(packs[i].reads, msas[i]);
         correct_pack(packs[i], msas[i], V, P->min_occ, P->gap_occ, P->err_ratio);
         msas[i].clear();
-    });
+    }); }
     std::vector<hread> corrected;
     std::vector<int32_t> cor_cid;
     for (auto &p : packs) {                                         // :413-425 (pack order)
@@ -324,6 +329,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     }
     // ---- POA #2 over the corrected reads, stably sorted by length desc (:427-445)
     {
+        phase_timer T("correct: POA#2 stage");
         std::vector<const std::vector<hread> *> groups;
         for (auto &p : packs) {
             std::stable_sort(p.corrected.begin(), p.corrected.end(), [](const hread &a, const hread &b) { return a.seq.size() > b.seq.size(); });

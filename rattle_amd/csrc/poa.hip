@@ -718,6 +718,7 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
 
     size_t free_b = 0, total_b = 0;
     RT_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += ctx->poa_arena_bytes;            // the cached arena is ours to reuse
     // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas
     uint32_t node_cap = 16384;
     uint64_t cell_cap = 24ull << 20;           // elements per matrix (x3 matrices x2 bytes = 144 MiB)
@@ -744,13 +745,20 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         const uint64_t budget = (uint64_t)(free_b * 0.85);
         const uint32_t max_slots = (uint32_t)std::max<uint64_t>(1, budget / per_slot);
         const uint32_t n_slots = std::min<uint32_t>((uint32_t)todo.size(), std::min<uint32_t>(max_slots, 256 * 8));
-        uint8_t *arena = nullptr;
-        if (hipMalloc((void **)&arena, (size_t)per_slot * n_slots) != hipSuccess) {
-            set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break;
+        phase_timer T_round("    poa round (arena+kernel)");
+        if (getenv("RATTLE_TIMING")) fprintf(stderr, "[rattle]     poa round %d: %zu packs, %u slots x %.1f MB\n", round, todo.size(), n_slots, per_slot / 1e6);
+        if (ctx->poa_arena_bytes < (size_t)per_slot * n_slots) {
+            if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
+            ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
+            if (hipMalloc((void **)&ctx->poa_arena, (size_t)per_slot * n_slots) != hipSuccess) {
+                set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break;
+            }
+            ctx->poa_arena_bytes = (size_t)per_slot * n_slots;
         }
+        uint8_t *arena = ctx->poa_arena;
         hipError_t e = hipMemcpyAsync(d_queue.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemsetAsync(d_head.p, 0, 4, st);
-        if (e != hipSuccess) { (void)hipFree(arena); set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
+        if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
         A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p; A.n_queue = (uint32_t)todo.size();
         A.queue_head = d_head.p; A.arena = arena; A.slot_stride = per_slot;
         A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
@@ -764,7 +772,6 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(arena);
         if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
         std::vector<uint32_t> again;
         for (uint32_t p : todo) {
@@ -793,6 +800,7 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     if (rc) return rc;
 
     // expand rows on the host: row = '-' * width with each base at its column
+    phase_timer T_expand("    poa expand rows");
     uint64_t bytes = 0;
     for (uint32_t p = 0; p < n_packs; ++p) {
         R->width[p] = h_width[p];
