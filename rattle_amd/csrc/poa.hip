@@ -114,15 +114,21 @@ __device__ __forceinline__ int32_t wave_scan_max(int32_t v, int32_t ident) {
     return v;
 }
 __device__ __forceinline__ int32_t wave_last(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
+// ordering inside ONE wavefront (other waves of the block are parked at a barrier): make this
+// wave's LDS / global writes visible to its own other lanes
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ---- DFS stack with spill to global --------------------------------------------------------
 __device__ __forceinline__ void st_push(poa_ws &S, const poa_args &A, uint32_t v) {
     if (S.sp == POA_STACK) {
         if (S.spilled + POA_STACK / 2 > A.spill_cap) { S.err = POA_ERR_SPILL; return; }
         for (uint32_t t = threadIdx.x; t < POA_STACK / 2; t += 64) S.spill[S.spilled + t] = S.stack[t];
-        __syncthreads();
+        wave_sync();
         for (uint32_t t = threadIdx.x; t < POA_STACK / 2; t += 64) S.stack[t] = S.stack[t + POA_STACK / 2];
-        __syncthreads();
+        wave_sync();
         S.spilled += POA_STACK / 2;
         S.sp = POA_STACK / 2;
     }
@@ -131,10 +137,10 @@ __device__ __forceinline__ void st_push(poa_ws &S, const poa_args &A, uint32_t v
 
 __device__ __forceinline__ void st_refill(poa_ws &S) {
     if (S.sp == 0 && S.spilled > 0) {
-        __syncthreads();
+        wave_sync();
         S.spilled -= POA_STACK / 2;
         for (uint32_t t = threadIdx.x; t < POA_STACK / 2; t += 64) S.stack[t] = S.spill[S.spilled + t];
-        __syncthreads();
+        wave_sync();
         S.sp = POA_STACK / 2;
     }
 }
@@ -144,7 +150,7 @@ __device__ __forceinline__ void st_refill(poa_ws &S) {
 __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emit, uint32_t &n_cols) {
     const uint32_t n = S.n_nodes;
     for (uint32_t t = threadIdx.x; t < (n + 31) / 32; t += 64) { S.done[t] = 0; S.nocheck[t] = 0; }
-    __syncthreads();
+    wave_sync();
     n_emit = 0; n_cols = 0;
     S.sp = 0; S.spilled = 0;
     const bool l0 = threadIdx.x == 0;
@@ -192,45 +198,82 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
             ++n_cols;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
-// ---- DP over all rows of one alignment -----------------------------------------------------------
-// Rows are 1..n (rank+1); column j (1..L) is stored at index j-1, rows are Lp wide (Lp is a
-// multiple of CPL).  A lane owns CPL consecutive columns of a 64*CPL-column segment.  With one
-// segment (the usual case) the two previous rows stay in registers (WIN rows).
-// Returns best score and its row (first maximum in rank order).
+// ---- DP over all rows of one alignment: 4 wavefronts per pack ---------------------------------
+// Rows are 1..n (rank+1); column j (1..L) is stored at index j-1, rows are Lp wide (multiple of
+// CPL).  Thread tid of the 256-thread block owns the CPL consecutive columns j = tid*CPL+1 ..
+// tid*CPL+CPL of every row; the last WIN rows stay in registers.
+//
+// Horizontal affine gaps, exactly: E[j] = max(H[j-1]+g, E[j-1]+e) with E[0] = -inf, H[0] = 0 is
+// E[j] = j*e + max_{k<j} u_k with u_k = Hn[k] + g - (k+1)*e, Hn = max(diagonal, F, 0) (H without
+// its E term; valid because e >= g), u_0 = g - e.  So a row is: Hn from the predecessor rows,
+// an exclusive prefix-max of u (in-thread, DPP wave scan, one LDS exchange of the four wave
+// totals = ONE workgroup barrier per row), then H = max(Hn, E).
+// The column left of a wave's first column belongs to the previous wave; its H value is
+// rebuilt after the barrier from three published numbers (wave total without its last
+// column, Hn of that column) so later rows can use it as the diagonal source.
 template <int CPL>
 __device__ __forceinline__ void load_block(const int16_t *__restrict__ p, int32_t *v) {
-    const uint4 *q = (const uint4 *)p;
+    if (CPL % 4 == 0) {
+        const uint2 *q = (const uint2 *)p;
 #pragma unroll
-    for (int u = 0; u < CPL / 8; ++u) {
-        const uint4 a = q[u];
-        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+        for (int u = 0; u < CPL / 4; ++u) {
+            const uint2 a = q[u];
+            v[4 * u] = (int16_t)(a.x & 0xFFFF); v[4 * u + 1] = (int16_t)(a.x >> 16);
+            v[4 * u + 2] = (int16_t)(a.y & 0xFFFF); v[4 * u + 3] = (int16_t)(a.y >> 16);
+        }
+    } else {
+        const uint32_t *q = (const uint32_t *)p;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { v[8 * u + 2 * t] = (int16_t)(w[t] & 0xFFFF); v[8 * u + 2 * t + 1] = (int16_t)(w[t] >> 16); }
+        for (int u = 0; u < CPL / 2; ++u) {
+            const uint32_t a = q[u];
+            v[2 * u] = (int16_t)(a & 0xFFFF); v[2 * u + 1] = (int16_t)(a >> 16);
+        }
     }
 }
 
 template <int CPL>
 __device__ __forceinline__ void store_block(int16_t *__restrict__ p, const int32_t *v) {
-    uint4 *q = (uint4 *)p;
+    if (CPL % 4 == 0) {
+        uint2 *q = (uint2 *)p;
 #pragma unroll
-    for (int u = 0; u < CPL / 8; ++u) {
-        uint32_t w[4];
+        for (int u = 0; u < CPL / 4; ++u) {
+            uint2 a;
+            a.x = (uint32_t)(uint16_t)(int16_t)v[4 * u] | ((uint32_t)(uint16_t)(int16_t)v[4 * u + 1] << 16);
+            a.y = (uint32_t)(uint16_t)(int16_t)v[4 * u + 2] | ((uint32_t)(uint16_t)(int16_t)v[4 * u + 3] << 16);
+            q[u] = a;
+        }
+    } else {
+        uint32_t *q = (uint32_t *)p;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            w[t] = (uint32_t)(uint16_t)(int16_t)v[8 * u + 2 * t] | ((uint32_t)(uint16_t)(int16_t)v[8 * u + 2 * t + 1] << 16);
-        q[u] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int u = 0; u < CPL / 2; ++u)
+            q[u] = (uint32_t)(uint16_t)(int16_t)v[2 * u] | ((uint32_t)(uint16_t)(int16_t)v[2 * u + 1] << 16);
     }
 }
 
+struct dp_xchg {                 // LDS, double-buffered by row parity
+    int32_t T[2][4];             // wave-inclusive max of u
+    int32_t Tp[2][4];            // same without the wave's last column
+    int32_t Hn[2][4];            // Hn of the wave's last column
+    int32_t best[4];
+    uint32_t best_row[4];
+};
+
 template <int CPL, int WIN>
-__device__ void dp_rows(poa_ws &S, const poa_args &A, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
-    const int lane = threadIdx.x;
-    constexpr uint32_t SEG = 64 * CPL;
-    const bool one_seg = Lp <= SEG;
-    best = 0; best_row = 0;
+__device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c0 = (uint32_t)tid * CPL;
+    const bool act = c0 < Lp;
+    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
+    {
+        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
+#pragma unroll
+        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
+#pragma unroll
+        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
+    }
     int32_t h1[CPL], f1[CPL], h2[WIN > 1 ? CPL : 1], f2[WIN > 1 ? CPL : 1];
 #pragma unroll
     for (int t = 0; t < CPL; ++t) { h1[t] = 0; f1[t] = POA_NEG; }
@@ -238,7 +281,10 @@ __device__ void dp_rows(poa_ws &S, const poa_args &A, uint32_t n, uint32_t L, ui
 #pragma unroll
         for (int t = 0; t < CPL; ++t) { h2[t] = 0; f2[t] = POA_NEG; }
     }
+    int32_t hl1 = 0, hl2 = 0;                    // H[row1][c0], H[row2][c0] (column left of the block)
     uint32_t row1 = 0xFFFFFFFFu, row2 = 0xFFFFFFFFu;
+    int32_t my_best = 0;
+    uint32_t my_best_row = 0;
     for (uint32_t r0 = 0; r0 < n; r0 += 64) {
         const uint32_t nb = min(64u, n - r0);
         uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
@@ -248,105 +294,111 @@ __device__ void dp_rows(poa_ws &S, const poa_args &A, uint32_t n, uint32_t L, ui
             const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
                                     (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
             const uint32_t row = r0 + i + 1;
+            const uint32_t par = row & 1u;
             const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
-            int16_t *Hr = S.H + (uint64_t)row * Lp;
-            int16_t *Fr = S.F + (uint64_t)row * Lp;
-            int16_t *Er = S.E + (uint64_t)row * Lp;
-            int32_t row_max = 0;
-            int32_t carry_e = POA_NEG;      // E' prefix max entering the segment
-            int32_t carry_hn = 0;           // Hn left of the segment (column 0: H = 0)
-            if (!one_seg) __syncthreads();  // rows read below may need another lane's last column
-            for (uint32_t seg = 0; seg < Lp; seg += SEG) {
-                const uint32_t c0 = seg + lane * CPL;
-                const bool act = c0 < Lp;
-                int32_t hn[CPL], fr[CPL], hv[CPL], ev[CPL];
-                uint32_t sw[CPL / 4];
-                {
-                    const uint2 *sp = (const uint2 *)(S.sq + (act ? c0 : 0));
+            int32_t hn[CPL], fr[CPL];
 #pragma unroll
-                    for (int u = 0; u < CPL / 8; ++u) { const uint2 x = sp[u]; sw[2 * u] = x.x; sw[2 * u + 1] = x.y; }
-#pragma unroll
-                    for (int t = 0; t < CPL; ++t) { hn[t] = POA_NEG; fr[t] = POA_NEG; }
+            for (int t = 0; t < CPL; ++t) { hn[t] = POA_NEG; fr[t] = POA_NEG; }
+            uint32_t e = more;
+            for (uint32_t k = 0; k < (n_in ? n_in : 1u); ++k) {
+                int32_t hp[CPL], fp[CPL];
+                int32_t hl = 0;                  // H[p][c0] for lane 0 of waves 1..3
+                uint32_t prow = 0;
+                if (n_in) {
+                    if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
+                    else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
                 }
-                uint32_t e = more;
-                for (uint32_t k = 0; k < (n_in ? n_in : 1u); ++k) {
-                    int32_t hp[CPL], fp[CPL];
-                    int32_t seg_left = 0;
-                    uint32_t prow = 0;
-                    if (n_in) {
-                        if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
-                        else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
-                    }
-                    if (n_in == 0) {
+                if (n_in == 0) {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
+                } else if (prow == row1) {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hp[t] = h1[t]; fp[t] = f1[t]; }
+                    hl = hl1;
+                } else if (WIN > 1 && prow == row2) {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hp[t] = h2[t]; fp[t] = f2[t]; }
+                    hl = hl2;
+                } else {
+                    const int16_t *Hp = S.H + (uint64_t)prow * Lp;
+                    const int16_t *Fp = S.F + (uint64_t)prow * Lp;
+                    if (act) {
+                        load_block<CPL>(Hp + c0, hp);
+                        load_block<CPL>(Fp + c0, fp);
+                        if (lane == 0 && wave > 0) hl = (int32_t)Hp[c0 - 1];
+                    } else {
 #pragma unroll
                         for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
-                    } else if (one_seg && prow == row1) {
-#pragma unroll
-                        for (int t = 0; t < CPL; ++t) { hp[t] = h1[t]; fp[t] = f1[t]; }
-                    } else if (WIN > 1 && one_seg && prow == row2) {
-#pragma unroll
-                        for (int t = 0; t < CPL; ++t) { hp[t] = h2[t]; fp[t] = f2[t]; }
-                    } else {
-                        const int16_t *Hp = S.H + (uint64_t)prow * Lp;
-                        const int16_t *Fp = S.F + (uint64_t)prow * Lp;
-                        if (act) {
-                            load_block<CPL>(Hp + c0, hp);
-                            load_block<CPL>(Fp + c0, fp);
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
-                        }
-                        if (seg != 0) seg_left = (int32_t)Hp[seg - 1];
-                    }
-                    const int32_t hleft = wave_shr1(hp[CPL - 1], seg_left);    // H[p][j-1] of the lane's first column
-#pragma unroll
-                    for (int t = 0; t < CPL; ++t) {
-                        const int32_t hl = t == 0 ? hleft : hp[t - 1];
-                        const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-                        hn[t] = max(hn[t], hl + sc);
-                        fr[t] = max(fr[t], max(hp[t] + POA_G, fp[t] + POA_E));
                     }
                 }
-                // Hn = max(diag, F, 0); t_j = Hn[j-1] + g - j*e; E'[j] = prefix max; E[j] = E'[j] + j*e
-#pragma unroll
-                for (int t = 0; t < CPL; ++t) hn[t] = max(max(hn[t], fr[t]), 0);
-                const int32_t left_hn = wave_shr1(hn[CPL - 1], carry_hn);
-                int32_t run = POA_NEG;
+                const int32_t hleft = wave_shr1(hp[CPL - 1], hl);      // H[p][j-1] of the thread's first column
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) {
-                    const int32_t j = (int32_t)(c0 + t) + 1;
-                    const int32_t hl = t == 0 ? left_hn : hn[t - 1];
-                    run = max(run, hl + POA_G - j * POA_E);
-                    ev[t] = run;
+                    const int32_t hd = t == 0 ? hleft : hp[t - 1];
+                    const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                    hn[t] = max(hn[t], hd + sc);
+                    fr[t] = max(fr[t], max(hp[t] + POA_G, fp[t] + POA_E));
                 }
-                const int32_t incl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
-                const int32_t excl = max(wave_shr1(incl, POA_NEG), carry_e);
-                int32_t lane_max = 0;
-#pragma unroll
-                for (int t = 0; t < CPL; ++t) {
-                    const int32_t j = (int32_t)(c0 + t) + 1;
-                    ev[t] = max(ev[t], excl) + j * POA_E;
-                    hv[t] = max(hn[t], ev[t]);
-                    if (c0 + t < L) lane_max = max(lane_max, hv[t]);
-                }
-                if (act) {
-                    store_block<CPL>(Hr + c0, hv);
-                    store_block<CPL>(Fr + c0, fr);
-                    store_block<CPL>(Er + c0, ev);
-                }
-                if (WIN > 1) {
-#pragma unroll
-                    for (int t = 0; t < CPL; ++t) { h2[t] = h1[t]; f2[t] = f1[t]; }
-                }
-#pragma unroll
-                for (int t = 0; t < CPL; ++t) { h1[t] = hv[t]; f1[t] = fr[t]; }
-                carry_e = max(wave_last(incl), carry_e);
-                carry_hn = wave_last(hn[CPL - 1]);
-                row_max = max(row_max, wave_last(wave_scan_max(lane_max, 0)));
             }
-            row2 = row1; row1 = row;
-            if (row_max > best) { best = row_max; best_row = row; }
+            int32_t ex[CPL];                     // in-thread exclusive prefix max of u
+            int32_t run = POA_NEG;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                hn[t] = max(max(hn[t], fr[t]), 0);
+                ex[t] = run;
+                run = max(run, hn[t] + POA_G - ((int32_t)(c0 + t) + 2) * POA_E);     // u_j, j = c0+t+1
+            }
+            const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
+            const int32_t texcl = wave_shr1(wincl, POA_NEG);
+            if (lane == 63) { X.T[par][wave] = wincl; X.Tp[par][wave] = max(texcl, ex[CPL - 1]); X.Hn[par][wave] = hn[CPL - 1]; }
+            __syncthreads();
+            int32_t base = POA_G - POA_E;        // u_0
+            int32_t hl_new = 0;
+            if (wave > 0) {
+                int32_t bp = POA_G - POA_E;
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    if (w < wave - 1) bp = max(bp, X.T[par][w]);
+                    if (w < wave) base = max(base, X.T[par][w]);
+                }
+                const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);            // 1-based index of the column left of the wave
+                hl_new = max(X.Hn[par][wave - 1], max(bp, X.Tp[par][wave - 1]) + c0w * POA_E);
+            }
+            base = max(base, texcl);
+            int32_t hv[CPL], ev[CPL];
+            int32_t lane_max = 0;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int32_t j = (int32_t)(c0 + t) + 1;
+                ev[t] = max(base, ex[t]) + j * POA_E;
+                hv[t] = max(hn[t], ev[t]);
+                if (c0 + t < L) lane_max = max(lane_max, hv[t]);
+            }
+            if (act) {
+                store_block<CPL>(S.H + (uint64_t)row * Lp + c0, hv);
+                store_block<CPL>(S.F + (uint64_t)row * Lp + c0, fr);
+                store_block<CPL>(S.E + (uint64_t)row * Lp + c0, ev);
+            }
+            if (WIN > 1) {
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) { h2[t] = h1[t]; f2[t] = f1[t]; }
+                hl2 = hl1; row2 = row1;
+            }
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { h1[t] = hv[t]; f1[t] = fr[t]; }
+            hl1 = hl_new; row1 = row;
+            const int32_t row_max = wave_last(wave_scan_max(lane_max, 0));
+            if (row_max > my_best) { my_best = row_max; my_best_row = row; }
         }
+    }
+    if (lane == 0) { X.best[wave] = my_best; X.best_row[wave] = my_best_row; }
+    __syncthreads();
+    best = 0; best_row = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int32_t b = X.best[w];
+        const uint32_t r = X.best_row[w];
+        if (b > best || (b == best && b > 0 && r < best_row)) { best = b; best_row = r; }
     }
     __syncthreads();
 }
@@ -397,11 +449,14 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
-__global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
+template <int CPL, int WIN>
+__global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
     __shared__ uint32_t s_bc[8];
-    const int lane = threadIdx.x;
+    __shared__ dp_xchg X;
+    const int tid = threadIdx.x;
+    const bool w0 = tid < 64;                 // wave 0 runs the serial graph phases
     poa_ws S;
     {
         uint8_t *base = A.arena + (uint64_t)blockIdx.x * A.slot_stride;
@@ -416,7 +471,7 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
 
     while (true) {
         __syncthreads();
-        if (lane == 0) s_pack = atomicAdd(A.queue_head, 1u);
+        if (tid == 0) s_pack = atomicAdd(A.queue_head, 1u);
         __syncthreads();
         const uint32_t qi = s_pack;
         if (qi >= A.n_queue) break;
@@ -434,18 +489,21 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
             uint32_t n_aln = 0;
             if (S.n_nodes > 0) {
                 const uint32_t n = S.n_nodes;
-                // columns per lane: 16 (<= 1024 columns in one segment), 24 (<= 1536), else 16 with segments
-                const uint32_t cpl = (L > 1024 && L <= 1536) ? 24u : 16u;
-                const uint32_t Lp = (L + cpl - 1) / cpl * cpl;
-                if ((uint64_t)(n + 1) * Lp > A.cell_cap) { S.err = POA_ERR_CELLS; break; }
-                // ---- 1. toposort ----
+                const uint32_t Lp = (L + CPL - 1) / CPL * CPL;
+                if ((uint64_t)(n + 1) * Lp > A.cell_cap || Lp > 256u * CPL) { S.err = POA_ERR_CELLS; break; }
+                // ---- 1. toposort (wave 0) ----
                 unsigned long long t0 = PT_NOW();
-                uint32_t n_emit, n_cols;
-                toposort(S, A, 0, n_emit, n_cols);
+                if (w0) {
+                    uint32_t n_emit, n_cols;
+                    toposort(S, A, 0, n_emit, n_cols);
+                    if (!S.err && n_emit != n) S.err = POA_ERR_GRAPH;
+                    if (tid == 0) s_bc[4] = S.err;
+                }
+                __syncthreads();
+                S.err = s_bc[4];
                 if (S.err) break;
-                if (n_emit != n) { S.err = POA_ERR_GRAPH; break; }
-                // ---- 2. plan + sequence to LDS ----
-                for (uint32_t r = lane; r < n; r += 64) {
+                // ---- 2. plan + sequence to LDS (all threads) ----
+                for (uint32_t r = tid; r < n; r += 256) {
                     const uint32_t v = S.order[r];
                     const uint4 rec = S.nrec[v];
                     const uint32_t n_in = rd_nin(rec.x);
@@ -459,29 +517,26 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                     S.plan[r] = make_uint4(rec.x, v, e, 0);
                     S.planb[r] = pr;
                 }
-                for (uint32_t t = lane; t < Lp; t += 64) S.sq[t] = t < L ? s[t] : 0;
+                for (uint32_t t = tid; t < Lp; t += 256) S.sq[t] = t < L ? s[t] : 0;
                 __syncthreads();
                 unsigned long long t1 = PT_NOW();
                 t_topo += t1 - t0;
-                // ---- 3. DP ----
+                // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
-                if (cpl == 24) dp_rows<24, 1>(S, A, n, L, Lp, best, best_row);
-                else dp_rows<16, 2>(S, A, n, L, Lp, best, best_row);
+                dp_rows<CPL, WIN>(S, X, n, L, Lp, best, best_row);
                 cells += (unsigned long long)n * L;
                 rows += n;
                 unsigned long long t2 = PT_NOW();
                 t_dp += t2 - t1;
-#ifdef POA_BENCH_NOTB
-                best = 0;
-#endif
                 if (best > 0) {
                     // ---- 4. best cell + traceback ----
                     const int16_t *Hb = S.H + (uint64_t)best_row * Lp;
-                    uint32_t bj = 0xFFFFFFFFu;
-                    for (uint32_t c = lane; c < L; c += 64) if ((int32_t)Hb[c] == best) { bj = c + 1; break; }
-#pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) bj = min(bj, (uint32_t)__shfl_xor((int)bj, d, 64));
-                    if (lane == 0) {
+                    if (tid == 0) s_bc[5] = 0xFFFFFFFFu;
+                    __syncthreads();
+                    for (uint32_t c = tid; c < L; c += 256) if ((int32_t)Hb[c] == best) { atomicMin(&s_bc[5], c + 1); break; }
+                    __syncthreads();
+                    const uint32_t bj = s_bc[5];
+                    if (tid == 0) {
                         uint32_t i = best_row, j = bj, cnt = 0, err = 0;
                         const int16_t *H = S.H, *F = S.F, *E = S.E;
                         auto Hat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? 0 : (int32_t)H[(uint64_t)r * Lp + c - 1]; };
@@ -548,14 +603,6 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                             }
                         }
                         s_bc[0] = cnt; s_bc[1] = err;
-#ifdef POA_DEBUG
-                        printf("seq %u: n=%u L=%u Lp=%u best=%d row=%u col=%u n_aln=%u err=%u\n", q, n, L, Lp, best, best_row, bj, cnt, err);
-                        for (uint32_t r = 1; r <= n && r <= 24; ++r) { printf("H[%2u]:", r); for (uint32_t c = 1; c <= L; ++c) printf(" %3d", Hat(r, c)); printf("\n"); }
-                        for (uint32_t t = 0; t < cnt; ++t) printf("(%d,%d) ", S.aln[2 * t], S.aln[2 * t + 1]);
-                        printf("\n");
-                        for (uint32_t r = 1; r <= n && r <= 24; ++r) { printf("F[%2u]:", r); for (uint32_t c = 1; c <= L; ++c) printf(" %3d", Fat(r, c)); printf("\n"); }
-                        for (uint32_t r = 1; r <= 0; ++r) { printf("E[%2u]:", r); for (uint32_t c = 1; c <= L; ++c) printf(" %3d", Eat(r, c)); printf("\n"); }
-#endif
                     }
                     __syncthreads();
                     n_aln = s_bc[0];
@@ -563,9 +610,9 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
                 }
                 t_tb += PT_NOW() - t2;
             }
-            // ---- 5. add_alignment (lane 0) ----
+            // ---- 5. add_alignment (thread 0) ----
             unsigned long long t3 = PT_NOW();
-            if (lane == 0) {
+            if (tid == 0) {
                 if (n_aln == 0) {
                     g_add_chain(S, A, s, 0, L, path);
                 } else {
@@ -646,19 +693,25 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
         }
 
         // ---- generate_multiple_sequence_alignment: column per node, then per base ----
-        uint32_t width = 0;
+        __syncthreads();
+        if (tid == 0) { s_bc[6] = 0; s_bc[4] = S.err; }
+        __syncthreads();
         if (!S.err && S.n_nodes > 0) {
-            uint32_t n_emit, n_cols;
-            toposort(S, A, 1, n_emit, n_cols);
-            if (!S.err && n_emit != S.n_nodes) S.err = POA_ERR_GRAPH;
-            width = n_cols;
+            if (w0) {
+                uint32_t n_emit, n_cols;
+                toposort(S, A, 1, n_emit, n_cols);
+                if (!S.err && n_emit != S.n_nodes) S.err = POA_ERR_GRAPH;
+                if (tid == 0) { s_bc[6] = n_cols; s_bc[4] = S.err; }
+            }
             __syncthreads();
+            S.err = s_bc[4];
             if (!S.err) {
                 const uint64_t b0 = A.off[q0], b1 = A.off[q1];
-                for (uint64_t b = b0 + lane; b < b1; b += 64) A.out_col[b] = (uint32_t)S.rank[A.out_col[b]];
+                for (uint64_t b = b0 + tid; b < b1; b += 256) A.out_col[b] = (uint32_t)S.rank[A.out_col[b]];
             }
         }
-        if (lane == 0) {
+        const uint32_t width = s_bc[6];
+        if (tid == 0) {
             A.out_width[pk] = width;
             A.status[pk] = S.err;
             atomicAdd(&A.counters[0], cells);
@@ -676,6 +729,21 @@ __global__ __launch_bounds__(64) void poa_kernel(poa_args A) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
+template <int CPL, int WIN>
+static hipError_t launch_poa(const poa_args &A, uint32_t n_slots, size_t shm, hipStream_t st) {
+    if (shm > 60 * 1024)
+        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL((poa_kernel<CPL, WIN>), dim3(n_slots), dim3(256), shm, st, A);
+    return hipGetLastError();
+}
+
+template <int CPL, int WIN>
+static int max_blocks_per_cu(size_t shm) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, WIN>, 256, shm) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
 int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n_seqs, const uint32_t *pack_first,
                 uint32_t n_packs, rattle_msa_set **out) {
     hipStream_t st = ctx->stream;
@@ -688,17 +756,19 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
     const uint64_t total = off[n_seqs];
 
+    // columns-per-thread class of each pack (256 threads x CPL columns cover the longest sequence)
+    static const uint32_t class_cpl[5] = {4, 6, 8, 16, 24};
     std::vector<uint64_t> pbases(n_packs);
     std::vector<uint32_t> pmaxL(n_packs);
-    uint32_t maxL = 0;
+    std::vector<uint32_t> by_class[5];
     for (uint32_t p = 0; p < n_packs; ++p) {
         uint32_t m = 0;
         for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) m = std::max<uint32_t>(m, (uint32_t)(off[q + 1] - off[q]));
         pbases[p] = off[pack_first[p + 1]] - off[pack_first[p]];
         pmaxL[p] = m;
-        maxL = std::max(maxL, m);
+        if (m > 256u * 24u) { set_error("sequence too long for the int16 POA kernel (> 6144 nt)"); return RATTLE_ERR_ARG; }
+        by_class[m <= 1024 ? 0 : m <= 1536 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 3 : 4].push_back(p);
     }
-    if (5ull * maxL + 16 > 32000) { set_error("sequence too long for the int16 POA kernel (> 6396 nt)"); return RATTLE_ERR_ARG; }
     if (total && memchr(seq, 0, total)) { set_error("NUL byte in sequence"); return RATTLE_ERR_ARG; }
 
     dbuf<uint8_t> d_seq; dbuf<uint64_t> d_off; dbuf<uint32_t> d_pf, d_queue, d_head, d_col, d_width, d_status;
@@ -711,80 +781,89 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     RT_HIP(hipMemcpyAsync(d_pf.p, pack_first, (n_packs + 1) * 4, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemsetAsync(d_cnt.p, 0, 64, st));
     RT_HIP(hipMemsetAsync(d_status.p, 0xFF, n_packs * 4, st));
-
-    std::vector<uint32_t> todo(n_packs);
-    for (uint32_t p = 0; p < n_packs; ++p) todo[p] = p;
     std::vector<uint32_t> h_status(n_packs), h_width(n_packs);
 
     size_t free_b = 0, total_b = 0;
     RT_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += ctx->poa_arena_bytes;            // the cached arena is ours to reuse
-    // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas
-    uint32_t node_cap = 16384;
-    uint64_t cell_cap = 24ull << 20;           // elements per matrix (x3 matrices x2 bytes = 144 MiB)
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    const uint32_t n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
     int rc = 0;
-    for (int round = 0; round < 6 && !todo.empty() && rc == 0; ++round) {
-        std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
-        uint64_t tb = 0; uint32_t tl = 0;
-        for (uint32_t p : todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
-        uint32_t ncap = (uint32_t)std::min<uint64_t>(node_cap, tb + 1);
-        ncap = (ncap + 31u) & ~31u;
-        const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
-        const uint32_t acap = tl + ncap + 16;
-        const uint32_t scap = ncap + POA_STACK;
-        const uint32_t qcap = ((tl + 23u) / 24u * 24u + 15u) & ~15u;      // covers both column-per-lane paddings
-        const uint64_t ccap = std::min<uint64_t>(cell_cap, (uint64_t)(ncap + 1) * qcap);
-        poa_args A;
-        uint64_t o = 0;
-        auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
-        A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
-        A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
-        A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
-        A.o_aln = take((uint64_t)acap * 8); A.o_spill = take((uint64_t)scap * 4);
-        const uint64_t per_slot = o;
-        const uint64_t budget = (uint64_t)(free_b * 0.85);
-        const uint32_t max_slots = (uint32_t)std::max<uint64_t>(1, budget / per_slot);
-        const uint32_t n_slots = std::min<uint32_t>((uint32_t)todo.size(), std::min<uint32_t>(max_slots, 256 * 8));
-        phase_timer T_round("    poa round (arena+kernel)");
-        if (getenv("RATTLE_TIMING")) fprintf(stderr, "[rattle]     poa round %d: %zu packs, %u slots x %.1f MB\n", round, todo.size(), n_slots, per_slot / 1e6);
-        if (ctx->poa_arena_bytes < (size_t)per_slot * n_slots) {
-            if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
-            ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
-            if (hipMalloc((void **)&ctx->poa_arena, (size_t)per_slot * n_slots) != hipSuccess) {
-                set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break;
+    for (int cls = 0; cls < 5 && rc == 0; ++cls) {
+        std::vector<uint32_t> todo = by_class[cls];
+        const uint32_t cpl = class_cpl[cls];
+        // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas
+        uint32_t node_cap = 16384;
+        uint64_t cell_cap = 24ull << 20;           // elements per matrix (x3 matrices x2 bytes = 144 MiB)
+        for (int round = 0; round < 6 && !todo.empty() && rc == 0; ++round) {
+            std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
+            uint64_t tb = 0; uint32_t tl = 0;
+            for (uint32_t p : todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
+            uint32_t ncap = (uint32_t)std::min<uint64_t>(node_cap, tb + 1);
+            ncap = (ncap + 31u) & ~31u;
+            const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
+            const uint32_t acap = tl + ncap + 16;
+            const uint32_t scap = ncap + POA_STACK;
+            const uint32_t qcap = ((tl + cpl - 1) / cpl * cpl + 15u) & ~15u;
+            const uint64_t ccap = std::min<uint64_t>(cell_cap, (uint64_t)(ncap + 1) * qcap);
+            poa_args A;
+            uint64_t o = 0;
+            auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
+            A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
+            A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4);
+            A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
+            A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
+            A.o_aln = take((uint64_t)acap * 8); A.o_spill = take((uint64_t)scap * 4);
+            const uint64_t per_slot = o;
+            const size_t shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4;
+            const int bpc = cls == 0 ? max_blocks_per_cu<4, 2>(shm) : cls == 1 ? max_blocks_per_cu<6, 2>(shm)
+                          : cls == 2 ? max_blocks_per_cu<8, 2>(shm) : cls == 3 ? max_blocks_per_cu<16, 1>(shm)
+                                                                    : max_blocks_per_cu<24, 1>(shm);
+            const uint64_t budget = (uint64_t)(free_b * 0.85);
+            const uint32_t max_slots = (uint32_t)std::max<uint64_t>(1, budget / per_slot);
+            const uint32_t n_slots = std::min<uint32_t>((uint32_t)todo.size(), std::min<uint32_t>(max_slots, n_cu * (uint32_t)bpc));
+            phase_timer T_round("    poa round (arena+kernel)");
+            if (getenv("RATTLE_TIMING"))
+                fprintf(stderr, "[rattle]     poa class %u round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n", cpl, round, todo.size(),
+                        n_slots, per_slot / 1e6, bpc);
+            if (ctx->poa_arena_bytes < (size_t)per_slot * n_slots) {
+                if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
+                ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
+                if (hipMalloc((void **)&ctx->poa_arena, (size_t)per_slot * n_slots) != hipSuccess) {
+                    set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break;
+                }
+                ctx->poa_arena_bytes = (size_t)per_slot * n_slots;
             }
-            ctx->poa_arena_bytes = (size_t)per_slot * n_slots;
+            hipError_t e = hipMemcpyAsync(d_queue.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemsetAsync(d_head.p, 0, 4, st);
+            if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
+            A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p; A.n_queue = (uint32_t)todo.size();
+            A.queue_head = d_head.p; A.arena = ctx->poa_arena; A.slot_stride = per_slot;
+            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
+            A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p;
+            {
+                ktimer T(ctx, K_POA, 0);
+                e = cls == 0 ? launch_poa<4, 2>(A, n_slots, shm, st) : cls == 1 ? launch_poa<6, 2>(A, n_slots, shm, st)
+                  : cls == 2 ? launch_poa<8, 2>(A, n_slots, shm, st) : cls == 3 ? launch_poa<16, 1>(A, n_slots, shm, st)
+                                                                     : launch_poa<24, 1>(A, n_slots, shm, st);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
+            std::vector<uint32_t> again;
+            for (uint32_t p : todo) {
+                const uint32_t s = h_status[p];
+                if (s == POA_OK) continue;
+                if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) again.push_back(p);
+                else { set_error("poa_kernel: pack " + std::to_string(p) + " failed with status " + std::to_string(s)); rc = RATTLE_ERR_HIP; break; }
+            }
+            todo.swap(again);
+            node_cap = std::min<uint32_t>(node_cap * 4, 1u << 20);
+            cell_cap *= 8;
         }
-        uint8_t *arena = ctx->poa_arena;
-        hipError_t e = hipMemcpyAsync(d_queue.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemsetAsync(d_head.p, 0, 4, st);
-        if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
-        A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p; A.n_queue = (uint32_t)todo.size();
-        A.queue_head = d_head.p; A.arena = arena; A.slot_stride = per_slot;
-        A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
-        A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p;
-        const size_t shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4;
-        if (shm > 60 * 1024) (void)hipFuncSetAttribute((const void *)poa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        {
-            ktimer T(ctx, K_POA, 0);
-            hipLaunchKernelGGL(poa_kernel, dim3(n_slots), dim3(64), shm, st, A);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
-        std::vector<uint32_t> again;
-        for (uint32_t p : todo) {
-            const uint32_t s = h_status[p];
-            if (s == POA_OK) continue;
-            if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) again.push_back(p);
-            else { set_error("poa_kernel: pack " + std::to_string(p) + " failed with status " + std::to_string(s)); rc = RATTLE_ERR_HIP; break; }
-        }
-        todo.swap(again);
-        node_cap = std::min<uint32_t>(node_cap * 4, 1u << 20);
-        cell_cap *= 8;
+        if (rc == 0 && !todo.empty()) { set_error("poa: " + std::to_string(todo.size()) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
-    if (rc == 0 && !todo.empty()) { set_error("poa: " + std::to_string(todo.size()) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     std::vector<uint32_t> h_col;
     unsigned long long h_cnt[8] = {0};
     if (rc == 0) {
