@@ -59,10 +59,11 @@ struct poa_args {
     uint32_t *queue_head;
     uint8_t *arena;                // n_slots * slot_stride bytes
     uint64_t slot_stride;
-    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_plan, o_planb, o_H, o_F, o_E, o_aln, o_spill;
+    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_order2, o_srank, o_rowmax, o_nn, o_plan, o_planb, o_H, o_F, o_E, o_aln, o_spill;
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
+    uint32_t lds_topo;             // 1: compact node topology (first in-edge, degrees) mirrored in LDS
     uint32_t *out_col;             // per base: node id during the run, MSA column at the end
     uint32_t *out_width;           // per pack
     uint32_t *status;              // per pack: 0 ok, else error code
@@ -80,12 +81,16 @@ enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_
 struct poa_ws {                    // per-block workspace: global pointers + LDS + wave-uniform state
     uint4 *nrec, *nal, *plan, *planb;
     uint2 *edges;
-    int32_t *rank;
-    uint32_t *order;
+    int32_t *rank;                         // node -> DP row - 1 (block order), MSA column in the final pass
+    uint32_t *order, *order2;              // DP row - 1 -> node (double buffer for the incremental merge)
+    int32_t *srank;                        // spoa rank per node (only computed when best rows tie)
+    int32_t *rowmax;                       // [row][wave] row maximum of H
+    uint32_t *nn;                          // new nodes of the last add_alignment: (node, anchor) pairs in path order
     int16_t *H, *F, *E;
     int32_t *aln;
     uint32_t *spill;
     uint32_t *done, *nocheck, *stack;      // LDS
+    uint32_t *topo;                        // LDS: in0 | min(n_in,63) << 20 | n_al << 26 per node, or nullptr
     uint8_t *sq;                           // LDS copy of the sequence, 16-byte aligned
     uint32_t n_nodes, n_edges, sp, spilled, err;
 };
@@ -95,6 +100,10 @@ __device__ __forceinline__ void bit_set(uint32_t *b, uint32_t i) { b[i >> 5] |= 
 __device__ __forceinline__ uint32_t rd_letter(uint32_t info) { return info & 0xFFu; }
 __device__ __forceinline__ uint32_t rd_nal(uint32_t info) { return (info >> 8) & 0xFFu; }
 __device__ __forceinline__ uint32_t rd_nin(uint32_t info) { return info >> 16; }
+__device__ __forceinline__ uint32_t topo_pack(const uint4 &rec) {
+    const uint32_t n_in = rd_nin(rec.x);
+    return (rec.y & 0xFFFFFu) | ((n_in < 63u ? n_in : 63u) << 20) | (rd_nal(rec.x) << 26);
+}
 __device__ __forceinline__ uint32_t u4_get(const uint4 &v, uint32_t k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 __device__ __forceinline__ void u4_set(uint4 &v, uint32_t k, uint32_t x) { if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x; }
 
@@ -146,7 +155,9 @@ __device__ __forceinline__ void st_refill(poa_ws &S) {
 }
 
 // ---- spoa Graph::topological_sort ----------------------------------------------------------------
-// mode 0: order[]/rank[];  mode 1: rank[] receives the MSA column of each node.
+// mode 1: rank[] receives the MSA column of each node (final pass);  mode 2: srank[] receives
+// the spoa rank (tie-break of best rows).  The DP itself runs in the incrementally maintained
+// block order (see merge_order), which is a topological order with aligned groups contiguous.
 __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emit, uint32_t &n_cols) {
     const uint32_t n = S.n_nodes;
     for (uint32_t t = threadIdx.x; t < (n + 31) / 32; t += 64) { S.done[t] = 0; S.nocheck[t] = 0; }
@@ -162,12 +173,19 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
             if (S.sp == 0) break;
             const uint32_t v = S.stack[S.sp - 1];
             if (bit_get(S.done, v)) { --S.sp; continue; }
-            const uint4 rec = S.nrec[v];
-            const uint32_t n_in = rd_nin(rec.x), n_al = rd_nal(rec.x);
+            uint32_t n_in, n_al, in0, more;
+            if (S.topo) {
+                const uint32_t w = S.topo[v];
+                in0 = w & 0xFFFFFu; n_in = (w >> 20) & 63u; n_al = w >> 26; more = POA_NONE;
+                if (n_in > 1) { const uint4 rec = S.nrec[v]; n_in = rd_nin(rec.x); more = rec.z; }
+            } else {
+                const uint4 rec = S.nrec[v];
+                n_in = rd_nin(rec.x); n_al = rd_nal(rec.x); in0 = rec.y; more = rec.z;
+            }
             bool valid = true;
             if (n_in > 0) {
-                if (!bit_get(S.done, rec.y)) { st_push(S, A, rec.y); valid = false; }
-                uint32_t e = rec.z;
+                if (!bit_get(S.done, in0)) { st_push(S, A, in0); valid = false; }
+                uint32_t e = more;
                 for (uint32_t k = 1; k < n_in; ++k) {
                     const uint2 ed = S.edges[e];
                     e = ed.y;
@@ -191,7 +209,7 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
                 const uint32_t u = g == 0 ? v : u4_get(al, g - 1);
                 if (l0) {
                     if (mode == 1) S.rank[u] = (int32_t)n_cols;
-                    else { S.rank[u] = (int32_t)n_emit; S.order[n_emit] = u; }
+                    else S.srank[u] = (int32_t)n_emit;
                 }
                 ++n_emit;
             }
@@ -388,6 +406,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             for (int t = 0; t < CPL; ++t) { h1[t] = hv[t]; f1[t] = fr[t]; }
             hl1 = hl_new; row1 = row;
             const int32_t row_max = wave_last(wave_scan_max(lane_max, 0));
+            if (lane == 0) S.rowmax[row * 4 + wave] = row_max;
             if (row_max > my_best) { my_best = row_max; my_best_row = row; }
         }
     }
@@ -407,6 +426,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
 __device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
     if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return 0; }
     S.nrec[S.n_nodes] = make_uint4(letter, 0, POA_NONE, POA_NONE);
+    if (S.topo) S.topo[S.n_nodes] = 0;
     return S.n_nodes++;
 }
 
@@ -432,6 +452,7 @@ __device__ void g_add_edge(poa_ws &S, const poa_args &A, uint32_t b, uint32_t en
     if (n_in >= 0xFFFF) { S.err = POA_ERR_GRAPH; return; }
     nd.x += 1u << 16;
     S.nrec[en] = nd;
+    if (S.topo) S.topo[en] = topo_pack(nd);
 }
 
 // Graph::add_sequence(b, e): fresh chain; returns first node or -1.  Records the path.
@@ -444,6 +465,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
         if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return -1; }
         const uint32_t id = S.n_nodes++;
         S.nrec[id] = make_uint4((uint32_t)s[i] | (1u << 16), id - 1, POA_NONE, POA_NONE);     // its only in-edge
+        if (S.topo) S.topo[id] = (id - 1) | (1u << 20);
         path[i] = id;
     }
     return (int32_t)first;
@@ -461,12 +483,14 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
     {
         uint8_t *base = A.arena + (uint64_t)blockIdx.x * A.slot_stride;
         S.nrec = (uint4 *)(base + A.o_nrec); S.nal = (uint4 *)(base + A.o_nal); S.edges = (uint2 *)(base + A.o_edges);
-        S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb);
+        S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.order2 = (uint32_t *)(base + A.o_order2);
+        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb);
         S.H = (int16_t *)(base + A.o_H); S.F = (int16_t *)(base + A.o_F); S.E = (int16_t *)(base + A.o_E);
         S.aln = (int32_t *)(base + A.o_aln); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = (A.node_cap + 31) / 32;
         S.sq = (uint8_t *)lds;                                   // seq_cap bytes (multiple of 16)
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
+        S.topo = A.lds_topo ? S.stack + POA_STACK : nullptr;
     }
 
     while (true) {
@@ -491,17 +515,8 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                 const uint32_t n = S.n_nodes;
                 const uint32_t Lp = (L + CPL - 1) / CPL * CPL;
                 if ((uint64_t)(n + 1) * Lp > A.cell_cap || Lp > 256u * CPL) { S.err = POA_ERR_CELLS; break; }
-                // ---- 1. toposort (wave 0) ----
+                // ---- 1. rows are taken in the incrementally maintained block order (merge_order) ----
                 unsigned long long t0 = PT_NOW();
-                if (w0) {
-                    uint32_t n_emit, n_cols;
-                    toposort(S, A, 0, n_emit, n_cols);
-                    if (!S.err && n_emit != n) S.err = POA_ERR_GRAPH;
-                    if (tid == 0) s_bc[4] = S.err;
-                }
-                __syncthreads();
-                S.err = s_bc[4];
-                if (S.err) break;
                 // ---- 2. plan + sequence to LDS (all threads) ----
                 for (uint32_t r = tid; r < n; r += 256) {
                     const uint32_t v = S.order[r];
@@ -529,6 +544,43 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                 unsigned long long t2 = PT_NOW();
                 t_dp += t2 - t1;
                 if (best > 0) {
+                    // spoa takes the first maximum in ITS rank order: when several rows reach the best
+                    // score, run its topological sort and keep the row with the smallest rank
+                    if (tid == 0) { s_bc[5] = 0; s_bc[7] = 0xFFFFFFFFu; }
+                    __syncthreads();
+                    {
+                        uint32_t cnt = 0;
+                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
+                            cnt += max(max(m.x, m.y), max(m.z, m.w)) == best ? 1u : 0u;
+                        }
+                        if (cnt) atomicAdd(&s_bc[5], cnt);
+                    }
+                    __syncthreads();
+                    if (s_bc[5] > 1) {
+                        if (w0) {
+                            uint32_t n_emit, n_cols;
+                            toposort(S, A, 2, n_emit, n_cols);
+                            if (!S.err && n_emit != n) S.err = POA_ERR_GRAPH;
+                            if (tid == 0) s_bc[4] = S.err;
+                        }
+                        __syncthreads();
+                        S.err = s_bc[4];
+                        if (S.err) break;
+                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
+                            if (max(max(m.x, m.y), max(m.z, m.w)) == best) atomicMin(&s_bc[7], (uint32_t)S.srank[S.order[r - 1]]);
+                        }
+                        __syncthreads();
+                        const uint32_t want = s_bc[7];
+                        __syncthreads();
+                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
+                            if (max(max(m.x, m.y), max(m.z, m.w)) == best && (uint32_t)S.srank[S.order[r - 1]] == want) s_bc[7] = r;
+                        }
+                        __syncthreads();
+                        best_row = s_bc[7];
+                    }
                     // ---- 4. best cell + traceback ----
                     const int16_t *Hb = S.H + (uint64_t)best_row * Lp;
                     if (tid == 0) s_bc[5] = 0xFFFFFFFFu;
@@ -611,10 +663,19 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                 t_tb += PT_NOW() - t2;
             }
             // ---- 5. add_alignment (thread 0) ----
+            // Besides spoa's graph update, every NEW node is recorded with the position (in the
+            // current row order) it must be inserted before: an unaligned run goes right before
+            // the aligned group of the next graph node on the path, a mismatch node right after
+            // the group it joins, trailing nodes at the end.  Anchors are non-decreasing along
+            // the path, so merge_order below is a stable merge.
             unsigned long long t3 = PT_NOW();
+            const uint32_t n_old = S.n_nodes;
             if (tid == 0) {
+                uint32_t T = 0;
+                auto nn_push = [&](uint32_t node, uint32_t anchor) { S.nn[2 * T] = node; S.nn[2 * T + 1] = anchor; ++T; };
                 if (n_aln == 0) {
                     g_add_chain(S, A, s, 0, L, path);
+                    if (!S.err) for (uint32_t i = 0; i < L; ++i) nn_push(n_old + i, n_old);
                 } else {
                     // pairs are stored reversed: forward pair t = aln[n_aln-1-t]
                     int32_t first_valid = -1, last_valid = -1;
@@ -625,7 +686,11 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                     const uint32_t before = S.n_nodes;
                     g_add_chain(S, A, s, 0, (uint32_t)first_valid, path);
                     int32_t head = before == S.n_nodes ? -1 : (int32_t)S.n_nodes - 1;
+                    uint32_t pa0 = before, pan = S.n_nodes - before;        // pending: prefix chain
+                    const uint32_t suf0 = S.n_nodes;
                     const int32_t tail = S.err ? -1 : g_add_chain(S, A, s, (uint32_t)last_valid + 1, L, path);
+                    const uint32_t sufn = S.n_nodes - suf0;
+                    uint32_t pb0 = 0, pbn = 0;                                  // pending: current insertion run
                     for (uint32_t t = 0; t < n_aln && !S.err; ++t) {
                         const int32_t an = S.aln[2 * (n_aln - 1 - t)], pos = S.aln[2 * (n_aln - 1 - t) + 1];
                         if (pos == -1) continue;
@@ -633,14 +698,31 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                         uint32_t cur;
                         if (an == -1) {
                             cur = g_add_node(S, A, letter);
+                            if (S.err) break;
+                            if (pbn == 0) pb0 = cur;
+                            ++pbn;
                         } else {
                             uint4 nd = S.nrec[an];
-                            if (rd_letter(nd.x) == letter) {
+                            const uint32_t n_al = rd_nal(nd.x);
+                            uint4 al = make_uint4(0, 0, 0, 0);
+                            if (n_al) al = S.nal[an];
+                            const bool same = rd_letter(nd.x) == letter;
+                            // old row range of an's aligned group (needed for pending nodes / a new sibling)
+                            uint32_t gs = 0, ge = 0;
+                            if (pan + pbn > 0 || !same) {
+                                gs = (uint32_t)S.rank[an]; ge = gs;
+                                for (uint32_t k = 0; k < n_al; ++k) {
+                                    const uint32_t r = (uint32_t)S.rank[u4_get(al, k)];
+                                    gs = min(gs, r); ge = max(ge, r);
+                                }
+                                ++ge;
+                                for (uint32_t i = 0; i < pan; ++i) nn_push(pa0 + i, gs);
+                                for (uint32_t i = 0; i < pbn; ++i) nn_push(pb0 + i, gs);
+                                pan = 0; pbn = 0;
+                            }
+                            if (same) {
                                 cur = (uint32_t)an;
                             } else {
-                                const uint32_t n_al = rd_nal(nd.x);
-                                uint4 al = make_uint4(0, 0, 0, 0);
-                                if (n_al) al = S.nal[an];
                                 int32_t hit = -1;
                                 for (uint32_t k = 0; k < n_al; ++k) {
                                     const uint32_t a = u4_get(al, k);
@@ -652,6 +734,7 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                                     if (n_al >= 4) { S.err = POA_ERR_GRAPH; break; }
                                     cur = g_add_node(S, A, letter);
                                     if (S.err) break;
+                                    nn_push(cur, ge);
                                     uint4 cal = make_uint4(0, 0, 0, 0);
                                     for (uint32_t k = 0; k < n_al; ++k) {
                                         const uint32_t a = u4_get(al, k);
@@ -683,12 +766,40 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                         head = (int32_t)cur;
                     }
                     if (!S.err && tail != -1) g_add_edge(S, A, (uint32_t)head, (uint32_t)tail);
+                    if (!S.err) {
+                        for (uint32_t i = 0; i < pan; ++i) nn_push(pa0 + i, n_old);
+                        for (uint32_t i = 0; i < pbn; ++i) nn_push(pb0 + i, n_old);
+                        for (uint32_t i = 0; i < sufn; ++i) nn_push(suf0 + i, n_old);
+                    }
                 }
+                if (!S.err && T != S.n_nodes - n_old) S.err = POA_ERR_GRAPH;
                 s_bc[2] = S.n_nodes; s_bc[3] = S.n_edges; s_bc[4] = S.err;
             }
             __syncthreads();
             S.n_nodes = s_bc[2]; S.n_edges = s_bc[3]; S.err = s_bc[4];
             __syncthreads();
+            // ---- 6. merge_order: insert the new nodes into the row order (all threads) ----
+            if (!S.err) {
+                const uint32_t T = S.n_nodes - n_old;
+                if (T > 0) {
+                    const uint32_t first = S.nn[1];
+                    for (uint32_t r = first + tid; r < n_old; r += 256) {
+                        uint32_t lo = 0, hi = T;                     // number of anchors <= r
+                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S.nn[2 * mid + 1] <= r) lo = mid + 1; else hi = mid; }
+                        const uint32_t v = S.order[r];
+                        S.order2[r + lo] = v;
+                        S.rank[v] = (int32_t)(r + lo);
+                    }
+                    for (uint32_t t = tid; t < T; t += 256) {
+                        const uint32_t v = S.nn[2 * t], pos = S.nn[2 * t + 1] + t;
+                        S.order2[pos] = v;
+                        S.rank[v] = (int32_t)pos;
+                    }
+                    __syncthreads();
+                    for (uint32_t r = first + tid; r < n_old + T; r += 256) S.order[r] = S.order2[r];
+                    __syncthreads();
+                }
+            }
             t_add += PT_NOW() - t3;
         }
 
@@ -794,7 +905,7 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         std::vector<uint32_t> todo = by_class[cls];
         const uint32_t cpl = class_cpl[cls];
         // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas
-        uint32_t node_cap = 16384;
+        uint32_t node_cap = 10240;
         uint64_t cell_cap = 24ull << 20;           // elements per matrix (x3 matrices x2 bytes = 144 MiB)
         for (int round = 0; round < 6 && !todo.empty() && rc == 0; ++round) {
             std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
@@ -811,12 +922,14 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
             uint64_t o = 0;
             auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
             A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
-            A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4);
+            A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
+            A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
             A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
             A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
             A.o_aln = take((uint64_t)acap * 8); A.o_spill = take((uint64_t)scap * 4);
             const uint64_t per_slot = o;
-            const size_t shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4;
+            const uint32_t lds_topo = 0u;      // LDS mirror of the node topology: measured no gain, costs occupancy
+            const size_t shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (lds_topo ? (size_t)ncap * 4 : 0);
             const int bpc = cls == 0 ? max_blocks_per_cu<4, 2>(shm) : cls == 1 ? max_blocks_per_cu<6, 2>(shm)
                           : cls == 2 ? max_blocks_per_cu<8, 2>(shm) : cls == 3 ? max_blocks_per_cu<16, 1>(shm)
                                                                     : max_blocks_per_cu<24, 1>(shm);
@@ -840,7 +953,7 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
             if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
             A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p; A.n_queue = (uint32_t)todo.size();
             A.queue_head = d_head.p; A.arena = ctx->poa_arena; A.slot_stride = per_slot;
-            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
+            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap; A.lds_topo = lds_topo;
             A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p;
             {
                 ktimer T(ctx, K_POA, 0);
