@@ -557,7 +557,34 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                         if (cnt) atomicAdd(&s_bc[5], cnt);
                     }
                     __syncthreads();
-                    if (s_bc[5] > 1) {
+                    // cheap exit: if every tied row except the first has a tied direct predecessor, all of
+                    // them descend from the first one, which then precedes them in ANY topological order
+                    bool need_sort = s_bc[5] > 1;
+                    if (need_sort) {
+                        __syncthreads();
+                        if (tid == 0) s_bc[5] = 0;
+                        __syncthreads();
+                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
+                            if (max(max(m.x, m.y), max(m.z, m.w)) != best || r == best_row) continue;
+                            const uint4 pl = S.plan[r - 1], plb = S.planb[r - 1];
+                            const uint32_t n_in = rd_nin(pl.x);
+                            bool ok = false;
+                            for (uint32_t k = 0; k < n_in && k < 4; ++k) {
+                                const uint32_t p = u4_get(plb, k);
+                                if (p == 0) continue;
+                                const int4 pm = *(const int4 *)(S.rowmax + p * 4);
+                                if (max(max(pm.x, pm.y), max(pm.z, pm.w)) == best) ok = true;
+                            }
+                            if (!ok) s_bc[5] = 1;
+                        }
+                        __syncthreads();
+                        need_sort = s_bc[5] != 0;
+#ifdef POA_PROFILE
+                        if (tid == 0) { atomicAdd(&A.counters[4], 1ull << 32); if (need_sort) atomicAdd(&A.counters[4], 1ull); }
+#endif
+                    }
+                    if (need_sort) {
                         if (w0) {
                             uint32_t n_emit, n_cols;
                             toposort(S, A, 2, n_emit, n_cols);
@@ -830,7 +857,7 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
             atomicAdd(&A.counters[2], (unsigned long long)S.n_nodes);
             atomicAdd(&A.counters[3], rows);
 #ifdef POA_PROFILE
-            atomicAdd(&A.counters[4], t_topo);         // toposort + plan (100 MHz ticks)
+            (void)t_topo;                              // counters[4]: ties << 32 | ties that needed the exact sort
             atomicAdd(&A.counters[5], t_dp);           // DP rows
             atomicAdd(&A.counters[6], t_tb);           // best cell + traceback
             atomicAdd(&A.counters[7], t_add);          // add_alignment
@@ -901,24 +928,48 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     RT_HIP(hipGetDeviceProperties(&prop, ctx->device));
     const uint32_t n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
     int rc = 0;
-    for (int cls = 0; cls < 5 && rc == 0; ++cls) {
-        std::vector<uint32_t> todo = by_class[cls];
-        const uint32_t cpl = class_cpl[cls];
-        // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas
+    if (!ctx->poa_go) {
+        RT_HIP(hipEventCreateWithFlags(&ctx->poa_go, hipEventDisableTiming));
+        for (int i = 0; i < 5; ++i) {
+            RT_HIP(hipStreamCreateWithFlags(&ctx->poa_st[i], hipStreamNonBlocking));
+            RT_HIP(hipEventCreateWithFlags(&ctx->poa_ev[i], hipEventDisableTiming));
+        }
+    }
+    dbuf<uint32_t> d_heads;
+    RT_TRY(d_heads.reserve(8));
+    struct cls_plan {
+        std::vector<uint32_t> todo;
         uint32_t node_cap = 10240;
-        uint64_t cell_cap = 24ull << 20;           // elements per matrix (x3 matrices x2 bytes = 144 MiB)
-        for (int round = 0; round < 6 && !todo.empty() && rc == 0; ++round) {
-            std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
+        uint64_t cell_cap = 24ull << 20;           // elements per matrix
+        poa_args A;
+        uint64_t per_slot = 0;
+        size_t shm = 0;
+        uint32_t n_slots = 0;
+        int bpc = 1;
+    } C[5];
+    for (int c = 0; c < 5; ++c) C[c].todo = by_class[c];
+    // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas.
+    // The column classes of one round run concurrently on their own streams.
+    for (int round = 0; round < 6 && rc == 0; ++round) {
+        bool any = false;
+        uint64_t want_bytes = 0;
+        for (int c = 0; c < 5; ++c) {
+            cls_plan &P = C[c];
+            P.n_slots = 0;
+            if (P.todo.empty()) continue;
+            any = true;
+            const uint32_t cpl = class_cpl[c];
+            std::sort(P.todo.begin(), P.todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
             uint64_t tb = 0; uint32_t tl = 0;
-            for (uint32_t p : todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
-            uint32_t ncap = (uint32_t)std::min<uint64_t>(node_cap, tb + 1);
+            for (uint32_t p : P.todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
+            uint32_t ncap = (uint32_t)std::min<uint64_t>(P.node_cap, tb + 1);
             ncap = (ncap + 31u) & ~31u;
             const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
             const uint32_t acap = tl + ncap + 16;
             const uint32_t scap = ncap + POA_STACK;
             const uint32_t qcap = ((tl + cpl - 1) / cpl * cpl + 15u) & ~15u;
-            const uint64_t ccap = std::min<uint64_t>(cell_cap, (uint64_t)(ncap + 1) * qcap);
-            poa_args A;
+            const uint64_t ccap = std::min<uint64_t>(P.cell_cap, (uint64_t)(ncap + 1) * qcap);
+            poa_args &A = P.A;
             uint64_t o = 0;
             auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
             A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
@@ -927,55 +978,88 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
             A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
             A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
             A.o_aln = take((uint64_t)acap * 8); A.o_spill = take((uint64_t)scap * 4);
-            const uint64_t per_slot = o;
-            const uint32_t lds_topo = 0u;      // LDS mirror of the node topology: measured no gain, costs occupancy
-            const size_t shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (lds_topo ? (size_t)ncap * 4 : 0);
-            const int bpc = cls == 0 ? max_blocks_per_cu<4, 2>(shm) : cls == 1 ? max_blocks_per_cu<6, 2>(shm)
-                          : cls == 2 ? max_blocks_per_cu<8, 2>(shm) : cls == 3 ? max_blocks_per_cu<16, 1>(shm)
-                                                                    : max_blocks_per_cu<24, 1>(shm);
-            const uint64_t budget = (uint64_t)(free_b * 0.85);
-            const uint32_t max_slots = (uint32_t)std::max<uint64_t>(1, budget / per_slot);
-            const uint32_t n_slots = std::min<uint32_t>((uint32_t)todo.size(), std::min<uint32_t>(max_slots, n_cu * (uint32_t)bpc));
-            phase_timer T_round("    poa round (arena+kernel)");
-            if (getenv("RATTLE_TIMING"))
-                fprintf(stderr, "[rattle]     poa class %u round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n", cpl, round, todo.size(),
-                        n_slots, per_slot / 1e6, bpc);
-            if (ctx->poa_arena_bytes < (size_t)per_slot * n_slots) {
-                if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
-                ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
-                if (hipMalloc((void **)&ctx->poa_arena, (size_t)per_slot * n_slots) != hipSuccess) {
-                    set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break;
-                }
-                ctx->poa_arena_bytes = (size_t)per_slot * n_slots;
+            P.per_slot = o;
+            A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
+            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4;
+            P.bpc = c == 0 ? max_blocks_per_cu<4, 2>(P.shm) : c == 1 ? max_blocks_per_cu<6, 2>(P.shm)
+                  : c == 2 ? max_blocks_per_cu<8, 2>(P.shm) : c == 3 ? max_blocks_per_cu<16, 1>(P.shm) : max_blocks_per_cu<24, 1>(P.shm);
+            P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
+            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
+            want_bytes += P.per_slot * P.n_slots;
+        }
+        if (!any) break;
+        const uint64_t budget = (uint64_t)(free_b * 0.85);
+        if (want_bytes > budget) {             // scale every class down proportionally (at least one slot each)
+            const double f = (double)budget / (double)want_bytes;
+            want_bytes = 0;
+            for (int c = 0; c < 5; ++c) if (C[c].n_slots) {
+                C[c].n_slots = std::max<uint32_t>(1, (uint32_t)(C[c].n_slots * f));
+                want_bytes += C[c].per_slot * C[c].n_slots;
             }
-            hipError_t e = hipMemcpyAsync(d_queue.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemsetAsync(d_head.p, 0, 4, st);
-            if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
-            A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p; A.n_queue = (uint32_t)todo.size();
-            A.queue_head = d_head.p; A.arena = ctx->poa_arena; A.slot_stride = per_slot;
-            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap; A.lds_topo = lds_topo;
+        }
+        phase_timer T_round("    poa round (arena+kernels)");
+        if (ctx->poa_arena_bytes < want_bytes) {
+            if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
+            ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
+            if (hipMalloc((void **)&ctx->poa_arena, want_bytes) != hipSuccess) { set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break; }
+            ctx->poa_arena_bytes = want_bytes;
+        }
+        hipError_t e = hipMemsetAsync(d_heads.p, 0, 32, st);
+        uint64_t aoff = 0;
+        uint32_t qoff = 0;
+        for (int c = 0; c < 5 && e == hipSuccess; ++c) {
+            cls_plan &P = C[c];
+            if (!P.n_slots) continue;
+            e = hipMemcpyAsync(d_queue.p + qoff, P.todo.data(), P.todo.size() * 4, hipMemcpyHostToDevice, st);
+            poa_args &A = P.A;
+            A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p + qoff; A.n_queue = (uint32_t)P.todo.size();
+            A.queue_head = d_heads.p + c; A.arena = ctx->poa_arena + aoff; A.slot_stride = P.per_slot;
             A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p;
-            {
-                ktimer T(ctx, K_POA, 0);
-                e = cls == 0 ? launch_poa<4, 2>(A, n_slots, shm, st) : cls == 1 ? launch_poa<6, 2>(A, n_slots, shm, st)
-                  : cls == 2 ? launch_poa<8, 2>(A, n_slots, shm, st) : cls == 3 ? launch_poa<16, 1>(A, n_slots, shm, st)
-                                                                     : launch_poa<24, 1>(A, n_slots, shm, st);
+            aoff += P.per_slot * P.n_slots;
+            qoff += (uint32_t)P.todo.size();
+            if (getenv("RATTLE_TIMING"))
+                fprintf(stderr, "[rattle]     poa class %u round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n", class_cpl[c], round,
+                        P.todo.size(), P.n_slots, P.per_slot / 1e6, P.bpc);
+        }
+        if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
+        {
+            ktimer T(ctx, K_POA, 0);
+            e = hipEventRecord(ctx->poa_go, st);
+            for (int c = 0; c < 5 && e == hipSuccess; ++c) {
+                cls_plan &P = C[c];
+                if (!P.n_slots) continue;
+                hipStream_t cs = ctx->poa_st[c];
+                e = hipStreamWaitEvent(cs, ctx->poa_go, 0);
+                if (e != hipSuccess) break;
+                e = c == 0 ? launch_poa<4, 2>(P.A, P.n_slots, P.shm, cs) : c == 1 ? launch_poa<6, 2>(P.A, P.n_slots, P.shm, cs)
+                  : c == 2 ? launch_poa<8, 2>(P.A, P.n_slots, P.shm, cs) : c == 3 ? launch_poa<16, 1>(P.A, P.n_slots, P.shm, cs)
+                                                                          : launch_poa<24, 1>(P.A, P.n_slots, P.shm, cs);
+                if (e == hipSuccess) e = hipEventRecord(ctx->poa_ev[c], cs);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[c], 0);
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
+        for (int c = 0; c < 5 && rc == 0; ++c) {
+            cls_plan &P = C[c];
+            if (!P.n_slots) continue;
             std::vector<uint32_t> again;
-            for (uint32_t p : todo) {
+            for (uint32_t p : P.todo) {
                 const uint32_t s = h_status[p];
                 if (s == POA_OK) continue;
                 if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) again.push_back(p);
                 else { set_error("poa_kernel: pack " + std::to_string(p) + " failed with status " + std::to_string(s)); rc = RATTLE_ERR_HIP; break; }
             }
-            todo.swap(again);
-            node_cap = std::min<uint32_t>(node_cap * 4, 1u << 20);
-            cell_cap *= 8;
+            P.todo.swap(again);
+            if (!P.todo.empty()) { P.node_cap = std::min<uint32_t>(P.node_cap * 4, 1u << 20); P.cell_cap *= 8; }
         }
-        if (rc == 0 && !todo.empty()) { set_error("poa: " + std::to_string(todo.size()) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
+    }
+    d_heads.release();
+    if (rc == 0) {
+        size_t left = 0;
+        for (int c = 0; c < 5; ++c) left += C[c].todo.size();
+        if (left) { set_error("poa: " + std::to_string(left) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
     std::vector<uint32_t> h_col;
     unsigned long long h_cnt[8] = {0};

@@ -12,5 +12,5 @@ ctx=Context(0)
 t=time.time(); rows,width,c=ctx.poa_msa(packs); dt=time.time()-t
 print('time',dt,'cells',c[0],'GCUPS',c[0]/dt/1e9,'rows',c[3])
 tick=1e-8
-print('per-row us: dfs+dp %.2f  dp %.2f  | per-aln ms: tb %.2f add %.2f'%(c[4]*tick/c[3]*1e6, c[5]*tick/c[3]*1e6, c[6]*tick/c[1]*1e3, c[7]*tick/c[1]*1e3))
-print('totals s (sum over waves): dfs+dp %.2f dp %.2f tb %.2f add %.2f'%(c[4]*tick,c[5]*tick,c[6]*tick,c[7]*tick))
+print('ties %d needing sort %d of %d alignments | per-row us: dp %.2f  | per-aln ms: tb %.2f add %.2f'%(int(c[4])>>32, int(c[4])&0xffffffff, c[1], c[5]*tick/c[3]*1e6, c[6]*tick/c[1]*1e3, c[7]*tick/c[1]*1e3))
+print('totals s: dp %.2f tb %.2f add %.2f'%(c[5]*tick,c[6]*tick,c[7]*tick))
