@@ -59,7 +59,7 @@ struct poa_args {
     uint32_t *queue_head;
     uint8_t *arena;                // n_slots * slot_stride bytes
     uint64_t slot_stride;
-    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_order2, o_srank, o_rowmax, o_nn, o_plan, o_planb, o_H, o_F, o_E, o_aln, o_spill;
+    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_order2, o_srank, o_rowmax, o_lh, o_nn, o_plan, o_planb, o_H, o_F, o_E, o_aln, o_ainfo, o_spill;
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
@@ -85,9 +85,11 @@ struct poa_ws {                    // per-block workspace: global pointers + LDS
     uint32_t *order, *order2;              // DP row - 1 -> node (double buffer for the incremental merge)
     int32_t *srank;                        // spoa rank per node (only computed when best rows tie)
     int32_t *rowmax;                       // [row][wave] row maximum of H
+    int32_t *lh;                           // [row][wave] H of the column left of the wave (written and read by lane 0 of that wave)
     uint32_t *nn;                          // new nodes of the last add_alignment: (node, anchor) pairs in path order
     int16_t *H, *F, *E;
     int32_t *aln;
+    uint4 *ainfo;                          // per forward pair: kind, target node, group row range (add_alignment)
     uint32_t *spill;
     uint32_t *done, *nocheck, *stack;      // LDS
     uint32_t *topo;                        // LDS: in0 | min(n_in,63) << 20 | n_al << 26 per node, or nullptr
@@ -129,6 +131,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+
+// Row barrier of the DP: only LDS traffic has to be ordered across the four waves, so global
+// loads/stores stay in flight (a __syncthreads() would drain vmcnt every row).
+#ifdef POA_SYNCTHREADS
+__device__ __forceinline__ void row_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void row_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // ---- DFS stack with spill to global --------------------------------------------------------
 __device__ __forceinline__ void st_push(poa_ws &S, const poa_args &A, uint32_t v) {
@@ -343,7 +353,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                     if (act) {
                         load_block<CPL>(Hp + c0, hp);
                         load_block<CPL>(Fp + c0, fp);
-                        if (lane == 0 && wave > 0) hl = (int32_t)Hp[c0 - 1];
+                        if (lane == 0 && wave > 0) hl = S.lh[prow * 4 + wave];
                     } else {
 #pragma unroll
                         for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
@@ -369,7 +379,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
             const int32_t texcl = wave_shr1(wincl, POA_NEG);
             if (lane == 63) { X.T[par][wave] = wincl; X.Tp[par][wave] = max(texcl, ex[CPL - 1]); X.Hn[par][wave] = hn[CPL - 1]; }
-            __syncthreads();
+            row_barrier();
             int32_t base = POA_G - POA_E;        // u_0
             int32_t hl_new = 0;
             if (wave > 0) {
@@ -381,6 +391,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                 }
                 const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);            // 1-based index of the column left of the wave
                 hl_new = max(X.Hn[par][wave - 1], max(bp, X.Tp[par][wave - 1]) + c0w * POA_E);
+                if (lane == 0) S.lh[row * 4 + wave] = hl_new;
             }
             base = max(base, texcl);
             int32_t hv[CPL], ev[CPL];
@@ -430,8 +441,9 @@ __device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
     return S.n_nodes++;
 }
 
-// Graph::add_edge: nothing if begin->end exists, else append to end's in-edge list.
-__device__ void g_add_edge(poa_ws &S, const poa_args &A, uint32_t b, uint32_t en) {
+// Graph::add_edge: nothing if begin->end exists, else append to end's in-edge list.  Called by
+// many threads at once for DISTINCT end nodes; edge slots come from an LDS counter.
+__device__ void g_add_edge(poa_ws &S, const poa_args &A, uint32_t b, uint32_t en, uint32_t *edge_counter, uint32_t *err) {
     uint4 nd = S.nrec[en];
     const uint32_t n_in = rd_nin(nd.x);
     if (n_in > 0) {
@@ -442,17 +454,16 @@ __device__ void g_add_edge(poa_ws &S, const poa_args &A, uint32_t b, uint32_t en
     if (n_in == 0) {
         nd.y = b;
     } else {
-        if (S.n_edges >= A.edge_cap) { S.err = POA_ERR_EDGES; return; }
-        const uint32_t id = S.n_edges++;
+        const uint32_t id = atomicAdd(edge_counter, 1u);
+        if (id >= A.edge_cap) { *err = POA_ERR_EDGES; return; }
         S.edges[id] = make_uint2(b, POA_NONE);
         if (nd.z == POA_NONE) nd.z = id;
         else S.edges[nd.w].y = id;
         nd.w = id;
     }
-    if (n_in >= 0xFFFF) { S.err = POA_ERR_GRAPH; return; }
+    if (n_in >= 0xFFFF) { *err = POA_ERR_GRAPH; return; }
     nd.x += 1u << 16;
     S.nrec[en] = nd;
-    if (S.topo) S.topo[en] = topo_pack(nd);
 }
 
 // Graph::add_sequence(b, e): fresh chain; returns first node or -1.  Records the path.
@@ -484,9 +495,9 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
         uint8_t *base = A.arena + (uint64_t)blockIdx.x * A.slot_stride;
         S.nrec = (uint4 *)(base + A.o_nrec); S.nal = (uint4 *)(base + A.o_nal); S.edges = (uint2 *)(base + A.o_edges);
         S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.order2 = (uint32_t *)(base + A.o_order2);
-        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb);
+        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb);
         S.H = (int16_t *)(base + A.o_H); S.F = (int16_t *)(base + A.o_F); S.E = (int16_t *)(base + A.o_E);
-        S.aln = (int32_t *)(base + A.o_aln); S.spill = (uint32_t *)(base + A.o_spill);
+        S.aln = (int32_t *)(base + A.o_aln); S.ainfo = (uint4 *)(base + A.o_ainfo); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = (A.node_cap + 31) / 32;
         S.sq = (uint8_t *)lds;                                   // seq_cap bytes (multiple of 16)
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
@@ -689,121 +700,138 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                 }
                 t_tb += PT_NOW() - t2;
             }
-            // ---- 5. add_alignment (thread 0) ----
-            // Besides spoa's graph update, every NEW node is recorded with the position (in the
-            // current row order) it must be inserted before: an unaligned run goes right before
-            // the aligned group of the next graph node on the path, a mismatch node right after
-            // the group it joins, trailing nodes at the end.  Anchors are non-decreasing along
-            // the path, so merge_order below is a stable merge.
+            // ---- 5. add_alignment ----
+            // (a) all threads resolve the pairs against the graph as it is (reuse / sibling / new node,
+            //     row range of the aligned group); (b) thread 0 creates the nodes in spoa's id order,
+            //     updates aligned groups and records, for every NEW node, the row it must be inserted
+            //     before (an unaligned run goes right before the group of the next graph node on the
+            //     path, a mismatch node right after the group it joins, trailing nodes at the end;
+            //     anchors are non-decreasing along the path); (c) all threads add the path edges
+            //     (one per sequence position, distinct target nodes).
             unsigned long long t3 = PT_NOW();
             const uint32_t n_old = S.n_nodes;
+            enum { K_SKIP = 0, K_INS = 1, K_SAME = 2, K_SIB = 3, K_NEW = 4 };
+            for (uint32_t f = tid; f < n_aln; f += 256) {
+                const int32_t an = S.aln[2 * (n_aln - 1 - f)], pos = S.aln[2 * (n_aln - 1 - f) + 1];
+                uint4 inf = make_uint4(K_SKIP, 0, 0, 0);
+                if (pos != -1) {
+                    if (an == -1) {
+                        inf.x = K_INS;
+                    } else {
+                        const uint8_t letter = s[pos];
+                        const uint4 nd = S.nrec[an];
+                        const uint32_t n_al = rd_nal(nd.x);
+                        uint4 al = make_uint4(0, 0, 0, 0);
+                        if (n_al) al = S.nal[an];
+                        uint32_t gs = (uint32_t)S.rank[an], ge = gs;
+                        int32_t hit = -1;
+                        for (uint32_t k = 0; k < n_al; ++k) {
+                            const uint32_t a = u4_get(al, k);
+                            const uint32_t r = (uint32_t)S.rank[a];
+                            gs = min(gs, r); ge = max(ge, r);
+                            if (hit == -1 && rd_letter(S.nrec[a].x) == letter) hit = (int32_t)a;
+                        }
+                        if (rd_letter(nd.x) == letter) { inf.x = K_SAME; inf.y = (uint32_t)an; }
+                        else if (hit != -1) { inf.x = K_SIB; inf.y = (uint32_t)hit; }
+                        else { inf.x = K_NEW; inf.y = (uint32_t)an; }
+                        inf.z = gs; inf.w = ge + 1;
+                    }
+                }
+                S.ainfo[f] = inf;
+            }
+            __syncthreads();
             if (tid == 0) {
                 uint32_t T = 0;
                 auto nn_push = [&](uint32_t node, uint32_t anchor) { S.nn[2 * T] = node; S.nn[2 * T + 1] = anchor; ++T; };
+                uint32_t e_lo = 1, e_hi = 0;                           // sequence positions p that need the edge path[p-1] -> path[p]
                 if (n_aln == 0) {
                     g_add_chain(S, A, s, 0, L, path);
                     if (!S.err) for (uint32_t i = 0; i < L; ++i) nn_push(n_old + i, n_old);
                 } else {
-                    // pairs are stored reversed: forward pair t = aln[n_aln-1-t]
+                    // pairs are stored reversed: forward pair f = aln[n_aln-1-f]
                     int32_t first_valid = -1, last_valid = -1;
-                    for (uint32_t t = 0; t < n_aln; ++t) {
-                        const int32_t pos = S.aln[2 * (n_aln - 1 - t) + 1];
-                        if (pos != -1) { if (first_valid == -1) first_valid = pos; last_valid = pos; }
-                    }
+                    for (uint32_t f = 0; f < n_aln && first_valid == -1; ++f) first_valid = S.aln[2 * (n_aln - 1 - f) + 1];
+                    for (uint32_t f = n_aln; f-- > 0 && last_valid == -1;) last_valid = S.aln[2 * (n_aln - 1 - f) + 1];
                     const uint32_t before = S.n_nodes;
                     g_add_chain(S, A, s, 0, (uint32_t)first_valid, path);
-                    int32_t head = before == S.n_nodes ? -1 : (int32_t)S.n_nodes - 1;
                     uint32_t pa0 = before, pan = S.n_nodes - before;        // pending: prefix chain
                     const uint32_t suf0 = S.n_nodes;
-                    const int32_t tail = S.err ? -1 : g_add_chain(S, A, s, (uint32_t)last_valid + 1, L, path);
+                    if (!S.err) g_add_chain(S, A, s, (uint32_t)last_valid + 1, L, path);
                     const uint32_t sufn = S.n_nodes - suf0;
-                    uint32_t pb0 = 0, pbn = 0;                                  // pending: current insertion run
-                    for (uint32_t t = 0; t < n_aln && !S.err; ++t) {
-                        const int32_t an = S.aln[2 * (n_aln - 1 - t)], pos = S.aln[2 * (n_aln - 1 - t) + 1];
-                        if (pos == -1) continue;
+                    uint32_t pb0 = 0, pbn = 0;                              // pending: current insertion run
+                    for (uint32_t f = 0; f < n_aln && !S.err; ++f) {
+                        const uint4 inf = S.ainfo[f];
+                        if (inf.x == K_SKIP) continue;
+                        const int32_t pos = S.aln[2 * (n_aln - 1 - f) + 1];
                         const uint8_t letter = s[pos];
                         uint32_t cur;
-                        if (an == -1) {
+                        if (inf.x == K_INS) {
                             cur = g_add_node(S, A, letter);
                             if (S.err) break;
                             if (pbn == 0) pb0 = cur;
                             ++pbn;
                         } else {
-                            uint4 nd = S.nrec[an];
-                            const uint32_t n_al = rd_nal(nd.x);
-                            uint4 al = make_uint4(0, 0, 0, 0);
-                            if (n_al) al = S.nal[an];
-                            const bool same = rd_letter(nd.x) == letter;
-                            // old row range of an's aligned group (needed for pending nodes / a new sibling)
-                            uint32_t gs = 0, ge = 0;
-                            if (pan + pbn > 0 || !same) {
-                                gs = (uint32_t)S.rank[an]; ge = gs;
-                                for (uint32_t k = 0; k < n_al; ++k) {
-                                    const uint32_t r = (uint32_t)S.rank[u4_get(al, k)];
-                                    gs = min(gs, r); ge = max(ge, r);
-                                }
-                                ++ge;
-                                for (uint32_t i = 0; i < pan; ++i) nn_push(pa0 + i, gs);
-                                for (uint32_t i = 0; i < pbn; ++i) nn_push(pb0 + i, gs);
+                            if (pan + pbn > 0) {
+                                for (uint32_t i = 0; i < pan; ++i) nn_push(pa0 + i, inf.z);
+                                for (uint32_t i = 0; i < pbn; ++i) nn_push(pb0 + i, inf.z);
                                 pan = 0; pbn = 0;
                             }
-                            if (same) {
-                                cur = (uint32_t)an;
+                            if (inf.x != K_NEW) {
+                                cur = inf.y;
                             } else {
-                                int32_t hit = -1;
+                                const uint32_t an = inf.y;
+                                uint4 nd = S.nrec[an];
+                                const uint32_t n_al = rd_nal(nd.x);
+                                uint4 al = make_uint4(0, 0, 0, 0);
+                                if (n_al) al = S.nal[an];
+                                if (n_al >= 4) { S.err = POA_ERR_GRAPH; break; }
+                                cur = g_add_node(S, A, letter);
+                                if (S.err) break;
+                                nn_push(cur, inf.w);
+                                uint4 cal = make_uint4(0, 0, 0, 0);
                                 for (uint32_t k = 0; k < n_al; ++k) {
                                     const uint32_t a = u4_get(al, k);
-                                    if (rd_letter(S.nrec[a].x) == letter) { hit = (int32_t)a; break; }
+                                    u4_set(cal, k, a);
+                                    uint4 ar = S.nrec[a];
+                                    const uint32_t c = rd_nal(ar.x);
+                                    if (c >= 4) { S.err = POA_ERR_GRAPH; break; }
+                                    uint4 aal = c ? S.nal[a] : make_uint4(0, 0, 0, 0);
+                                    u4_set(aal, c, cur);
+                                    S.nal[a] = aal;
+                                    ar.x += 1u << 8;
+                                    S.nrec[a] = ar;
                                 }
-                                if (hit != -1) {
-                                    cur = (uint32_t)hit;
-                                } else {
-                                    if (n_al >= 4) { S.err = POA_ERR_GRAPH; break; }
-                                    cur = g_add_node(S, A, letter);
-                                    if (S.err) break;
-                                    nn_push(cur, ge);
-                                    uint4 cal = make_uint4(0, 0, 0, 0);
-                                    for (uint32_t k = 0; k < n_al; ++k) {
-                                        const uint32_t a = u4_get(al, k);
-                                        u4_set(cal, k, a);
-                                        uint4 ar = S.nrec[a];
-                                        const uint32_t c = rd_nal(ar.x);
-                                        if (c >= 4) { S.err = POA_ERR_GRAPH; break; }
-                                        uint4 aal = c ? S.nal[a] : make_uint4(0, 0, 0, 0);
-                                        u4_set(aal, c, cur);
-                                        S.nal[a] = aal;
-                                        ar.x += 1u << 8;
-                                        S.nrec[a] = ar;
-                                    }
-                                    u4_set(cal, n_al, (uint32_t)an);
-                                    S.nal[cur] = cal;
-                                    uint4 cr = S.nrec[cur];
-                                    cr.x += (n_al + 1) << 8;
-                                    S.nrec[cur] = cr;
-                                    u4_set(al, n_al, cur);
-                                    S.nal[an] = al;
-                                    nd.x += 1u << 8;
-                                    S.nrec[an] = nd;
-                                }
+                                u4_set(cal, n_al, an);
+                                S.nal[cur] = cal;
+                                S.nrec[cur] = make_uint4((uint32_t)letter | ((n_al + 1) << 8), 0, POA_NONE, POA_NONE);
+                                u4_set(al, n_al, cur);
+                                S.nal[an] = al;
+                                nd.x += 1u << 8;
+                                S.nrec[an] = nd;
                             }
                         }
                         if (S.err) break;
                         path[pos] = cur;
-                        if (head != -1) g_add_edge(S, A, (uint32_t)head, cur);
-                        head = (int32_t)cur;
                     }
-                    if (!S.err && tail != -1) g_add_edge(S, A, (uint32_t)head, (uint32_t)tail);
                     if (!S.err) {
                         for (uint32_t i = 0; i < pan; ++i) nn_push(pa0 + i, n_old);
                         for (uint32_t i = 0; i < pbn; ++i) nn_push(pb0 + i, n_old);
                         for (uint32_t i = 0; i < sufn; ++i) nn_push(suf0 + i, n_old);
+                        e_lo = (uint32_t)std::max(first_valid, 1);
+                        e_hi = std::min((uint32_t)last_valid + 1, L - 1);
                     }
                 }
                 if (!S.err && T != S.n_nodes - n_old) S.err = POA_ERR_GRAPH;
-                s_bc[2] = S.n_nodes; s_bc[3] = S.n_edges; s_bc[4] = S.err;
+                s_bc[2] = S.n_nodes; s_bc[3] = S.n_edges; s_bc[4] = S.err; s_bc[5] = e_lo; s_bc[6] = e_hi;
             }
             __syncthreads();
-            S.n_nodes = s_bc[2]; S.n_edges = s_bc[3]; S.err = s_bc[4];
+            S.n_nodes = s_bc[2]; S.err = s_bc[4];
+            if (!S.err) {
+                const uint32_t e_lo = s_bc[5], e_hi = s_bc[6];
+                for (uint32_t p = e_lo + tid; p <= e_hi && e_lo <= e_hi; p += 256) g_add_edge(S, A, path[p - 1], path[p], &s_bc[3], &s_bc[4]);
+            }
+            __syncthreads();
+            S.n_edges = s_bc[3]; S.err = s_bc[4];
             __syncthreads();
             // ---- 6. merge_order: insert the new nodes into the row order (all threads) ----
             if (!S.err) {
@@ -974,10 +1002,10 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
             auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
             A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
             A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
-            A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
+            A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
             A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
             A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
-            A.o_aln = take((uint64_t)acap * 8); A.o_spill = take((uint64_t)scap * 4);
+            A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
             A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
             P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4;
