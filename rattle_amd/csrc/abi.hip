@@ -65,6 +65,7 @@ void rattle_hip_ctx_destroy(rattle_ctx *c) {
     if (c->poa_arena) (void)hipFree(c->poa_arena);
     for (int i = 0; i < 5; ++i) { if (c->poa_st[i]) (void)hipStreamDestroy(c->poa_st[i]); if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]); }
     if (c->poa_go) (void)hipEventDestroy(c->poa_go);
+    c->h_poa_col.release();
     c->h_surv.release(); c->h_res.release(); c->h_var.release(); c->h_counter.release();
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);

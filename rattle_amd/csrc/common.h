@@ -8,9 +8,11 @@
 
 #include "../../include/rattle_hip.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 namespace rattle {
 
@@ -30,6 +32,21 @@ struct phase_timer {
 };
 
 void set_error(const std::string &msg);
+
+// Host-side data-parallel loop (post-MSA logic, packing, row expansion): dynamic chunks of one item.
+template <typename F>
+void parallel_for(size_t n, int n_threads, F f) {
+    if (n == 0) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = n_threads > 0 ? (size_t)n_threads : (hw ? hw : 1);
+    T = std::min(T, n);
+    if (T <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t)
+        th.emplace_back([&]() { for (size_t i = next++; i < n; i = next++) f(i); });
+    for (auto &x : th) x.join();
+}
 
 #define RT_HIP(call)                                                                                   \
     do {                                                                                               \
@@ -147,6 +164,7 @@ struct rattle_ctx {
     hipStream_t poa_st[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // one per column class: classes run concurrently
     hipEvent_t poa_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t poa_go = nullptr;
+    rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns
 };
 
 namespace rattle {

@@ -6,11 +6,9 @@
 // post-MSA logic (fix_msa_ends :32-92, column vote :94-193, per-read correction :196-309) runs
 // between launches on host threads, one pack per task, in the reference's operation order.
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
 
 #include "common.h"
 
@@ -193,42 +191,35 @@ int poa_stage(rattle_ctx *ctx, const std::vector<const std::vector<hread> *> &gr
     msas.assign(groups.size(), {});
     std::vector<uint64_t> off(1, 0);
     std::vector<uint32_t> first(1, 0);
-    std::string cat;
     for (auto g : groups) {
-        for (auto &r : *g) { cat += r.seq; off.push_back(cat.size()); }
+        for (auto &r : *g) off.push_back(off.back() + r.seq.size());
         first.push_back((uint32_t)off.size() - 1);
     }
+    std::string cat(off.back(), 'A');
+    parallel_for(groups.size(), 0, [&](size_t g) {
+        uint32_t q = first[g];
+        for (auto &r : *groups[g]) { memcpy(&cat[off[q]], r.seq.data(), r.seq.size()); ++q; }
+    });
     rattle_msa_set *ms = nullptr;
-    phase_timer T0("  poa_stage: msa_run");
-    int rc = poa_msa_run(ctx, (const uint8_t *)cat.data(), off.data(), (uint32_t)off.size() - 1, first.data(),
+    int rc;
+    {
+        phase_timer T0("  poa_stage: msa_run");
+        rc = poa_msa_run(ctx, (const uint8_t *)cat.data(), off.data(), (uint32_t)off.size() - 1, first.data(),
                          (uint32_t)groups.size(), &ms);
-    phase_timer T1("  poa_stage: copy rows");
+    }
     if (rc == 0) {
-        uint32_t q = 0;
-        for (size_t g = 0; g < groups.size(); ++g) {
+        phase_timer T1("  poa_stage: copy rows");
+        parallel_for(groups.size(), 0, [&](size_t g) {
+            uint32_t q = first[g];
             msas[g].resize(groups[g]->size());
             for (size_t i = 0; i < groups[g]->size(); ++i, ++q)
                 msas[g][i].assign(ms->rows + ms->row_offset[q], ms->rows + ms->row_offset[q + 1]);
-        }
+        });
         counters[0] += ms->counters[0];
         counters[1] += ms->counters[1];
     }
     rattle_hip_msa_set_free(ms);
     return rc;
-}
-
-template <typename F>
-void parallel_for(size_t n, int n_threads, F f) {
-    if (n == 0) return;
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t T = n_threads > 0 ? (size_t)n_threads : (hw ? hw : 1);
-    T = std::min(T, n);
-    if (T <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
-    std::atomic<size_t> next(0);
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < T; ++t)
-        th.emplace_back([&]() { for (size_t i = next++; i < n; i = next++) f(i); });
-    for (auto &x : th) x.join();
 }
 
 void fill_set(rattle_read_set &S, const std::vector<hread> &v, const std::vector<int32_t> &cid, const std::vector<int32_t> &nr) {
@@ -237,21 +228,22 @@ void fill_set(rattle_read_set &S, const std::vector<hread> &v, const std::vector
     S.read_id = (int32_t *)malloc(n * 4); S.cluster_id = (int32_t *)malloc(n * 4); S.n_reads = (int32_t *)malloc(n * 4);
     S.off = (uint64_t *)malloc((v.size() + 1) * 8);
     uint64_t tot = 0;
-    for (auto &r : v) tot += r.seq.size();
+    for (size_t i = 0; i < v.size(); ++i) { S.off[i] = tot; tot += v[i].seq.size(); }
+    S.off[v.size()] = tot;
     S.seq = (char *)malloc(tot + 1); S.qual = (char *)malloc(tot + 1);
-    uint64_t p = 0;
-    for (size_t i = 0; i < v.size(); ++i) {
-        S.read_id[i] = v[i].rid; S.cluster_id[i] = cid[i]; S.n_reads[i] = nr.empty() ? 0 : nr[i];
-        S.off[i] = p;
-        memcpy(S.seq + p, v[i].seq.data(), v[i].seq.size());
-        // qualities always have the sequence's length on this path; guard anyway
-        size_t ql = std::min(v[i].qual.size(), v[i].seq.size());
-        memcpy(S.qual + p, v[i].qual.data(), ql);
-        if (ql < v[i].seq.size()) memset(S.qual + p + ql, '!', v[i].seq.size() - ql);
-        p += v[i].seq.size();
-    }
-    S.off[v.size()] = p;
-    S.seq[p] = 0; S.qual[p] = 0;
+    const size_t chunk = 1024;
+    parallel_for((v.size() + chunk - 1) / chunk, 0, [&](size_t c) {
+        for (size_t i = c * chunk; i < std::min(v.size(), (c + 1) * chunk); ++i) {
+            S.read_id[i] = v[i].rid; S.cluster_id[i] = cid[i]; S.n_reads[i] = nr.empty() ? 0 : nr[i];
+            const uint64_t p = S.off[i];
+            memcpy(S.seq + p, v[i].seq.data(), v[i].seq.size());
+            // qualities always have the sequence's length on this path; guard anyway
+            const size_t ql = std::min(v[i].qual.size(), v[i].seq.size());
+            memcpy(S.qual + p, v[i].qual.data(), ql);
+            if (ql < v[i].seq.size()) memset(S.qual + p + ql, '!', v[i].seq.size() - ql);
+        }
+    });
+    S.seq[tot] = 0; S.qual[tot] = 0;
 }
 
 }  // namespace
@@ -272,36 +264,42 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     std::vector<hread> uncorrected;
     std::vector<int32_t> unc_cid;
     std::vector<std::vector<size_t>> cluster_packs(n_clusters);
-    // ---- correct.cpp:328-370 pack building
-    for (uint32_t c = 0; c < n_clusters; ++c) {
-        const uint32_t a = coff[c], b = coff[c + 1];
-        const int n = (int)(b - a);
-        if (n == 0) continue;
-        const int n_files = (n - 1) / split + 1;
-        for (int nf = 0; nf < n_files; ++nf) {
-            pack_t pk;
-            pk.cid = (int32_t)c;
-            for (int j = nf; j < n; j += n_files) {
-                const int32_t rid = mid[a + j];
-                if (rid < 0 || (uint32_t)rid >= n_reads) { set_error("cluster member id out of range"); return RATTLE_ERR_ARG; }
-                hread r;
-                r.rid = rid;
-                r.seq.assign((const char *)seq + off[rid], (const char *)seq + off[rid + 1]);
-                r.qual.assign((const char *)qual + off[rid], (const char *)qual + off[rid + 1]);
-                if (mrev[a + j]) {                                   // :343-346
-                    std::string rc(r.seq.size(), 'A');
-                    for (size_t t = 0; t < r.seq.size(); ++t) rc[t] = comp_base(r.seq[r.seq.size() - 1 - t]);
-                    r.seq.swap(rc);
-                    std::reverse(r.qual.begin(), r.qual.end());
+    // ---- correct.cpp:328-370 pack building (clusters are independent: built in parallel, kept in order)
+    {
+        phase_timer T("correct: build packs");
+        struct built { std::vector<pack_t> packs; std::vector<hread> small; int err = 0; };
+        std::vector<built> B(n_clusters);
+        parallel_for(n_clusters, P->n_threads, [&](size_t c) {
+            const uint32_t a = coff[c], b = coff[c + 1];
+            const int n = (int)(b - a);
+            if (n == 0) return;
+            const int n_files = (n - 1) / split + 1;
+            for (int nf = 0; nf < n_files; ++nf) {
+                pack_t pk;
+                pk.cid = (int32_t)c;
+                for (int j = nf; j < n; j += n_files) {
+                    const int32_t rid = mid[a + j];
+                    if (rid < 0 || (uint32_t)rid >= n_reads) { B[c].err = 1; return; }
+                    hread r;
+                    r.rid = rid;
+                    r.seq.assign((const char *)seq + off[rid], (const char *)seq + off[rid + 1]);
+                    r.qual.assign((const char *)qual + off[rid], (const char *)qual + off[rid + 1]);
+                    if (mrev[a + j]) {                                   // :343-346
+                        std::string rc(r.seq.size(), 'A');
+                        for (size_t t = 0; t < r.seq.size(); ++t) rc[t] = comp_base(r.seq[r.seq.size() - 1 - t]);
+                        r.seq.swap(rc);
+                        std::reverse(r.qual.begin(), r.qual.end());
+                    }
+                    pk.reads.push_back(std::move(r));
                 }
-                pk.reads.push_back(std::move(r));
+                if ((int)pk.reads.size() > P->min_reads) B[c].packs.push_back(std::move(pk));     // :360 strict
+                else for (auto &r : pk.reads) B[c].small.push_back(std::move(r));
             }
-            if ((int)pk.reads.size() > P->min_reads) {               // :360 strict
-                cluster_packs[c].push_back(packs.size());
-                packs.push_back(std::move(pk));
-            } else {
-                for (auto &r : pk.reads) { uncorrected.push_back(r); unc_cid.push_back((int32_t)c); }
-            }
+        });
+        for (uint32_t c = 0; c < n_clusters; ++c) {
+            if (B[c].err) { set_error("cluster member id out of range"); return RATTLE_ERR_ARG; }
+            for (auto &pk : B[c].packs) { cluster_packs[c].push_back(packs.size()); packs.push_back(std::move(pk)); }
+            for (auto &r : B[c].small) { uncorrected.push_back(std::move(r)); unc_cid.push_back((int32_t)c); }
         }
     }
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -383,6 +381,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         con_cid.push_back((int32_t)c);
         con_n.push_back(total);
     }
+    phase_timer T_fill("correct: fill results");
     fill_set(R->corrected, corrected, cor_cid, {});
     fill_set(R->uncorrected, uncorrected, unc_cid, {});
     fill_set(R->consensi, consensi, con_cid, con_n);

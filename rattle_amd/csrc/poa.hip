@@ -1089,22 +1089,25 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         for (int c = 0; c < 5; ++c) left += C[c].todo.size();
         if (left) { set_error("poa: " + std::to_string(left) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
-    std::vector<uint32_t> h_col;
     unsigned long long h_cnt[8] = {0};
     if (rc == 0) {
-        h_col.resize(total);
-        hipError_t e = hipMemcpyAsync(h_col.data(), d_col.p, total * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_width.data(), d_width.p, n_packs * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 64, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
+        phase_timer T_d2h("    poa readback");
+        rc = ctx->h_poa_col.reserve(total);
+        if (rc == 0) {
+            hipError_t e = hipMemcpyAsync(ctx->h_poa_col.p, d_col.p, total * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_width.data(), d_width.p, n_packs * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 64, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
+        }
     }
     d_seq.release(); d_off.release(); d_pf.release(); d_queue.release(); d_head.release(); d_col.release();
     d_width.release(); d_status.release(); d_cnt.release();
     if (rc) return rc;
 
-    // expand rows on the host: row = '-' * width with each base at its column
+    // expand rows on the host (one task per pack): row = '-' * width with each base at its column
     phase_timer T_expand("    poa expand rows");
+    const uint32_t *h_col = ctx->h_poa_col.p;
     uint64_t bytes = 0;
     for (uint32_t p = 0; p < n_packs; ++p) {
         R->width[p] = h_width[p];
@@ -1112,13 +1115,16 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     }
     R->row_offset[n_seqs] = bytes;
     R->rows = (char *)malloc(bytes + 1);
-    memset(R->rows, '-', bytes);
     R->rows[bytes] = 0;
-    for (uint32_t p = 0; p < n_packs; ++p)
-        for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) {
+    parallel_for(n_packs, 0, [&](size_t p) {
+        const uint32_t q0 = pack_first[p], q1 = pack_first[p + 1];
+        if (q0 == q1) return;
+        memset(R->rows + R->row_offset[q0], '-', R->row_offset[q1] - R->row_offset[q0]);
+        for (uint32_t q = q0; q < q1; ++q) {
             char *row = R->rows + R->row_offset[q];
             for (uint64_t b = off[q]; b < off[q + 1]; ++b) row[h_col[b]] = (char)seq[b];
         }
+    });
     for (int i = 0; i < 8; ++i) R->counters[i] = h_cnt[i];
     ctx->stats[K_POA].bytes += 6ull * h_cnt[0];
     return 0;
