@@ -69,9 +69,9 @@ def cpu_baseline(cat, qcat, off, tid, target_reads=600):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("RATTLE_BENCH_READS", 100000)), help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("RATTLE_BENCH_READS", 1000000)), help="reads per GPU")
     ap.add_argument("--genes", type=int, default=0, help="transcripts per GPU shard (default reads/200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -129,12 +129,13 @@ def main():
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         cells = int(res[3][0])
         out = {
-            "metric": "reads/sec for cluster+correct on synthetic ONT cDNA reads (mean 1 kb, 10% error)",
+            "metric": "reads/sec for `cluster`+`correct` on 1e6\u00d71kb synthetic ONT reads, 1\u21928 GPU",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
-            "config": {"workload": f"{a.reads} synthetic cDNA reads per GPU (mean 1 kb, 10% err, {genes} transcripts, Zipf), "
-                                   "k=10 gene-level cluster + correct (BASELINE configs[1] size, plus correct)",
+            "config": {"workload": f"{a.reads} synthetic cDNA reads per GPU (mean 1 kb, 10% err, both strands, {genes} transcripts, "
+                                   "Zipf abundance), `rattle cluster` k=10 gene level + `rattle correct` "
+                                   "(BASELINE metric size; configs[1]/[3] shape on one GPU)",
                        "reads_per_gpu": a.reads, "clusters": int(len(cl.main_id)), "poa_dp_cells_per_step": cells,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "kernel": "poa_align", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
