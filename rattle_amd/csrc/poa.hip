@@ -289,52 +289,19 @@ struct dp_xchg {                 // LDS, double-buffered by row parity
     uint32_t best_row[4];
 };
 
-// pack two int16 (low halves of a, b) into one word: 1 v_perm_b32
-__device__ __forceinline__ uint32_t pack16(int32_t a, int32_t b) { return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u); }
-
-template <int CPL>
-__device__ __forceinline__ void store_block_packed(int16_t *__restrict__ p, const int32_t *v) {
-    if (CPL % 4 == 0) {
-        uint2 *q = (uint2 *)p;
-#pragma unroll
-        for (int u = 0; u < CPL / 4; ++u) q[u] = make_uint2(pack16(v[4 * u], v[4 * u + 1]), pack16(v[4 * u + 2], v[4 * u + 3]));
-    } else {
-        uint32_t *q = (uint32_t *)p;
-#pragma unroll
-        for (int u = 0; u < CPL / 2; ++u) q[u] = pack16(v[2 * u], v[2 * u + 1]);
-    }
-}
-
-// Accumulate one predecessor row into the biased diagonal maximum hb (= Hn - n before the
-// final fix-up) and F: hb = max(hb, H[p][j-1] + (match ? m-n : 0)), fr = max(fr, H[p][j]+g, F[p][j]+e).
-template <int CPL>
-__device__ __forceinline__ void acc_pred(const int32_t *hp, const int32_t *fp, int32_t hl, const int32_t *bonus, int32_t *hb, int32_t *fr) {
-    const int32_t hleft = wave_shr1(hp[CPL - 1], hl);              // H[p][j-1] of the thread's first column
-#pragma unroll
-    for (int t = 0; t < CPL; ++t) {
-        const int32_t hd = t == 0 ? hleft : hp[t - 1];
-        hb[t] = max(hb[t], hd + bonus[t]);
-        fr[t] = max(fr[t], max(hp[t] + POA_G, fp[t] + POA_E));
-    }
-}
-
 template <int CPL, int WIN>
 __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c0 = (uint32_t)tid * CPL;
     const bool act = c0 < Lp;
-    // per-letter match masks of this thread's CPL sequence bytes (bit t: column c0+t+1 matches)
-    uint32_t mA = 0, mC = 0, mG = 0, mT = 0, mU = 0;
-    if (act) {
+    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
+    {
+        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) {
-            const uint32_t ch = S.sq[c0 + t];
-            mA |= (ch == 'A' ? 1u : 0u) << t; mC |= (ch == 'C' ? 1u : 0u) << t; mG |= (ch == 'G' ? 1u : 0u) << t;
-            mT |= (ch == 'T' ? 1u : 0u) << t; mU |= (ch == 'U' ? 1u : 0u) << t;
-        }
+        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
+#pragma unroll
+        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
     }
-    const int32_t cu0 = POA_G - ((int32_t)c0 + 2) * POA_E, cj0 = ((int32_t)c0 + 1) * POA_E;   // u offset and j*e of column c0+1
-    const uint32_t nvalid = c0 < L ? min((uint32_t)CPL, L - c0) : 0u;          // columns of this thread inside the sequence
     int32_t h1[CPL], f1[CPL], h2[WIN > 1 ? CPL : 1], f2[WIN > 1 ? CPL : 1];
 #pragma unroll
     for (int t = 0; t < CPL; ++t) { h1[t] = 0; f1[t] = POA_NEG; }
@@ -351,55 +318,65 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
         uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
         if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
         for (uint32_t i = 0; i < nb; ++i) {
-            const uint32_t info = __builtin_amdgcn_readlane(my.x, i);
+            const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
+            const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
+                                    (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
             const uint32_t row = r0 + i + 1;
             const uint32_t par = row & 1u;
             const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
-            const uint32_t mask = letter == 'A' ? mA : letter == 'C' ? mC : letter == 'G' ? mG : letter == 'T' ? mT : letter == 'U' ? mU : 0u;
-            int32_t bonus[CPL], hb[CPL], fr[CPL];
+            int32_t hn[CPL], fr[CPL];
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { bonus[t] = (mask >> t) & 1u ? (POA_M - POA_N) : 0; hb[t] = POA_NEG; fr[t] = POA_NEG; }
-            if (n_in == 0) {
+            for (int t = 0; t < CPL; ++t) { hn[t] = POA_NEG; fr[t] = POA_NEG; }
+            uint32_t e = more;
+            for (uint32_t k = 0; k < (n_in ? n_in : 1u); ++k) {
                 int32_t hp[CPL], fp[CPL];
+                int32_t hl = 0;                  // H[p][c0] for lane 0 of waves 1..3
+                uint32_t prow = 0;
+                if (n_in) {
+                    if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
+                    else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
+                }
+                if (n_in == 0) {
 #pragma unroll
-                for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
-                acc_pred<CPL>(hp, fp, 0, bonus, hb, fr);
-            } else {
-                uint32_t e = 0;
-                for (uint32_t k = 0; k < n_in; ++k) {
-                    uint32_t prow;
-                    if (k < 4) prow = __builtin_amdgcn_readlane(k == 0 ? myb.x : k == 1 ? myb.y : k == 2 ? myb.z : myb.w, i);
-                    else {
-                        if (k == 4) e = __builtin_amdgcn_readlane(my.z, i);
-                        const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1;
-                    }
-                    if (prow == row1) {
-                        acc_pred<CPL>(h1, f1, hl1, bonus, hb, fr);
-                    } else if (WIN > 1 && prow == row2) {
-                        acc_pred<CPL>(h2, f2, hl2, bonus, hb, fr);
+                    for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
+                } else if (prow == row1) {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hp[t] = h1[t]; fp[t] = f1[t]; }
+                    hl = hl1;
+                } else if (WIN > 1 && prow == row2) {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hp[t] = h2[t]; fp[t] = f2[t]; }
+                    hl = hl2;
+                } else {
+                    const int16_t *Hp = S.H + (uint64_t)prow * Lp;
+                    const int16_t *Fp = S.F + (uint64_t)prow * Lp;
+                    if (act) {
+                        load_block<CPL>(Hp + c0, hp);
+                        load_block<CPL>(Fp + c0, fp);
+                        if (lane == 0 && wave > 0) hl = S.lh[prow * 4 + wave];
                     } else {
-                        int32_t hp[CPL], fp[CPL];
-                        int32_t hl = 0;
-                        if (act) {
-                            load_block<CPL>(S.H + (uint64_t)prow * Lp + c0, hp);
-                            load_block<CPL>(S.F + (uint64_t)prow * Lp + c0, fp);
-                            if (lane == 0 && wave > 0) hl = S.lh[prow * 4 + wave];
-                        } else {
 #pragma unroll
-                            for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
-                        }
-                        acc_pred<CPL>(hp, fp, hl, bonus, hb, fr);
+                        for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
                     }
                 }
+                const int32_t hleft = wave_shr1(hp[CPL - 1], hl);      // H[p][j-1] of the thread's first column
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const int32_t hd = t == 0 ? hleft : hp[t - 1];
+                    const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                    hn[t] = max(hn[t], hd + sc);
+                    fr[t] = max(fr[t], max(hp[t] + POA_G, fp[t] + POA_E));
+                }
             }
-            int32_t hn[CPL], ex[CPL + 1];        // Hn, and the in-thread exclusive prefix max of u
-            ex[0] = POA_NEG;
+            int32_t ex[CPL];                     // in-thread exclusive prefix max of u
+            int32_t run = POA_NEG;
 #pragma unroll
             for (int t = 0; t < CPL; ++t) {
-                hn[t] = max(max(hb[t] + POA_N, fr[t]), 0);
-                ex[t + 1] = max(ex[t], hn[t] + cu0 + (-t * POA_E));  // u_j, j = c0+t+1
+                hn[t] = max(max(hn[t], fr[t]), 0);
+                ex[t] = run;
+                run = max(run, hn[t] + POA_G - ((int32_t)(c0 + t) + 2) * POA_E);     // u_j, j = c0+t+1
             }
-            const int32_t wincl = wave_scan_max(act ? ex[CPL] : POA_NEG, POA_NEG);
+            const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
             const int32_t texcl = wave_shr1(wincl, POA_NEG);
             if (lane == 63) { X.T[par][wave] = wincl; X.Tp[par][wave] = max(texcl, ex[CPL - 1]); X.Hn[par][wave] = hn[CPL - 1]; }
             row_barrier();
@@ -417,26 +394,28 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                 if (lane == 0) S.lh[row * 4 + wave] = hl_new;
             }
             base = max(base, texcl);
-            int32_t ev[CPL];
+            int32_t hv[CPL], ev[CPL];
             int32_t lane_max = 0;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int32_t j = (int32_t)(c0 + t) + 1;
+                ev[t] = max(base, ex[t]) + j * POA_E;
+                hv[t] = max(hn[t], ev[t]);
+                if (c0 + t < L) lane_max = max(lane_max, hv[t]);
+            }
+            if (act) {
+                store_block<CPL>(S.H + (uint64_t)row * Lp + c0, hv);
+                store_block<CPL>(S.F + (uint64_t)row * Lp + c0, fr);
+                store_block<CPL>(S.E + (uint64_t)row * Lp + c0, ev);
+            }
             if (WIN > 1) {
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) { h2[t] = h1[t]; f2[t] = f1[t]; }
                 hl2 = hl1; row2 = row1;
             }
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) {
-                ev[t] = max(base, ex[t]) + cj0 + t * POA_E;
-                h1[t] = max(hn[t], ev[t]);
-                f1[t] = fr[t];
-                lane_max = max(lane_max, (uint32_t)t < nvalid ? h1[t] : 0);
-            }
+            for (int t = 0; t < CPL; ++t) { h1[t] = hv[t]; f1[t] = fr[t]; }
             hl1 = hl_new; row1 = row;
-            if (act) {
-                store_block_packed<CPL>(S.H + (uint64_t)row * Lp + c0, h1);
-                store_block_packed<CPL>(S.F + (uint64_t)row * Lp + c0, fr);
-                store_block_packed<CPL>(S.E + (uint64_t)row * Lp + c0, ev);
-            }
             const int32_t row_max = wave_last(wave_scan_max(lane_max, 0));
             if (lane == 0) S.rowmax[row * 4 + wave] = row_max;
             if (row_max > my_best) { my_best = row_max; my_best_row = row; }
