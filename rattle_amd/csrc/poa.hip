@@ -92,6 +92,9 @@ struct poa_ws {                    // per-block workspace: global pointers + LDS
     uint4 *ainfo;                          // per forward pair: kind, target node, group row range (add_alignment)
     uint32_t *spill;
     uint32_t *done, *nocheck, *stack;      // LDS
+    unsigned long long *hist;
+    uint32_t *ring;                        // LDS: last RING rows of packed H|F per thread (thread-private)
+    int32_t *lh_ring;                      // LDS: left-column H of the last RING rows per wave
     uint32_t *topo;                        // LDS: in0 | min(n_in,63) << 20 | n_al << 26 per node, or nullptr
     uint8_t *sq;                           // LDS copy of the sequence, 16-byte aligned
     uint32_t n_nodes, n_edges, sp, spilled, err;
@@ -289,7 +292,7 @@ struct dp_xchg {                 // LDS, double-buffered by row parity
     uint32_t best_row[4];
 };
 
-template <int CPL, int WIN>
+template <int CPL, int WIN, int RING>
 __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c0 = (uint32_t)tid * CPL;
@@ -336,6 +339,9 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                     if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
                     else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
                 }
+#ifdef POA_HIST
+                if (tid == 0 && n_in) { const uint32_t d = row - prow; atomicAdd(&S.hist[8 + (d == 1 ? 0 : d == 2 ? 1 : d <= 4 ? 2 : d <= 8 ? 3 : d <= 16 ? 4 : d <= 64 ? 5 : 6)], 1ull); if (k > 0) atomicAdd(&S.hist[15], 1ull); }
+#endif
                 if (n_in == 0) {
 #pragma unroll
                     for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
@@ -347,6 +353,16 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
 #pragma unroll
                     for (int t = 0; t < CPL; ++t) { hp[t] = h2[t]; fp[t] = f2[t]; }
                     hl = hl2;
+                } else if (RING > 0 && row - prow <= (uint32_t)RING) {
+                    const uint32_t slot = prow & (uint32_t)(RING - 1);
+                    const uint32_t *rp = S.ring + ((size_t)slot * 256 + tid) * CPL;
+#pragma unroll
+                    for (int u = 0; u < CPL / 2; ++u) {
+                        const uint32_t a = rp[u], b = rp[CPL / 2 + u];
+                        hp[2 * u] = (int16_t)(a & 0xFFFF); hp[2 * u + 1] = (int16_t)(a >> 16);
+                        fp[2 * u] = (int16_t)(b & 0xFFFF); fp[2 * u + 1] = (int16_t)(b >> 16);
+                    }
+                    hl = S.lh_ring[slot * 4 + wave];
                 } else {
                     const int16_t *Hp = S.H + (uint64_t)prow * Lp;
                     const int16_t *Fp = S.F + (uint64_t)prow * Lp;
@@ -402,6 +418,16 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                 ev[t] = max(base, ex[t]) + j * POA_E;
                 hv[t] = max(hn[t], ev[t]);
                 if (c0 + t < L) lane_max = max(lane_max, hv[t]);
+            }
+            if (RING > 0) {
+                const uint32_t slot = row & (uint32_t)(RING - 1);
+                uint32_t *rp = S.ring + ((size_t)slot * 256 + tid) * CPL;
+#pragma unroll
+                for (int u = 0; u < CPL / 2; ++u) {
+                    rp[u] = (uint32_t)(uint16_t)(int16_t)hv[2 * u] | ((uint32_t)(uint16_t)(int16_t)hv[2 * u + 1] << 16);
+                    rp[CPL / 2 + u] = (uint32_t)(uint16_t)(int16_t)fr[2 * u] | ((uint32_t)(uint16_t)(int16_t)fr[2 * u + 1] << 16);
+                }
+                if (lane == 0) S.lh_ring[slot * 4 + wave] = hl_new;
             }
             if (act) {
                 store_block<CPL>(S.H + (uint64_t)row * Lp + c0, hv);
@@ -482,7 +508,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
-template <int CPL, int WIN>
+template <int CPL, int WIN, int RING>
 __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
@@ -501,7 +527,10 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
         const uint32_t bit_words = (A.node_cap + 31) / 32;
         S.sq = (uint8_t *)lds;                                   // seq_cap bytes (multiple of 16)
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
-        S.topo = A.lds_topo ? S.stack + POA_STACK : nullptr;
+        S.hist = A.counters;
+        S.ring = S.stack + POA_STACK;
+        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * 256 * CPL);
+        S.topo = nullptr;
     }
 
     while (true) {
@@ -549,7 +578,7 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                 t_topo += t1 - t0;
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
-                dp_rows<CPL, WIN>(S, X, n, L, Lp, best, best_row);
+                dp_rows<CPL, WIN, RING>(S, X, n, L, Lp, best, best_row);
                 cells += (unsigned long long)n * L;
                 rows += n;
                 unsigned long long t2 = PT_NOW();
@@ -895,18 +924,18 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-template <int CPL, int WIN>
+template <int CPL, int WIN, int RING>
 static hipError_t launch_poa(const poa_args &A, uint32_t n_slots, size_t shm, hipStream_t st) {
     if (shm > 60 * 1024)
-        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((poa_kernel<CPL, WIN>), dim3(n_slots), dim3(256), shm, st, A);
+        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, WIN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL((poa_kernel<CPL, WIN, RING>), dim3(n_slots), dim3(256), shm, st, A);
     return hipGetLastError();
 }
 
-template <int CPL, int WIN>
+template <int CPL, int WIN, int RING>
 static int max_blocks_per_cu(size_t shm) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, WIN>, 256, shm) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, WIN, RING>, 256, shm) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
@@ -941,11 +970,11 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     dbuf<unsigned long long> d_cnt;
     RT_TRY(d_seq.reserve(total + 64)); RT_TRY(d_off.reserve(n_seqs + 1)); RT_TRY(d_pf.reserve(n_packs + 1));
     RT_TRY(d_queue.reserve(n_packs)); RT_TRY(d_head.reserve(1)); RT_TRY(d_col.reserve(total + 64));
-    RT_TRY(d_width.reserve(n_packs)); RT_TRY(d_status.reserve(n_packs)); RT_TRY(d_cnt.reserve(8));
+    RT_TRY(d_width.reserve(n_packs)); RT_TRY(d_status.reserve(n_packs)); RT_TRY(d_cnt.reserve(16));
     RT_HIP(hipMemcpyAsync(d_seq.p, seq, total, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(d_off.p, off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(d_pf.p, pack_first, (n_packs + 1) * 4, hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemsetAsync(d_cnt.p, 0, 64, st));
+    RT_HIP(hipMemsetAsync(d_cnt.p, 0, 128, st));
     RT_HIP(hipMemsetAsync(d_status.p, 0xFF, n_packs * 4, st));
     std::vector<uint32_t> h_status(n_packs), h_width(n_packs);
 
@@ -1008,9 +1037,10 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
             A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
             A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
-            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4;
-            P.bpc = c == 0 ? max_blocks_per_cu<4, 2>(P.shm) : c == 1 ? max_blocks_per_cu<6, 2>(P.shm)
-                  : c == 2 ? max_blocks_per_cu<8, 2>(P.shm) : c == 3 ? max_blocks_per_cu<16, 1>(P.shm) : max_blocks_per_cu<24, 1>(P.shm);
+            static const uint32_t class_ring[5] = {8, 8, 8, 0, 0};     // rows of packed H|F kept in LDS per thread
+            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)class_ring[c] * 256 * cpl * 4 + 8 * 4 * 4;
+            P.bpc = c == 0 ? max_blocks_per_cu<4, 2, 8>(P.shm) : c == 1 ? max_blocks_per_cu<6, 2, 8>(P.shm)
+                  : c == 2 ? max_blocks_per_cu<8, 2, 8>(P.shm) : c == 3 ? max_blocks_per_cu<16, 1, 0>(P.shm) : max_blocks_per_cu<24, 1, 0>(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
             A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
             want_bytes += P.per_slot * P.n_slots;
@@ -1059,9 +1089,9 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
                 hipStream_t cs = ctx->poa_st[c];
                 e = hipStreamWaitEvent(cs, ctx->poa_go, 0);
                 if (e != hipSuccess) break;
-                e = c == 0 ? launch_poa<4, 2>(P.A, P.n_slots, P.shm, cs) : c == 1 ? launch_poa<6, 2>(P.A, P.n_slots, P.shm, cs)
-                  : c == 2 ? launch_poa<8, 2>(P.A, P.n_slots, P.shm, cs) : c == 3 ? launch_poa<16, 1>(P.A, P.n_slots, P.shm, cs)
-                                                                          : launch_poa<24, 1>(P.A, P.n_slots, P.shm, cs);
+                e = c == 0 ? launch_poa<4, 2, 8>(P.A, P.n_slots, P.shm, cs) : c == 1 ? launch_poa<6, 2, 8>(P.A, P.n_slots, P.shm, cs)
+                  : c == 2 ? launch_poa<8, 2, 8>(P.A, P.n_slots, P.shm, cs) : c == 3 ? launch_poa<16, 1, 0>(P.A, P.n_slots, P.shm, cs)
+                                                                             : launch_poa<24, 1, 0>(P.A, P.n_slots, P.shm, cs);
                 if (e == hipSuccess) e = hipEventRecord(ctx->poa_ev[c], cs);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[c], 0);
             }
@@ -1089,14 +1119,14 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         for (int c = 0; c < 5; ++c) left += C[c].todo.size();
         if (left) { set_error("poa: " + std::to_string(left) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
-    unsigned long long h_cnt[8] = {0};
+    unsigned long long h_cnt[16] = {0};
     if (rc == 0) {
         phase_timer T_d2h("    poa readback");
         rc = ctx->h_poa_col.reserve(total);
         if (rc == 0) {
             hipError_t e = hipMemcpyAsync(ctx->h_poa_col.p, d_col.p, total * 4, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipMemcpyAsync(h_width.data(), d_width.p, n_packs * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 64, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 128, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
         }
@@ -1126,6 +1156,10 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         }
     });
     for (int i = 0; i < 8; ++i) R->counters[i] = h_cnt[i];
+#ifdef POA_HIST
+    fprintf(stderr, "[rattle] pred distance: d1 %llu d2 %llu d3-4 %llu d5-8 %llu d9-16 %llu d17-64 %llu d>64 %llu | extra preds %llu\n", h_cnt[8], h_cnt[9],
+            h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
+#endif
     ctx->stats[K_POA].bytes += 6ull * h_cnt[0];
     return 0;
 }
