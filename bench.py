@@ -79,6 +79,8 @@ def main():
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ranks of one node share the host cores for the post-MSA logic
+    os.environ.setdefault("RATTLE_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

@@ -37,7 +37,9 @@ void set_error(const std::string &msg);
 template <typename F>
 void parallel_for(size_t n, int n_threads, F f) {
     if (n == 0) return;
-    unsigned hw = std::thread::hardware_concurrency();
+    // default width: RATTLE_HOST_THREADS, else all cores (several ranks on one host should split them)
+    static const unsigned env_threads = getenv("RATTLE_HOST_THREADS") ? (unsigned)atoi(getenv("RATTLE_HOST_THREADS")) : 0u;
+    unsigned hw = env_threads ? env_threads : std::thread::hardware_concurrency();
     size_t T = n_threads > 0 ? (size_t)n_threads : (hw ? hw : 1);
     T = std::min(T, n);
     if (T <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
