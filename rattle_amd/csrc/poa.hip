@@ -600,8 +600,8 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                     // cheap exit: if every tied row except the first has a tied direct predecessor, all of
                     // them descend from the first one, which then precedes them in ANY topological order
                     bool need_sort = s_bc[5] > 1;
+                    __syncthreads();                  // every thread has read the count before the slot is reused
                     if (need_sort) {
-                        __syncthreads();
                         if (tid == 0) s_bc[5] = 0;
                         __syncthreads();
                         for (uint32_t r = 1 + tid; r <= n; r += 256) {
@@ -620,6 +620,7 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
                         }
                         __syncthreads();
                         need_sort = s_bc[5] != 0;
+                        __syncthreads();              // ... and again before s_bc[5] becomes the best-column slot
 #ifdef POA_PROFILE
                         if (tid == 0) { atomicAdd(&A.counters[4], 1ull << 32); if (need_sort) atomicAdd(&A.counters[4], 1ull); }
 #endif

@@ -1,0 +1,80 @@
+"""Edge cases of the hot path through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+from rattle_amd import hps, synth
+from rattle_amd.api import correct_command
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_and_single_read_sets(gpu_ctx, oracle):
+    gpu_ctx.load_reads([], 10, True)
+    assert gpu_ctx.cluster_reads().as_list() == []
+    one = [b"ACGTTGCAAGGCTTACGATCGATCGGATCCATGCAAGTCCATG" * 5]
+    gpu_ctx.load_reads(one, 10, True)
+    assert gpu_ctx.cluster_reads().as_list() == oracle.cluster_reads(one, k=10)[0] == [((0, 0, -1), [(0, 0, -1)])]
+
+
+def test_identical_reverse_and_short_reads(gpu_ctx, oracle):
+    rng = np.random.default_rng(3)
+    base = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 600)].tobytes()
+    rc = base.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]
+    reads = [base, base, rc, base[:300], rc[:200], b"ACGTACGTAC", b"ACGTACG", b"T" * 40]
+    reads.sort(key=lambda s: -len(s))
+    for is_rna in (False, True):
+        gpu_ctx.load_reads(reads, 10, not is_rna)
+        got = gpu_ctx.cluster_reads(is_rna=is_rna).as_list()
+        want, _ = oracle.cluster_reads(reads, k=10, is_rna=is_rna)
+        assert got == want
+        if not is_rna:
+            assert any(s[1] for _, mem in want for s in mem)          # the reverse-complement copies join on the reverse strand
+
+
+def test_all_unrelated_reads_stay_singletons(gpu_ctx, oracle):
+    rng = np.random.default_rng(11)
+    reads = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(200, 500)))].tobytes() for _ in range(300)]
+    reads.sort(key=lambda s: -len(s))
+    gpu_ctx.load_reads(reads, 10, True)
+    got = gpu_ctx.cluster_reads().as_list()
+    want, _ = oracle.cluster_reads(reads, k=10)
+    assert got == want and len(got) == 300
+
+
+def test_polish_like_parameters_no_merge_pass(gpu_ctx, oracle):
+    """-B == -b (main.cpp:669): the merge loop never runs (cluster.cpp:171-173)."""
+    seqs, _, _, _ = synth.reads(300, 4, 1, False, seed=2)
+    seqs.sort(key=lambda s: -len(s))
+    gpu_ctx.load_reads(seqs, 6, False)
+    got = gpu_ctx.cluster_reads(t_s=0.5, t_v=25.0, bv_threshold=0.4, min_bv_threshold=0.4, bv_falloff=0.05, is_rna=True).as_list()
+    want, _ = oracle.cluster_reads(seqs, k=6, t_s=0.5, t_v=25.0, bvB=0.4, bvb=0.4, bvf=0.05, is_rna=True)
+    assert got == want
+
+
+def test_correct_small_clusters_and_u_bases(gpu_ctx, oracle):
+    """Clusters at / below min_reads go to uncorrected untouched; RNA 'U' reads go through POA."""
+    seqs, quals, _, _ = synth.reads(60, 2, 1, False, seed=9)
+    seqs = [s.replace(b"T", b"U") for s in seqs]
+    headers = [b"@u%d" % i for i in range(len(seqs))]
+    clusters = [((0, 0, -1), [(i, 0, -1) for i in range(0, 5)]),            # 5 reads: not > min_reads
+                ((5, 0, -1), [(i, 0, -1) for i in range(5, 11)]),           # 6 reads: corrected
+                ((11, 0, -1), [(11, 0, -1)]),
+                ((12, 0, -1), [(i, 0, -1) for i in range(12, 60)])]
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters)
+    want = oracle.correct(headers, seqs, quals, hps.encode(clusters))
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    assert got[1].count(b"@u") >= 6
+
+
+def test_poa_unalignable_and_single_sequence_packs(gpu_ctx, oracle):
+    packs = [[b"ACGTTGCA" * 20], [b"A" * 100, b"C" * 80, b"G" * 60], [b"ACGTTGCA" * 20, b"TGCAACGT" * 20, b"ACGTTGCA" * 19]]
+    rows, width, _ = gpu_ctx.poa_msa(packs)
+    for p, pack in enumerate(packs):
+        want, _ = oracle.poa_msa(pack)
+        assert rows[p] == want
+
+
+def test_sequence_longer_than_kernel_limit_is_an_error(gpu_ctx):
+    from rattle_amd._lib import RattleError
+    with pytest.raises(RattleError):
+        gpu_ctx.poa_msa([[b"ACGT" * 1600, b"ACGT" * 1600]])      # 6400 nt > 6144
