@@ -49,7 +49,10 @@ def cpu_baseline(cat, qcat, off, tid, target_reads=600):
     orc = orc_mod.Oracle()
     rng = np.random.default_rng(1)
     ids = []
+    counts = np.bincount(tid)
     for g in rng.permutation(int(tid.max()) + 1):
+        if counts[g] > target_reads // 2 or counts[g] < 6:      # keep the sample bounded (~10-30 s of CPU)
+            continue
         ids += [i for i in np.nonzero(tid == g)[0]]
         if len(ids) >= target_reads:
             break
