@@ -3,6 +3,7 @@
 // :325-412 (`correct`) closely enough to diff output files against the product CLI.
 #include <cstring>
 #include <iostream>
+#include <map>
 
 #include "orc_cluster.hpp"
 #include "orc_correct.hpp"
@@ -63,6 +64,41 @@ int main(int argc, char **argv) {
         write_fastq(R.uncorrected, o + "/uncorrected.fq");
         write_fastq(R.consensi, o + "/consensi.fq");
         std::cerr << "packs=" << cc.packs << " alignments=" << cc.alignments << " dp_cells=" << cc.dp_cells << std::endl;
+        return 0;
+    }
+    if (mode == "polish") {                                       // main.cpp:612-762
+        read_set_t reads = read_fastq_plain(opt(argc, argv, "-i", ""), "");
+        sort_read_set(reads);
+        bool is_rna = flag(argc, argv, "--rna");
+        cluster_set_t clusters = cluster_reads(reads, 6, 0.5, 25, 0.4, 0.4, 0.05, 0, false, 0.15, is_rna);
+        correction_results_t R = correct_reads(clusters, reads, 0.3, 0.3, 30.0, 200, 0, {});
+        int cid = 0;
+        std::map<int, int> gene_map;
+        int gid = -1;
+        for (auto &r : R.consensi) {
+            int total_reads = 0;
+            for (auto &m : clusters[cid].seqs) {
+                const std::string &h = reads[m.seq_id].header;     // already carries the ",gene_cluster_x" suffix: irrelevant for '=' / '_' fields used below
+                auto info = split_string(h, '=');
+                total_reads += std::stoi(info[1]);
+                auto info_c = split_string(h, '_');
+                if (h.find("transcript_cluster") != std::string::npos) {
+                    int id = std::stoi(info_c[4]);
+                    if (gene_map.find(id) == gene_map.end()) { if (gid == -1) gid = id; gene_map.insert({id, gid}); }
+                    else gid = gene_map.find(id)->second;
+                }
+            }
+            int rcount = std::stoi(split_string(r.header, '=')[1]);
+            if (gid != -1)
+                r.header = "@transcript_cluster_" + std::to_string(cid) + " gene_cluster_" + std::to_string(gid) +
+                           " generated_from_transcript_clusters=" + std::to_string(rcount) + " total_reads=" + std::to_string(total_reads) + " labels=";
+            else
+                r.header = "@cluster_" + std::to_string(cid) + " generated_from_consensi_clusters=" + std::to_string(rcount) +
+                           " total_reads=" + std::to_string(total_reads) + " labels=";
+            ++cid;
+            gid = -1;
+        }
+        write_fastq(R.consensi, std::string(opt(argc, argv, "-o", ".")) + "/transcriptome.fq");
         return 0;
     }
     std::cerr << "unknown mode\n";

@@ -1,5 +1,5 @@
-// `rattle` command line: drop-in for `rattle cluster` (/root/reference/main.cpp:133-324) and
-// `rattle correct` (/root/reference/main.cpp:325-412) over librattle_hip.so's C ABI.
+// `rattle` command line: drop-in for `rattle cluster` (/root/reference/main.cpp:133-324),
+// `rattle correct` (:325-412) and `rattle polish` (:612-762) over librattle_hip.so's C ABI.
 // Same flags and defaults, same `clusters.out` (hps stream) and FASTQ outputs.  Host C++ only:
 // every compute step goes through include/rattle_hip.h.
 #include <unistd.h>
@@ -453,20 +453,132 @@ int mode_correct(int argc, char **argv) {
     return EXIT_SUCCESS;
 }
 
+// `rattle polish`, /root/reference/main.cpp:612-762: cluster the consensi (k=6, 0.5, 25, bv 0.4/0.4 so
+// no merge pass), correct with min_reads=0, rewrite the consensus headers.
+int mode_polish(int argc, char **argv) {
+    std::vector<opt_def> defs = {
+        {"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"output", {"-o", "--output-folder"}, true},
+        {"label", {"-l", "--label"}, true}, {"threads", {"-t", "--threads"}, true}, {"rna", {"--rna"}, false},
+        {"verbose", {"--verbose"}, false}, {"summary", {"--summary"}, false}, {"device", {"--device"}, true}};
+    args_t a = parse(argc, argv, defs);
+    if (a.has("help")) { std::cerr << "rattle polish -i consensi.fq [-o dir] [--rna] [--summary]\n"; return EXIT_SUCCESS; }
+    if (!a.has("input")) die("ERROR: No input file provided");
+    std::cerr << "Reading fasta file... ";
+    std::string in = a.str("input", "");
+    if (access(in.c_str(), F_OK)) die("\nError: Input file not found! \n");
+    read_set_t reads;
+    for_each_record(in, true, [&](const std::string &h, const std::string &s, const std::string &an, const std::string &q) {
+        reads.push_back(read_t{h, s, an, q});
+    });
+    std::stable_sort(reads.begin(), reads.end(), [](const read_t &x, const read_t &y) { return x.seq.size() > y.seq.size(); });
+    std::cerr << "Done" << std::endl;
+    const bool is_rna = a.has("rna"), summary = a.has("summary");
+    std::vector<std::string> labels = split_string(a.str("label", ""), ',');
+    std::cerr << "Clustering consensus sequences..." << std::endl;
+    rattle_ctx *ctx = nullptr;
+    chk(rattle_hip_ctx_create(a.i("device", 0), &ctx));
+    rattle_cluster_params P;
+    P.t_s = 0.5; P.t_v = 25; P.bv_threshold = 0.4; P.min_bv_threshold = 0.4; P.bv_falloff = 0.05;
+    P.min_reads_cluster = 0; P.use_hc = 0; P.repr_percentile = 0.15; P.is_rna = is_rna ? 1 : 0;
+    load(ctx, reads, 6, !is_rna);
+    rattle_cluster_set *raw = nullptr;
+    chk(rattle_hip_cluster_reads(ctx, &P, &raw));
+    cluster_set_t clusters = to_set(raw);
+
+    std::string cat, qcat;
+    std::vector<uint64_t> off(1, 0);
+    for (auto &r : reads) {
+        cat += r.seq;
+        std::string q = r.quality;
+        q.resize(r.seq.size(), '!');
+        qcat += q;
+        off.push_back(cat.size());
+    }
+    std::vector<uint32_t> coff(1, 0);
+    std::vector<int32_t> mid;
+    std::vector<uint8_t> mrev;
+    for (auto &c : clusters) {
+        for (auto &s : c.seqs) { mid.push_back(s.seq_id); mrev.push_back(s.rev ? 1 : 0); }
+        coff.push_back((uint32_t)mid.size());
+    }
+    rattle_correct_params CP;
+    memset(&CP, 0, sizeof(CP));
+    CP.min_occ = 0.3; CP.gap_occ = 0.3; CP.err_ratio = 30.0; CP.split = 200; CP.min_reads = 0; CP.n_threads = 0;
+    rattle_correction *R = nullptr;
+    chk(rattle_hip_correct_reads(ctx, (const uint8_t *)cat.data(), (const uint8_t *)qcat.data(), off.data(), (uint32_t)reads.size(),
+                                 (uint32_t)clusters.size(), coff.data(), mid.data(), mrev.data(), &CP, &R));
+    read_set_t out;
+    std::vector<std::string> summary_results;
+    std::map<int, int> gene_map;
+    int gid = -1;
+    for (uint32_t i = 0; i < R->consensi.n; ++i) {
+        const int cid = R->consensi.cluster_id[i];           // == i: every cluster has a pack with min_reads = 0
+        int total_reads = 0;
+        std::vector<int> label_counts(labels.size(), 0);
+        for (auto &m : clusters[cid].seqs) {
+            const std::string &h = reads[m.seq_id].header;
+            auto info = split_string(h, '=');
+            total_reads += std::stoi(info.at(1));
+            for (size_t l = 0; l < labels.size(); ++l) {
+                size_t idx = h.find(labels[l]);
+                if (idx != std::string::npos) {
+                    std::string sub = h.substr(idx + 1);
+                    label_counts[l] += std::stoi(sub.substr(sub.find_first_of(":") + 1));
+                }
+            }
+            auto info_c = split_string(h, '_');
+            if (h.find("transcript_cluster") != std::string::npos) {
+                int id = std::stoi(info_c.at(4));
+                if (gene_map.find(id) == gene_map.end()) { if (gid == -1) gid = id; gene_map.insert({id, gid}); }
+                else gid = gene_map.find(id)->second;
+                if (summary) summary_results.push_back("transcript_cluster_" + std::to_string(std::stoi(info_c.at(2))) + ", gene_cluster_" +
+                                                       std::to_string(id) + ", new_cluster_" + std::to_string(cid));
+            } else if (summary) {
+                summary_results.push_back("gene_cluster_" + std::to_string(std::stoi(info_c.at(2))) + ", new_cluster_" + std::to_string(cid));
+            }
+        }
+        const int rcount = R->consensi.n_reads[i];           // the "reads=" field correct_reads writes (correct.cpp:542)
+        read_t r;
+        if (gid != -1)
+            r.header = "@transcript_cluster_" + std::to_string(cid) + " gene_cluster_" + std::to_string(gid) + " generated_from_transcript_clusters=" +
+                       std::to_string(rcount) + " total_reads=" + std::to_string(total_reads) + " labels=";
+        else
+            r.header = "@cluster_" + std::to_string(cid) + " generated_from_consensi_clusters=" + std::to_string(rcount) + " total_reads=" +
+                       std::to_string(total_reads) + " labels=";
+        for (size_t l = 0; l < labels.size(); ++l) r.header += labels[l] + ":" + std::to_string(label_counts[l]) + ",";
+        r.seq.assign(R->consensi.seq + R->consensi.off[i], R->consensi.seq + R->consensi.off[i + 1]);
+        r.quality.assign(R->consensi.qual + R->consensi.off[i], R->consensi.qual + R->consensi.off[i + 1]);
+        r.ann = "+";
+        out.push_back(r);
+        gid = -1;
+    }
+    const std::string outdir = a.str("output", ".");
+    if (summary) {
+        std::ofstream f(outdir + "/polish_summary.tsv");
+        for (auto &l : summary_results) f << l << "\n";
+    }
+    write_fastq_file(out, outdir + "/transcriptome.fq");
+    rattle_hip_correction_free(R);
+    rattle_hip_ctx_destroy(ctx);
+    std::cerr << "Done" << std::endl;
+    return EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::cout << "Run with mode: ./rattle <cluster|correct>" << std::endl;
+        std::cout << "Run with mode: ./rattle <cluster|correct|polish>" << std::endl;
         return EXIT_FAILURE;
     }
     try {
         if (!strcmp(argv[1], "cluster")) return mode_cluster(argc, argv);
         if (!strcmp(argv[1], "correct")) return mode_correct(argc, argv);
+        if (!strcmp(argv[1], "polish")) return mode_polish(argc, argv);
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
         return EXIT_FAILURE;
     }
-    std::cout << "Run with mode: ./rattle <cluster|correct>" << std::endl;
+    std::cout << "Run with mode: ./rattle <cluster|correct|polish>" << std::endl;
     return EXIT_FAILURE;
 }

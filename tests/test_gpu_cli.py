@@ -53,3 +53,37 @@ def test_cluster_and_correct_cli_match_oracle_cli(built, tmp_path):
     for f in ("corrected.fq", "uncorrected.fq", "consensi.fq"):
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
     assert (a / "consensi.fq").read_bytes().startswith(b"@transcript_cluster_0 gene_cluster_0 reads=")
+
+
+def test_polish_cli_reproduces_transcriptome_fixture_and_oracle(built, tmp_path):
+    """`rattle polish --rna` on the shipped consensi.fq == toyset/rna/output/transcriptome.fq (175
+    singletons, length-sorted, same total_reads) and == the oracle CLI byte for byte."""
+    import re
+    (tmp_path / "consensi.fq").write_bytes(gzip.open(os.path.join(GOLDEN, "toyset_rna.consensi.fq.gz")).read())
+    a = tmp_path / "a"; b = tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    subprocess.run([RATTLE, "polish", "-i", str(tmp_path / "consensi.fq"), "-o", str(a), "--rna"], check=True, capture_output=True)
+    subprocess.run([ORACLE, "polish", "-i", str(tmp_path / "consensi.fq"), "-o", str(b), "--rna"], check=True, capture_output=True)
+    got = (a / "transcriptome.fq").read_bytes()
+    assert got == (b / "transcriptome.fq").read_bytes()
+    want = gzip.open(os.path.join(GOLDEN, "toyset_rna.transcriptome.fq.gz"), "rt").read().split("\n")
+    mine = got.decode().split("\n")
+    assert len(mine) == len(want) == 175 * 4 + 1
+    for i in range(0, 175 * 4, 4):
+        assert mine[i + 1] == want[i + 1]
+        assert mine[i].split()[0] == want[i].split()[0]
+        assert re.search(r"total_reads=(\d+)", mine[i]).group(1) == re.search(r"total_reads=(\d+)", want[i]).group(1)
+
+
+def test_polish_cli_merges_similar_consensi(built, tmp_path):
+    """cDNA-mode polish on consensi that DO cluster (near-duplicate sequences, some reverse-complemented)."""
+    seqs, quals, _, _ = synth.reads(40, 3, 1, True, seed=23, sub=0.01, ins=0.005, dele=0.005)
+    recs = b"".join(b"@gene_cluster_%d reads=%d labels=\n%s\n+\n%s\n" % (i, 6 + i, s, b"K" * len(s)) for i, s in enumerate(seqs))
+    (tmp_path / "c.fq").write_bytes(recs)
+    a = tmp_path / "a"; b = tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    subprocess.run([RATTLE, "polish", "-i", str(tmp_path / "c.fq"), "-o", str(a)], check=True, capture_output=True)
+    subprocess.run([ORACLE, "polish", "-i", str(tmp_path / "c.fq"), "-o", str(b)], check=True, capture_output=True)
+    got = (a / "transcriptome.fq").read_bytes()
+    assert got == (b / "transcriptome.fq").read_bytes()
+    assert 1 <= got.count(b"@cluster_") < 40
