@@ -453,6 +453,74 @@ int mode_correct(int argc, char **argv) {
     return EXIT_SUCCESS;
 }
 
+std::string reverse_complement(const std::string &seq) {          // utils.cpp:15-24
+    std::string r(seq.size(), 'A');
+    for (size_t i = 0; i < seq.size(); ++i) {
+        char c = seq[seq.size() - 1 - i];
+        r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'U' ? 'A' : c;
+    }
+    return r;
+}
+
+// `rattle cluster_summary`, /root/reference/main.cpp:413-483 (host only, no device)
+int mode_cluster_summary(int argc, char **argv) {
+    std::vector<opt_def> defs = {{"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"label", {"-l", "--label"}, true},
+                                 {"clusters", {"-c", "--clusters"}, true}};
+    args_t a = parse(argc, argv, defs);
+    if (a.has("help")) { std::cerr << "rattle cluster_summary -i reads.fq -c clusters.out\n"; return EXIT_SUCCESS; }
+    if (!a.has("input")) die("ERROR: No input file provided");
+    if (!a.has("clusters")) die("ERROR: No clusters file provided");
+    std::cerr << "Reading fasta file... ";
+    read_set_t reads = read_inputs(split_string(a.str("input", ""), ','), split_string(a.str("label", ""), ','));
+    std::cerr << "Done" << std::endl;
+    cluster_set_t clusters = read_clusters(a.str("clusters", ""));
+    int cid = 0;
+    for (auto &c : clusters) {
+        for (auto &s : c.seqs) {
+            if ((size_t)s.seq_id >= reads.size()) die("\nError: cluster member id out of range\n");
+            if (c.main_seq.gene_id == -1) std::cout << reads[s.seq_id].header << ",gene_cluster_" << cid << "\n";
+            else std::cout << reads[s.seq_id].header << ",gene_cluster_" << s.gene_id << ",transcript_cluster_" << cid << "\n";
+        }
+        ++cid;
+    }
+    return EXIT_SUCCESS;
+}
+
+// `rattle extract_clusters`, /root/reference/main.cpp:484-611 (host only, no device)
+int mode_extract_clusters(int argc, char **argv) {
+    std::vector<opt_def> defs = {{"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"label", {"-l", "--label"}, true},
+                                 {"clusters", {"-c", "--clusters"}, true}, {"output", {"-o", "--output-folder"}, true},
+                                 {"minreads", {"-m", "--min-reads"}, true}, {"fastq", {"--fastq"}, false}};
+    args_t a = parse(argc, argv, defs);
+    if (a.has("help")) { std::cerr << "rattle extract_clusters -i reads.fq -c clusters.out [-o dir] [-m N] [--fastq]\n"; return EXIT_SUCCESS; }
+    if (!a.has("input")) die("ERROR: No input file provided");
+    if (!a.has("clusters")) die("ERROR: No clusters file provided");
+    if (a.has("output") && access(a.str("output", ".").c_str(), F_OK)) die("\nOutput folder doesn't exit. Please create it first. \n");
+    std::cerr << "Reading fasta file... ";
+    read_set_t reads = read_inputs(split_string(a.str("input", ""), ','), split_string(a.str("label", ""), ','));
+    std::cerr << "Done" << std::endl;
+    cluster_set_t clusters = read_clusters(a.str("clusters", ""));
+    const int min_reads = a.i("minreads", 0);
+    const bool fastq = a.has("fastq");
+    int cid = 0;
+    for (auto &c : clusters) {
+        if ((int)c.seqs.size() > min_reads) {
+            std::string fn = (a.has("output") ? a.str("output", ".") + "/" : std::string()) + "cluster_" + std::to_string(cid) + (fastq ? ".fq" : ".fa");
+            std::ofstream f(fn);
+            for (auto &s : c.seqs) {
+                if ((size_t)s.seq_id >= reads.size()) die("\nError: cluster member id out of range\n");
+                const read_t &r = reads[s.seq_id];
+                if (c.main_seq.gene_id == -1) f << r.header << "\n";
+                else f << r.header << "," << s.gene_id << "\n";
+                f << (s.rev ? reverse_complement(r.seq) : r.seq) << "\n";          // quality is NOT reversed (main.cpp:585-588)
+                if (fastq) f << r.ann << "\n" << r.quality << "\n";
+            }
+        }
+        ++cid;
+    }
+    return EXIT_SUCCESS;
+}
+
 // `rattle polish`, /root/reference/main.cpp:612-762: cluster the consensi (k=6, 0.5, 25, bv 0.4/0.4 so
 // no merge pass), correct with min_reads=0, rewrite the consensus headers.
 int mode_polish(int argc, char **argv) {
@@ -568,17 +636,19 @@ int mode_polish(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::cout << "Run with mode: ./rattle <cluster|correct|polish>" << std::endl;
+        std::cout << "Run with mode: ./rattle <cluster|cluster_summary|extract_clusters|correct|polish>" << std::endl;
         return EXIT_FAILURE;
     }
     try {
         if (!strcmp(argv[1], "cluster")) return mode_cluster(argc, argv);
         if (!strcmp(argv[1], "correct")) return mode_correct(argc, argv);
         if (!strcmp(argv[1], "polish")) return mode_polish(argc, argv);
+        if (!strcmp(argv[1], "cluster_summary")) return mode_cluster_summary(argc, argv);
+        if (!strcmp(argv[1], "extract_clusters")) return mode_extract_clusters(argc, argv);
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
         return EXIT_FAILURE;
     }
-    std::cout << "Run with mode: ./rattle <cluster|correct|polish>" << std::endl;
+    std::cout << "Run with mode: ./rattle <cluster|cluster_summary|extract_clusters|correct|polish>" << std::endl;
     return EXIT_FAILURE;
 }

@@ -14,6 +14,8 @@ Outputs (data only: inputs and expected outputs, no reference source text):
   tests/golden/toyset_rna.consensi.fq.gz  expected `correct` consensi
   tests/golden/toyset_rna.uncorrected.ids expected headers of uncorrected.fq
   tests/golden/toyset_rna.transcriptome.fq.gz expected `polish` result
+  tests/golden/toyset_rna.cluster_summary.tsv.gz  expected `cluster_summary` output (old 2-column layout)
+  tests/golden/toyset_rna.cluster_{0,7,545}.fq    expected `extract_clusters --fastq` files (three samples)
   tests/golden/toyset_iso.clusters.out    3-field format KAT (cluster_benchmark)
   tests/golden/toyset_iso.summary.tsv.gz
 """
@@ -61,6 +63,9 @@ def main():
     unc = open(f"{REF}/rna/output/uncorrected.fq").read().split("\n")
     ids = [unc[i] for i in range(0, len(unc) - 1, 4)]
     open(f"{OUT}/toyset_rna.uncorrected.ids", "w").write("\n".join(ids) + "\n")
+    gz_write(f"{OUT}/toyset_rna.cluster_summary.tsv.gz", open(f"{REF}/rna/output/cluster_summary.tsv", "rb").read())
+    for cid in (0, 7, 545):
+        shutil.copyfile(f"{REF}/rna/output/clusters/cluster_{cid}.fq", f"{OUT}/toyset_rna.cluster_{cid}.fq")
     shutil.copyfile(f"{REF}/cluster_benchmark/output/clusters.out", f"{OUT}/toyset_iso.clusters.out")
     gz_write(f"{OUT}/toyset_iso.summary.tsv.gz", open(f"{REF}/cluster_benchmark/output/summary.tsv", "rb").read())
     print(f"recovered {n} reads, {len(clusters)} clusters, lengths {min(lens)}..{max(lens)}")
