@@ -1038,11 +1038,12 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
             A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
             A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
-            static const uint32_t class_ring[5] = {0, 0, 0, 0, 0};     // LDS ring of recent rows: helps a lone pack (-9 % DP) but costs
-            // occupancy; measured slower at 1e6 reads (34.1k vs 37.7k reads/s), so off
+            // LDS ring of the last RING rows (packed H|F, thread-private): 8 rows cost a block per CU and
+            // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.
+            static const uint32_t class_ring[5] = {4, 4, 4, 0, 0};
             P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)class_ring[c] * 256 * cpl * 4 + 8 * 4 * 4;
-            P.bpc = c == 0 ? max_blocks_per_cu<4, 2, 0>(P.shm) : c == 1 ? max_blocks_per_cu<6, 2, 0>(P.shm)
-                  : c == 2 ? max_blocks_per_cu<8, 2, 0>(P.shm) : c == 3 ? max_blocks_per_cu<16, 1, 0>(P.shm) : max_blocks_per_cu<24, 1, 0>(P.shm);
+            P.bpc = c == 0 ? max_blocks_per_cu<4, 2, 4>(P.shm) : c == 1 ? max_blocks_per_cu<6, 2, 4>(P.shm)
+                  : c == 2 ? max_blocks_per_cu<8, 2, 4>(P.shm) : c == 3 ? max_blocks_per_cu<16, 1, 0>(P.shm) : max_blocks_per_cu<24, 1, 0>(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
             A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
             want_bytes += P.per_slot * P.n_slots;
@@ -1091,8 +1092,8 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
                 hipStream_t cs = ctx->poa_st[c];
                 e = hipStreamWaitEvent(cs, ctx->poa_go, 0);
                 if (e != hipSuccess) break;
-                e = c == 0 ? launch_poa<4, 2, 0>(P.A, P.n_slots, P.shm, cs) : c == 1 ? launch_poa<6, 2, 0>(P.A, P.n_slots, P.shm, cs)
-                  : c == 2 ? launch_poa<8, 2, 0>(P.A, P.n_slots, P.shm, cs) : c == 3 ? launch_poa<16, 1, 0>(P.A, P.n_slots, P.shm, cs)
+                e = c == 0 ? launch_poa<4, 2, 4>(P.A, P.n_slots, P.shm, cs) : c == 1 ? launch_poa<6, 2, 4>(P.A, P.n_slots, P.shm, cs)
+                  : c == 2 ? launch_poa<8, 2, 4>(P.A, P.n_slots, P.shm, cs) : c == 3 ? launch_poa<16, 1, 0>(P.A, P.n_slots, P.shm, cs)
                                                                              : launch_poa<24, 1, 0>(P.A, P.n_slots, P.shm, cs);
                 if (e == hipSuccess) e = hipEventRecord(ctx->poa_ev[c], cs);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[c], 0);
