@@ -150,6 +150,8 @@ void correct_pack(pack_t &pk, const std::vector<std::string> &aln, const vote_t 
         long sp = -1;
         hread out;
         out.rid = pk.reads[i].rid;
+        out.seq.reserve(q.size() + 16);
+        out.qual.reserve(q.size() + 16);
         for (size_t k = 0; k < row.size(); ++k) {
             const char nt = row[k];
             double ep = 0.0;
@@ -181,6 +183,7 @@ void correct_pack(pack_t &pk, const std::vector<std::string> &aln, const vote_t 
 
 std::string strip_gaps(const std::string &s) {
     std::string o;
+    o.reserve(s.size());
     for (char c : s) if (c != '-') o += c;
     return o;
 }

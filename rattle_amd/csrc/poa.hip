@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
             atomicAdd(&A.counters[2], (unsigned long long)S.n_nodes);
             atomicAdd(&A.counters[3], rows);
 #ifdef POA_PROFILE
-            (void)t_topo;                              // counters[4]: ties << 32 | ties that needed the exact sort
+            (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add;                              // counters[4]: ties << 32 | ties that needed the exact sort
             atomicAdd(&A.counters[5], t_dp);           // DP rows
             atomicAdd(&A.counters[6], t_tb);           // best cell + traceback
             atomicAdd(&A.counters[7], t_add);          // add_alignment
