@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
         const uint32_t q0 = A.pack_first[pk], q1 = A.pack_first[pk + 1];
         S.n_nodes = 0; S.n_edges = 0; S.err = 0; S.sp = 0; S.spilled = 0;
         unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0;
+        (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add;
 
         for (uint32_t q = q0; q < q1 && !S.err; ++q) {
             const uint64_t so = A.off[q];
