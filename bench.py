@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from rattle_amd import synth  # noqa: E402
-from rattle_amd.api import K_FILTER, K_KMER, K_POA, K_SCORE, Context  # noqa: E402
+from rattle_amd.api import K_FILTER, K_KMER, K_POA, K_POST, K_SCORE, Context  # noqa: E402
 
 
 def make_workload(n_reads, genes, seed):
@@ -128,7 +128,7 @@ def main():
     value = total_reads / (dt / a.steps)
 
     if rank == 0:
-        names = {K_KMER: "kmer_extract", K_FILTER: "bv_filter", K_SCORE: "pair_score", K_POA: "poa_align"}
+        names = {K_KMER: "kmer_extract", K_FILTER: "bv_filter", K_SCORE: "pair_score", K_POA: "poa_align", K_POST: "post_msa"}
         kst = {names[k]: ctx.kernel_stats(k) for k in names}
         ms, launches, alg = kst["poa_align"]
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

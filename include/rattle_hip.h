@@ -182,7 +182,7 @@ void rattle_hip_correction_free(rattle_correction *c);
 
 /* ------------------------------------------------------------------------------------
  * Per-kernel timing measured with HIP events on the stream the kernels run on.
- * kernel: 0 kmer_extract, 1 bv_filter, 2 pair_score, 3 poa_align.  Accumulated since
+ * kernel: 0 kmer_extract, 1 bv_filter, 2 pair_score, 3 poa_align, 4 post_msa.  Accumulated since
  * the last reset: total milliseconds, number of launches, algorithmic bytes moved.
  */
 int rattle_hip_kernel_stats(rattle_ctx *ctx, int kernel, double *total_ms, uint64_t *launches, uint64_t *alg_bytes);

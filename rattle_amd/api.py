@@ -18,7 +18,7 @@ import numpy as np
 from . import _lib
 from ._lib import ClusterParams, ClusterSet, Correction, CorrectParams, MsaSet, check
 
-K_KMER, K_FILTER, K_SCORE, K_POA = 0, 1, 2, 3
+K_KMER, K_FILTER, K_SCORE, K_POA, K_POST = 0, 1, 2, 3, 4
 
 
 def _ptr(a: np.ndarray, t):

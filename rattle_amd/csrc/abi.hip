@@ -66,6 +66,7 @@ void rattle_hip_ctx_destroy(rattle_ctx *c) {
     for (int i = 0; i < 5; ++i) { if (c->poa_st[i]) (void)hipStreamDestroy(c->poa_st[i]); if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]); }
     if (c->poa_go) (void)hipEventDestroy(c->poa_go);
     c->h_poa_col.release();
+    c->d_phred_lo.release(); c->d_perr.release(); c->d_exc_bits.release(); c->d_exc_val.release();
     c->h_surv.release(); c->h_res.release(); c->h_var.release(); c->h_counter.release();
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);

@@ -110,7 +110,7 @@ struct hbuf {
     }
 };
 
-enum { K_KMER = 0, K_FILTER = 1, K_SCORE = 2, K_POA = 3, K_COUNT = 4 };
+enum { K_KMER = 0, K_FILTER = 1, K_SCORE = 2, K_POA = 3, K_POST = 4, K_COUNT = 5 };
 
 struct kstat {
     double ms = 0;
@@ -134,6 +134,47 @@ struct read_index {
     dbuf<uint32_t> kp[2];             // positions in that order                     [total_kmers]
     dbuf<uint64_t> bv[2];             // bit-vectors, 64 words per read              [n*64]
     dbuf<uint32_t> pc[2];             // popcount of each bit-vector                 [n]
+};
+
+// phred_symbol(p) = (char)(-10*log10(p)+33) as a table of thresholds built with the host libm (post_msa.hip)
+struct phred_table {
+    int n0 = 0;
+    std::vector<double> lo;             // lo[t]: smallest p whose symbol value is <= n0 + t
+    std::vector<uint64_t> exc_bits;     // doubles (bit patterns, sorted) the table would get wrong
+    std::vector<int32_t> exc_val;
+};
+void build_phred_table(phred_table &T);
+
+// copy descriptor of the gather kernel: flags bit 0 = reverse complement (qualities reversed)
+struct gather_desc {
+    uint64_t src, dst;
+    uint32_t len, flags;
+};
+
+// arguments of the post-MSA kernel (post_msa.hip)
+struct post_args {
+    const uint8_t *seq, *qual;          // stage input, concatenated (qual: MODE 1 only)
+    const uint64_t *off;                // per sequence
+    const uint32_t *pack_first;         // per pack
+    const uint32_t *col, *width;        // kernel C output: column per base, width per pack
+    const uint64_t *moff;               // per pack: byte offset of its rows x width matrix (16-byte aligned)
+    const uint64_t *coff;               // per pack: offset of its per-column arrays
+    uint8_t *rowc, *rowq;               // matrices: bases / quality bytes; MODE 1 leaves the corrected read at each row start
+    int32_t *rfirst, *rlast;            // per sequence: voting window after fix_msa_ends
+    uint32_t *tfront, *tback;           // per sequence: bases trimmed by fix_msa_ends (MODE 1)
+    uint32_t *olen;                     // per sequence: corrected length (MODE 1)
+    uint8_t *ccons, *cflag, *csym;      // per column: winner, occupancy tests, quality symbol of the winner's mean error
+    double *cerr;                       // per column: winner's mean error
+    uint8_t *cons_out;                  // per pack (at coff): gap-stripped consensus (MODE 2)
+    uint32_t *cons_len;
+    const double *perr;                 // [256] phred_err per quality byte (utils.cpp:10-13), host computed
+    const double *phred_lo;
+    const unsigned long long *exc_bits;
+    const int32_t *exc_val;
+    int32_t phred_n0, phred_cnt;
+    uint32_t n_exc;
+    uint8_t order[8];                   // vote slot order
+    double min_occ, gap_occ, err_ratio;
 };
 
 }  // namespace rattle
@@ -167,6 +208,12 @@ struct rattle_ctx {
     hipEvent_t poa_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t poa_go = nullptr;
     rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns
+    // post-MSA kernel constants (built on first use)
+    rattle::phred_table phred;
+    rattle::dbuf<double> d_phred_lo, d_perr;
+    rattle::dbuf<unsigned long long> d_exc_bits;
+    rattle::dbuf<int32_t> d_exc_val;
+    bool phred_ready = false;
 };
 
 namespace rattle {
@@ -200,6 +247,14 @@ int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fw
                      uint32_t list_cap);
 // pair_score.hip : pairs in ctx->d_pi/d_pj/d_ps; results in ctx->d_res (4 ints per pair) + ctx->d_var.
 int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs);
+// poa.hip : device-resident POA over packs (sequences, offsets, column output in HBM)
+int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n_seqs,
+                   const uint32_t *h_pack_first, uint32_t n_packs, uint32_t *d_col, uint32_t *d_width, uint32_t *h_width,
+                   unsigned long long *h_cnt);
+// post_msa.hip
+int launch_gather(rattle_ctx *ctx, const gather_desc *d_desc, uint32_t n, const uint8_t *sseq, const uint8_t *squal, uint8_t *dseq,
+                  uint8_t *dqual);
+int launch_post_msa(rattle_ctx *ctx, const post_args &A, uint32_t n_packs, int mode);
 // cluster_driver.cpp
 int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32_t *subset, uint32_t n_subset,
                    rattle_cluster_set **out);

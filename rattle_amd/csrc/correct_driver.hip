@@ -1,10 +1,13 @@
-// Host orchestration of `rattle correct`, /root/reference/correct.cpp:311-563, over kernel C.
+// Host orchestration of `rattle correct`, /root/reference/correct.cpp:311-563, over kernels C and D.
 //
 // The reference runs a queue of packs through worker threads, two POAs per pack
 // (correct.cpp:398-405, 428-436) plus one per multi-pack cluster (:520-532).  Packs are
-// independent, so here each POA stage is ONE device launch over all packs, and the cheap
-// post-MSA logic (fix_msa_ends :32-92, column vote :94-193, per-read correction :196-309) runs
-// between launches on host threads, one pack per task, in the reference's operation order.
+// independent, so here each POA stage is ONE device pass over all packs, and the post-MSA logic
+// (fix_msa_ends :32-92, column vote :94-193, per-read correction :196-309) is kernel D
+// (post_msa.hip), one workgroup per pack.  Sequences, qualities, MSA columns and row matrices stay
+// in HBM from the upload of the reads to the download of the corrected reads and consensi; between
+// stages the host only sees lengths (pack widths, corrected read lengths, trim counts), from which it
+// plans the next stage (pack order, length-sorted order for POA #2, gather descriptors).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -14,9 +17,6 @@
 
 namespace rattle {
 
-int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n_seqs, const uint32_t *pack_first,
-                uint32_t n_packs, rattle_msa_set **out);
-
 namespace {
 
 struct hread {
@@ -24,27 +24,7 @@ struct hread {
     int32_t rid;
 };
 
-struct pack_t {
-    int32_t cid;
-    std::vector<hread> reads;        // pack members (mutated by fix_msa_ends)
-    std::vector<hread> corrected;    // after correction, then length-sorted for POA #2
-    std::vector<hread> dropped;      // reads whose corrected sequence came out empty
-    std::string consensus;
-};
-
-struct vote_t {
-    char order[6];
-    int slot[256];
-    double perr[256];                // phred_err per quality byte, utils.cpp:10-13
-    void init(const char *o) {
-        memcpy(order, o, 6);
-        for (int i = 0; i < 256; ++i) slot[i] = -1;
-        for (int i = 0; i < 6; ++i) slot[(unsigned char)order[i]] = i;
-        for (int c = 0; c < 256; ++c) { double q = (char)c - 33; perr[c] = pow(10.0, -q / 10.0); }
-    }
-};
-
-inline char phred_symbol(double p) { return (char)(-10 * log10(p) + 33); }     // utils.cpp:6-8
+struct sref { int32_t rid; uint8_t rev; };
 
 inline char comp_base(char c) {                                                  // utils.hpp:8-14
     switch (c) {
@@ -54,175 +34,28 @@ inline char comp_base(char c) {                                                 
         case 'G': return 'C';
         case 'U': return 'A';
     }
-    return c;       // undefined in the reference (end() dereference); clustered reads never contain it
+    return c;
 }
 
-// correct.cpp:32-92.  Two phases per row: trim small leading blocks followed by a long gap,
-// then reverse and do the same from the other end; `seq`/`qual` follow (plain reversal).
-void fix_msa_ends(std::vector<hread> &reads, std::vector<std::string> &aln) {
-    for (size_t i = 0; i < aln.size(); ++i) {
-        std::string &row = aln[i];
-        const size_t n = row.size();
-        for (int phase = 0; phase < 2; ++phase) {
-            size_t pos = 0;
-            bool stopped = false;
-            while (pos < n) {
-                while (pos < n && row[pos] == '-') ++pos;
-                size_t end = pos;
-                int gaps = 0, sz = 0;
-                while (gaps < 4 && end < n) {
-                    if (row[end] == '-') ++gaps; else { ++sz; gaps = 0; }
-                    ++end;
-                }
-                if (sz < 10) {
-                    while (end < n && row[end] == '-') { ++end; ++gaps; }
-                    if (gaps >= 20) {
-                        std::fill(row.begin() + pos, row.begin() + end, '-');
-                        reads[i].qual.erase(0, sz);
-                        reads[i].seq.erase(0, sz);
-                        pos = end;
-                        continue;
-                    }
-                }
-                std::reverse(row.begin(), row.end());
-                std::reverse(reads[i].qual.begin(), reads[i].qual.end());
-                std::reverse(reads[i].seq.begin(), reads[i].seq.end());
-                stopped = true;
-                break;
-            }
-            if (!stopped) break;     // ran off the row end: no reversal, no second phase (goto never taken)
-        }
+// pack member in the orientation the reference aligns it in (correct.cpp:343-346), trimmed by [tf, len - tb)
+hread oriented_read(const uint8_t *seq, const uint8_t *qual, const uint64_t *off, sref r, uint32_t tf, uint32_t tb) {
+    hread h;
+    h.rid = r.rid;
+    h.seq.assign((const char *)seq + off[r.rid], (const char *)seq + off[r.rid + 1]);
+    h.qual.assign((const char *)qual + off[r.rid], (const char *)qual + off[r.rid + 1]);
+    if (r.rev) {
+        std::string rc(h.seq.size(), 'A');
+        for (size_t t = 0; t < h.seq.size(); ++t) rc[t] = comp_base(h.seq[h.seq.size() - 1 - t]);
+        h.seq.swap(rc);
+        std::reverse(h.qual.begin(), h.qual.end());
     }
-}
-
-struct colinfo { double err[6]; int occ[6]; int total; };
-
-// correct.cpp:94-193 (n_threads = 1 accumulation order: rows in order).
-void column_vote(const std::vector<hread> &reads, const std::vector<std::string> &aln, const vote_t &V,
-                 std::vector<colinfo> &cols, std::string &cons) {
-    cols.clear(); cons.clear();
-    if (reads.empty() || aln.empty()) return;
-    const size_t W = aln[0].size();
-    cols.assign(W, colinfo{});
-    for (size_t i = 0; i < reads.size(); ++i) {
-        const std::string &row = aln[i];
-        const std::string &q = reads[i].qual;
-        long sp = -1;
-        const long qn = (long)q.size();
-        for (size_t k = 0; k < W; ++k) {
-            const char nt = row[k];
-            double ep = 0.0;
-            if (nt != '-') { ++sp; ep = V.perr[(unsigned char)(sp < qn ? q[sp] : 0)]; }
-            if (sp >= 0 && sp < qn) {
-                const int s = V.slot[(unsigned char)nt];
-                colinfo &c = cols[k];
-                c.occ[s]++;
-                c.err[s] += ep;
-                if (sp == qn - 1) ++sp;
-            }
-        }
+    if (tf || tb) {
+        const size_t n = h.seq.size();
+        const size_t a = std::min<size_t>(tf, n), b = n - std::min<size_t>(tb, n - a);
+        h.seq = h.seq.substr(a, b - a);
+        h.qual = h.qual.substr(a, b - a);
     }
-    cons.resize(W);
-    for (size_t k = 0; k < W; ++k) {
-        colinfo &c = cols[k];
-        int tot = 0;
-        for (int s = 0; s < 6; ++s) tot += c.occ[s];
-        c.total = tot;
-        int best = 0; char nt = 0;
-        for (int s = 0; s < 6; ++s) {             // reference iteration order, strict '>' (correct.cpp:174-186)
-            if (c.occ[s] > 0) c.err[s] /= double(c.occ[s]);
-            if (c.occ[s] > best) { best = c.occ[s]; nt = V.order[s]; }
-        }
-        cons[k] = nt == 0 ? '-' : nt;
-    }
-}
-
-// correct.cpp:196-309
-void correct_pack(pack_t &pk, const std::vector<std::string> &aln, const vote_t &V, double min_occ, double gap_occ,
-                  double err_ratio) {
-    std::vector<colinfo> cols;
-    std::string cons;
-    column_vote(pk.reads, aln, V, cols, cons);
-    for (size_t i = 0; i < pk.reads.size(); ++i) {
-        const std::string &row = aln[i];
-        const std::string &q = pk.reads[i].qual;
-        const long qn = (long)q.size();
-        long sp = -1;
-        hread out;
-        out.rid = pk.reads[i].rid;
-        out.seq.reserve(q.size() + 16);
-        out.qual.reserve(q.size() + 16);
-        for (size_t k = 0; k < row.size(); ++k) {
-            const char nt = row[k];
-            double ep = 0.0;
-            if (nt != '-') { ++sp; ep = V.perr[(unsigned char)(sp < qn ? q[sp] : 0)]; }
-            if (sp >= 0 && sp < qn) {
-                const char cnt = cons[k];
-                const int cs = V.slot[(unsigned char)cnt];
-                const colinfo &c = cols[k];
-                const double occ_ratio = double(c.occ[cs]) / double(c.total);
-                const double cerr = c.err[cs];
-                if (cnt == '-') {
-                    if (nt != '-' && !(occ_ratio >= gap_occ)) { out.seq += nt; out.qual += q[sp]; }
-                } else if (nt == '-') {
-                    if (occ_ratio >= gap_occ) { out.seq += cnt; out.qual += phred_symbol(cerr); }
-                } else if (nt == cnt) {
-                    out.seq += nt; out.qual += q[sp];
-                } else if (occ_ratio >= min_occ && err_ratio * ep > cerr) {
-                    out.seq += cnt; out.qual += phred_symbol(cerr);
-                } else {
-                    out.seq += nt; out.qual += q[sp];
-                }
-                if (sp == qn - 1) ++sp;
-            }
-        }
-        if (!out.seq.empty()) pk.corrected.push_back(std::move(out));
-        else pk.dropped.push_back(pk.reads[i]);
-    }
-}
-
-std::string strip_gaps(const std::string &s) {
-    std::string o;
-    o.reserve(s.size());
-    for (char c : s) if (c != '-') o += c;
-    return o;
-}
-
-// Run one POA stage over a list of sequence groups; returns rows per group.
-int poa_stage(rattle_ctx *ctx, const std::vector<const std::vector<hread> *> &groups,
-              std::vector<std::vector<std::string>> &msas, uint64_t *counters) {
-    msas.assign(groups.size(), {});
-    std::vector<uint64_t> off(1, 0);
-    std::vector<uint32_t> first(1, 0);
-    for (auto g : groups) {
-        for (auto &r : *g) off.push_back(off.back() + r.seq.size());
-        first.push_back((uint32_t)off.size() - 1);
-    }
-    std::string cat(off.back(), 'A');
-    parallel_for(groups.size(), 0, [&](size_t g) {
-        uint32_t q = first[g];
-        for (auto &r : *groups[g]) { memcpy(&cat[off[q]], r.seq.data(), r.seq.size()); ++q; }
-    });
-    rattle_msa_set *ms = nullptr;
-    int rc;
-    {
-        phase_timer T0("  poa_stage: msa_run");
-        rc = poa_msa_run(ctx, (const uint8_t *)cat.data(), off.data(), (uint32_t)off.size() - 1, first.data(),
-                         (uint32_t)groups.size(), &ms);
-    }
-    if (rc == 0) {
-        phase_timer T1("  poa_stage: copy rows");
-        parallel_for(groups.size(), 0, [&](size_t g) {
-            uint32_t q = first[g];
-            msas[g].resize(groups[g]->size());
-            for (size_t i = 0; i < groups[g]->size(); ++i, ++q)
-                msas[g][i].assign(ms->rows + ms->row_offset[q], ms->rows + ms->row_offset[q + 1]);
-        });
-        counters[0] += ms->counters[0];
-        counters[1] += ms->counters[1];
-    }
-    rattle_hip_msa_set_free(ms);
-    return rc;
+    return h;
 }
 
 void fill_set(rattle_read_set &S, const std::vector<hread> &v, const std::vector<int32_t> &cid, const std::vector<int32_t> &nr) {
@@ -234,19 +67,115 @@ void fill_set(rattle_read_set &S, const std::vector<hread> &v, const std::vector
     for (size_t i = 0; i < v.size(); ++i) { S.off[i] = tot; tot += v[i].seq.size(); }
     S.off[v.size()] = tot;
     S.seq = (char *)malloc(tot + 1); S.qual = (char *)malloc(tot + 1);
-    const size_t chunk = 1024;
-    parallel_for((v.size() + chunk - 1) / chunk, 0, [&](size_t c) {
-        for (size_t i = c * chunk; i < std::min(v.size(), (c + 1) * chunk); ++i) {
-            S.read_id[i] = v[i].rid; S.cluster_id[i] = cid[i]; S.n_reads[i] = nr.empty() ? 0 : nr[i];
-            const uint64_t p = S.off[i];
-            memcpy(S.seq + p, v[i].seq.data(), v[i].seq.size());
-            // qualities always have the sequence's length on this path; guard anyway
-            const size_t ql = std::min(v[i].qual.size(), v[i].seq.size());
-            memcpy(S.qual + p, v[i].qual.data(), ql);
-            if (ql < v[i].seq.size()) memset(S.qual + p + ql, '!', v[i].seq.size() - ql);
-        }
-    });
+    for (size_t i = 0; i < v.size(); ++i) {
+        S.read_id[i] = v[i].rid; S.cluster_id[i] = cid[i]; S.n_reads[i] = nr.empty() ? 0 : nr[i];
+        const uint64_t p = S.off[i];
+        memcpy(S.seq + p, v[i].seq.data(), v[i].seq.size());
+        const size_t ql = std::min(v[i].qual.size(), v[i].seq.size());
+        memcpy(S.qual + p, v[i].qual.data(), ql);
+        if (ql < v[i].seq.size()) memset(S.qual + p + ql, '!', v[i].seq.size() - ql);
+    }
     S.seq[tot] = 0; S.qual[tot] = 0;
+}
+
+// constants of kernel D: phred_symbol thresholds (host libm) and phred_err per quality byte (utils.cpp:10-13)
+int ensure_post_constants(rattle_ctx *ctx) {
+    if (ctx->phred_ready) return 0;
+    build_phred_table(ctx->phred);
+    const phred_table &T = ctx->phred;
+    double perr[256];
+    for (int c = 0; c < 256; ++c) { double q = (char)c - 33; perr[c] = pow(10.0, -q / 10.0); }
+    RT_TRY(ctx->d_phred_lo.reserve(T.lo.size())); RT_TRY(ctx->d_perr.reserve(256));
+    RT_TRY(ctx->d_exc_bits.reserve(T.exc_bits.size() + 1)); RT_TRY(ctx->d_exc_val.reserve(T.exc_val.size() + 1));
+    RT_HIP(hipMemcpy(ctx->d_phred_lo.p, T.lo.data(), T.lo.size() * 8, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_perr.p, perr, sizeof(perr), hipMemcpyHostToDevice));
+    if (!T.exc_bits.empty()) {
+        RT_HIP(hipMemcpy(ctx->d_exc_bits.p, T.exc_bits.data(), T.exc_bits.size() * 8, hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(ctx->d_exc_val.p, T.exc_val.data(), T.exc_val.size() * 4, hipMemcpyHostToDevice));
+    }
+    ctx->phred_ready = true;
+    return 0;
+}
+
+// One POA stage + kernel D over device-resident sequences.
+struct stage {
+    std::vector<uint64_t> off;          // [n+1] host copy of the sequence offsets
+    std::vector<uint32_t> first;        // [n_packs+1]
+    std::vector<uint32_t> width;        // [n_packs] MSA width (after the POA)
+    std::vector<uint64_t> moff, coff;   // per pack: matrix byte offset / column-array offset
+    uint64_t cells = 0, cols = 0;
+    dbuf<uint8_t> seq, qual, rowc, rowq, ccons, cflag, csym, cons_out;
+    dbuf<uint64_t> d_off, d_moff, d_coff;
+    dbuf<uint32_t> col, d_width, d_first, tfront, tback, olen, cons_len;
+    dbuf<int32_t> rfirst, rlast;
+    dbuf<double> cerr;
+    uint32_t n() const { return (uint32_t)off.size() - 1; }
+    uint32_t n_packs() const { return (uint32_t)first.size() - 1; }
+    void release() {
+        seq.release(); qual.release(); rowc.release(); rowq.release(); ccons.release(); cflag.release(); csym.release();
+        cons_out.release(); d_off.release(); d_moff.release(); d_coff.release(); col.release(); d_width.release();
+        d_first.release(); tfront.release(); tback.release(); olen.release(); cons_len.release(); rfirst.release();
+        rlast.release(); cerr.release();
+    }
+};
+
+// gather the stage's sequences (descriptors built by the caller, dst offsets = st.off) and run POA + kernel D
+int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, const uint8_t *src_seq, const uint8_t *src_qual,
+              int mode, const rattle_correct_params *P, const char *order, uint64_t *counters) {
+    hipStream_t st = ctx->stream;
+    const uint32_t n = S.n(), np = S.n_packs();
+    const uint64_t total = S.off[n];
+    S.width.assign(np, 0);
+    if (np == 0) return 0;
+    dbuf<gather_desc> d_desc;
+    RT_TRY(d_desc.reserve(n + 1));
+    RT_TRY(S.seq.reserve(total + 64)); RT_TRY(S.d_off.reserve(n + 1)); RT_TRY(S.col.reserve(total + 64));
+    RT_TRY(S.d_width.reserve(np)); RT_TRY(S.d_first.reserve(np + 1));
+    if (mode == 1) RT_TRY(S.qual.reserve(total + 64));
+    if (n) RT_HIP(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n * sizeof(gather_desc), hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(S.d_off.p, S.off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(S.d_first.p, S.first.data(), (size_t)(np + 1) * 4, hipMemcpyHostToDevice, st));
+    RT_TRY(launch_gather(ctx, d_desc.p, n, src_seq, mode == 1 ? src_qual : nullptr, S.seq.p, mode == 1 ? S.qual.p : nullptr));
+    unsigned long long h_cnt[16];
+    {
+        phase_timer T("  stage: POA");
+        RT_TRY(poa_device_run(ctx, S.seq.p, S.d_off.p, S.off.data(), n, S.first.data(), np, S.col.p, S.d_width.p, S.width.data(), h_cnt));
+    }
+    d_desc.release();
+    counters[0] += h_cnt[0];
+    counters[1] += h_cnt[1];
+    // layout of the row matrices and per-column arrays
+    S.moff.assign(np, 0); S.coff.assign(np, 0);
+    uint64_t cells = 0, cols = 0;
+    for (uint32_t p = 0; p < np; ++p) {
+        S.moff[p] = cells; S.coff[p] = cols;
+        cells += ((uint64_t)(S.first[p + 1] - S.first[p]) * S.width[p] + 15) & ~(uint64_t)15;
+        cols += S.width[p];
+    }
+    S.cells = cells; S.cols = cols;
+    phase_timer T("  stage: post-MSA kernel");
+    RT_TRY(S.rowc.reserve(cells + 64)); RT_TRY(S.d_moff.reserve(np)); RT_TRY(S.d_coff.reserve(np));
+    RT_TRY(S.rfirst.reserve(n + 1)); RT_TRY(S.rlast.reserve(n + 1)); RT_TRY(S.ccons.reserve(cols + 64));
+    if (mode == 1) {
+        RT_TRY(S.rowq.reserve(cells + 64)); RT_TRY(S.tfront.reserve(n + 1)); RT_TRY(S.tback.reserve(n + 1)); RT_TRY(S.olen.reserve(n + 1));
+        RT_TRY(S.cflag.reserve(cols + 64)); RT_TRY(S.csym.reserve(cols + 64)); RT_TRY(S.cerr.reserve(cols + 8));
+    } else {
+        RT_TRY(S.cons_out.reserve(cols + 64)); RT_TRY(S.cons_len.reserve(np));
+    }
+    RT_HIP(hipMemcpyAsync(S.d_moff.p, S.moff.data(), (size_t)np * 8, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(S.d_coff.p, S.coff.data(), (size_t)np * 8, hipMemcpyHostToDevice, st));
+    post_args A;
+    memset(&A, 0, sizeof(A));
+    A.seq = S.seq.p; A.qual = S.qual.p; A.off = S.d_off.p; A.pack_first = S.d_first.p; A.col = S.col.p; A.width = S.d_width.p;
+    A.moff = S.d_moff.p; A.coff = S.d_coff.p; A.rowc = S.rowc.p; A.rowq = S.rowq.p; A.rfirst = S.rfirst.p; A.rlast = S.rlast.p;
+    A.tfront = S.tfront.p; A.tback = S.tback.p; A.olen = S.olen.p; A.ccons = S.ccons.p; A.cflag = S.cflag.p; A.csym = S.csym.p;
+    A.cerr = S.cerr.p; A.cons_out = S.cons_out.p; A.cons_len = S.cons_len.p; A.perr = ctx->d_perr.p; A.phred_lo = ctx->d_phred_lo.p;
+    A.exc_bits = ctx->d_exc_bits.p; A.exc_val = ctx->d_exc_val.p; A.phred_n0 = ctx->phred.n0; A.phred_cnt = (int32_t)ctx->phred.lo.size();
+    A.n_exc = (uint32_t)ctx->phred.exc_bits.size();
+    memcpy(A.order, order, 6);
+    A.min_occ = P->min_occ; A.gap_occ = P->gap_occ; A.err_ratio = P->err_ratio;
+    RT_TRY(launch_post_msa(ctx, A, np, mode));
+    return 0;
 }
 
 }  // namespace
@@ -254,138 +183,213 @@ void fill_set(rattle_read_set &S, const std::vector<hread> &v, const std::vector
 int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n_reads,
                    uint32_t n_clusters, const uint32_t *coff, const int32_t *mid, const uint8_t *mrev,
                    const rattle_correct_params *P, rattle_correction **out) {
-    vote_t V;
-    V.init(P->vote_order[0] ? P->vote_order : "U-GTCA");
+    char order[8] = {0};
+    memcpy(order, P->vote_order[0] ? P->vote_order : "U-GTCA", 6);
     for (int i = 0; i < 6; ++i)
-        if (!strchr("ACGTU-", V.order[i])) { set_error("vote_order must be a permutation of ACGTU-"); return RATTLE_ERR_ARG; }
+        if (!order[i] || !strchr("ACGTU-", order[i])) { set_error("vote_order must be a permutation of ACGTU-"); return RATTLE_ERR_ARG; }
     const int split = P->split > 0 ? P->split : 200;
     rattle_correction *R = (rattle_correction *)calloc(1, sizeof(rattle_correction));
     *out = R;
-
+    hipStream_t st = ctx->stream;
     phase_timer T_all("correct: total");
-    std::vector<pack_t> packs;
+    RT_TRY(ensure_post_constants(ctx));
+
+    // ---- correct.cpp:328-370 pack building: ids and strands only, the bases stay where they are
+    std::vector<int32_t> pk_cid;
+    std::vector<sref> S1r, small;
+    std::vector<int32_t> small_cid;
+    std::vector<uint32_t> cl_p0(n_clusters, 0), cl_np(n_clusters, 0);
+    stage S1;
+    S1.first.assign(1, 0);
+    for (uint32_t c = 0; c < n_clusters; ++c) {
+        const uint32_t a = coff[c], b = coff[c + 1];
+        const int n = (int)(b - a);
+        cl_p0[c] = (uint32_t)pk_cid.size();
+        if (n <= 0) continue;
+        const int n_files = (n - 1) / split + 1;
+        for (int nf = 0; nf < n_files; ++nf) {
+            const size_t start = S1r.size();
+            for (int j = nf; j < n; j += n_files) {
+                const int32_t rid = mid[a + j];
+                if (rid < 0 || (uint32_t)rid >= n_reads) { set_error("cluster member id out of range"); return RATTLE_ERR_ARG; }
+                S1r.push_back(sref{rid, (uint8_t)(mrev[a + j] ? 1 : 0)});
+            }
+            if ((int)(S1r.size() - start) > P->min_reads) {                      // :360 strict
+                pk_cid.push_back((int32_t)c);
+                S1.first.push_back((uint32_t)S1r.size());
+                ++cl_np[c];
+            } else {
+                for (size_t t = start; t < S1r.size(); ++t) { small.push_back(S1r[t]); small_cid.push_back((int32_t)c); }
+                S1r.resize(start);
+            }
+        }
+    }
+    const uint32_t n_packs = (uint32_t)pk_cid.size(), n1 = (uint32_t)S1r.size();
+    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    counters[2] = n_packs;
+
+    // only A, C, G, T, U are defined for the vote (an unordered_map key set in the reference)
+    {
+        bool ok[256] = {false};
+        ok['A'] = ok['C'] = ok['G'] = ok['T'] = ok['U'] = true;
+        std::atomic<int> bad(0);
+        const size_t chunk = 4096;
+        parallel_for((n1 + chunk - 1) / chunk, P->n_threads, [&](size_t c) {
+            for (size_t q = c * chunk; q < std::min<size_t>(n1, (c + 1) * chunk); ++q)
+                for (uint64_t b = off[S1r[q].rid]; b < off[S1r[q].rid + 1]; ++b)
+                    if (!ok[seq[b]]) { bad = 1; return; }
+        });
+        if (bad) { set_error("correct: read contains a base other than A, C, G, T, U"); return RATTLE_ERR_ARG; }
+    }
+
     std::vector<hread> uncorrected;
     std::vector<int32_t> unc_cid;
-    std::vector<std::vector<size_t>> cluster_packs(n_clusters);
-    // ---- correct.cpp:328-370 pack building (clusters are independent: built in parallel, kept in order)
-    {
-        phase_timer T("correct: build packs");
-        struct built { std::vector<pack_t> packs; std::vector<hread> small; int err = 0; };
-        std::vector<built> B(n_clusters);
-        parallel_for(n_clusters, P->n_threads, [&](size_t c) {
-            const uint32_t a = coff[c], b = coff[c + 1];
-            const int n = (int)(b - a);
-            if (n == 0) return;
-            const int n_files = (n - 1) / split + 1;
-            for (int nf = 0; nf < n_files; ++nf) {
-                pack_t pk;
-                pk.cid = (int32_t)c;
-                for (int j = nf; j < n; j += n_files) {
-                    const int32_t rid = mid[a + j];
-                    if (rid < 0 || (uint32_t)rid >= n_reads) { B[c].err = 1; return; }
-                    hread r;
-                    r.rid = rid;
-                    r.seq.assign((const char *)seq + off[rid], (const char *)seq + off[rid + 1]);
-                    r.qual.assign((const char *)qual + off[rid], (const char *)qual + off[rid + 1]);
-                    if (mrev[a + j]) {                                   // :343-346
-                        std::string rc(r.seq.size(), 'A');
-                        for (size_t t = 0; t < r.seq.size(); ++t) rc[t] = comp_base(r.seq[r.seq.size() - 1 - t]);
-                        r.seq.swap(rc);
-                        std::reverse(r.qual.begin(), r.qual.end());
-                    }
-                    pk.reads.push_back(std::move(r));
-                }
-                if ((int)pk.reads.size() > P->min_reads) B[c].packs.push_back(std::move(pk));     // :360 strict
-                else for (auto &r : pk.reads) B[c].small.push_back(std::move(r));
-            }
-        });
-        for (uint32_t c = 0; c < n_clusters; ++c) {
-            if (B[c].err) { set_error("cluster member id out of range"); return RATTLE_ERR_ARG; }
-            for (auto &pk : B[c].packs) { cluster_packs[c].push_back(packs.size()); packs.push_back(std::move(pk)); }
-            for (auto &r : B[c].small) { uncorrected.push_back(std::move(r)); unc_cid.push_back((int32_t)c); }
-        }
-    }
-    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    counters[2] = packs.size();
+    for (size_t i = 0; i < small.size(); ++i) { uncorrected.push_back(oriented_read(seq, qual, off, small[i], 0, 0)); unc_cid.push_back(small_cid[i]); }
 
-    // ---- POA #1 (correct.cpp:398-405) + fix ends + correction (:407-409)
-    std::vector<std::vector<std::string>> msas;
-    {
-        phase_timer T("correct: POA#1 stage");
-        std::vector<const std::vector<hread> *> groups;
-        for (auto &p : packs) groups.push_back(&p.reads);
-        RT_TRY(poa_stage(ctx, groups, msas, counters));
-    }
-    { phase_timer T("correct: vote+correct host");
-    parallel_for(packs.size(), P->n_threads, [&](size_t i) {
-        fix_msa_ends(packs[i].reads, msas[i]);
-        correct_pack(packs[i], msas[i], V, P->min_occ, P->gap_occ, P->err_ratio);
-        msas[i].clear();
-    }); }
-    std::vector<hread> corrected;
-    std::vector<int32_t> cor_cid;
-    for (auto &p : packs) {                                         // :413-425 (pack order)
-        for (auto &r : p.corrected) { corrected.push_back(r); cor_cid.push_back(p.cid); }
-        for (auto &r : p.dropped) { uncorrected.push_back(r); unc_cid.push_back(p.cid); }
-    }
-    // ---- POA #2 over the corrected reads, stably sorted by length desc (:427-445)
-    {
-        phase_timer T("correct: POA#2 stage");
-        std::vector<const std::vector<hread> *> groups;
-        for (auto &p : packs) {
-            std::stable_sort(p.corrected.begin(), p.corrected.end(), [](const hread &a, const hread &b) { return a.seq.size() > b.seq.size(); });
-            groups.push_back(&p.corrected);
-        }
-        RT_TRY(poa_stage(ctx, groups, msas, counters));
-    }
-    parallel_for(packs.size(), P->n_threads, [&](size_t i) {
-        fix_msa_ends(packs[i].corrected, msas[i]);
-        std::vector<colinfo> cols;
-        std::string cons;
-        column_vote(packs[i].corrected, msas[i], V, cols, cons);
-        packs[i].consensus = strip_gaps(cons);
-        msas[i].clear();
-    });
-    // ---- per-cluster consensus (:489-556); POA #3 for clusters with more than one pack
-    std::vector<std::vector<hread>> multi;
+    std::vector<uint32_t> olen(n1 + 1, 0), tfront(n1 + 1, 0), tback(n1 + 1, 0);
+    std::vector<uint32_t> cons_len2(n_packs + 1, 0);
+    std::vector<uint8_t> cons2;                      // pack consensi, concatenated at S2.coff
+    stage S2, S3;
     std::vector<uint32_t> multi_cid;
-    for (uint32_t c = 0; c < n_clusters; ++c) {
-        if (cluster_packs[c].size() > 1) {
-            std::vector<hread> g;
-            for (size_t pi : cluster_packs[c]) g.push_back(hread{packs[pi].consensus, std::string(packs[pi].consensus.size(), 'K'), -1});
-            multi.push_back(std::move(g));
+    std::vector<uint32_t> cons_len3;
+    std::vector<uint8_t> cons3;
+    if (n_packs) {
+        // ---- reads -> HBM, oriented pack members gathered into stage 1 (:343-346)
+        const uint64_t total_in = off[n_reads];
+        dbuf<uint8_t> d_rseq, d_rqual;
+        {
+            phase_timer T("correct: upload + gather");
+            RT_TRY(d_rseq.reserve(total_in + 64)); RT_TRY(d_rqual.reserve(total_in + 64));
+            RT_HIP(hipMemcpyAsync(d_rseq.p, seq, total_in, hipMemcpyHostToDevice, st));
+            RT_HIP(hipMemcpyAsync(d_rqual.p, qual, total_in, hipMemcpyHostToDevice, st));
+        }
+        std::vector<gather_desc> desc(n1);
+        S1.off.assign(n1 + 1, 0);
+        for (uint32_t q = 0; q < n1; ++q) {
+            const uint32_t len = (uint32_t)(off[S1r[q].rid + 1] - off[S1r[q].rid]);
+            desc[q] = gather_desc{off[S1r[q].rid], S1.off[q], len, S1r[q].rev};
+            S1.off[q + 1] = S1.off[q] + len;
+        }
+        // ---- POA #1 (correct.cpp:398-405) + fix ends + correction (:407-409)
+        {
+            phase_timer T("correct: stage 1");
+            RT_TRY(run_stage(ctx, S1, desc, d_rseq.p, d_rqual.p, 1, P, order, counters));
+            RT_HIP(hipMemcpyAsync(olen.data(), S1.olen.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipMemcpyAsync(tfront.data(), S1.tfront.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipMemcpyAsync(tback.data(), S1.tback.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+        }
+        d_rseq.release(); d_rqual.release();
+        S1.seq.release(); S1.qual.release(); S1.col.release();
+
+        // ---- corrected reads in pack order (:413-425): compacted on the device, one download
+        {
+            phase_timer T("correct: corrected reads D2H");
+            std::vector<gather_desc> od;
+            std::vector<uint32_t> oq;
+            uint64_t tot = 0;
+            for (uint32_t p = 0; p < n_packs; ++p)
+                for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q) {
+                    if (olen[q] == 0) continue;
+                    od.push_back(gather_desc{S1.moff[p] + (uint64_t)(q - S1.first[p]) * S1.width[p], tot, olen[q], 0u});
+                    oq.push_back(q);
+                    tot += olen[q];
+                }
+            rattle_read_set &C = R->corrected;
+            const size_t nc = od.size();
+            C.n = (uint32_t)nc;
+            C.read_id = (int32_t *)malloc(std::max<size_t>(1, nc) * 4); C.cluster_id = (int32_t *)malloc(std::max<size_t>(1, nc) * 4);
+            C.n_reads = (int32_t *)malloc(std::max<size_t>(1, nc) * 4); C.off = (uint64_t *)malloc((nc + 1) * 8);
+            C.seq = (char *)malloc(tot + 1); C.qual = (char *)malloc(tot + 1);
+            C.seq[tot] = 0; C.qual[tot] = 0;
+            uint32_t p = 0;
+            for (size_t i = 0; i < nc; ++i) {
+                while (oq[i] >= S1.first[p + 1]) ++p;
+                C.read_id[i] = S1r[oq[i]].rid; C.cluster_id[i] = pk_cid[p]; C.n_reads[i] = 0; C.off[i] = od[i].dst;
+            }
+            C.off[nc] = tot;
+            if (nc) {
+                dbuf<gather_desc> d_od;
+                dbuf<uint8_t> d_os, d_oq;
+                RT_TRY(d_od.reserve(nc)); RT_TRY(d_os.reserve(tot + 64)); RT_TRY(d_oq.reserve(tot + 64));
+                RT_HIP(hipMemcpyAsync(d_od.p, od.data(), nc * sizeof(gather_desc), hipMemcpyHostToDevice, st));
+                RT_TRY(launch_gather(ctx, d_od.p, (uint32_t)nc, S1.rowc.p, S1.rowq.p, d_os.p, d_oq.p));
+                RT_HIP(hipMemcpyAsync(C.seq, d_os.p, tot, hipMemcpyDeviceToHost, st));
+                RT_HIP(hipMemcpyAsync(C.qual, d_oq.p, tot, hipMemcpyDeviceToHost, st));
+                RT_HIP(hipStreamSynchronize(st));
+                d_od.release(); d_os.release(); d_oq.release();
+            }
+        }
+        // reads whose corrected sequence came out empty: uncorrected, as fix_msa_ends left them (:289-293)
+        for (uint32_t p = 0; p < n_packs; ++p)
+            for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q)
+                if (olen[q] == 0) { uncorrected.push_back(oriented_read(seq, qual, off, S1r[q], tfront[q], tback[q])); unc_cid.push_back(pk_cid[p]); }
+
+        // ---- POA #2 over the corrected reads, stably sorted by length desc (:427-445), + consensus vote
+        {
+            phase_timer T("correct: stage 2");
+            std::vector<gather_desc> desc2;
+            S2.first.assign(1, 0);
+            S2.off.assign(1, 0);
+            std::vector<uint32_t> rows;
+            for (uint32_t p = 0; p < n_packs; ++p) {
+                rows.clear();
+                for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q) if (olen[q]) rows.push_back(q);
+                std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return olen[a] > olen[b]; });
+                for (uint32_t q : rows) {
+                    desc2.push_back(gather_desc{S1.moff[p] + (uint64_t)(q - S1.first[p]) * S1.width[p], S2.off.back(), olen[q], 0u});
+                    S2.off.push_back(S2.off.back() + olen[q]);
+                }
+                S2.first.push_back((uint32_t)S2.off.size() - 1);
+            }
+            RT_TRY(run_stage(ctx, S2, desc2, S1.rowc.p, nullptr, 2, P, order, counters));
+            cons2.resize(S2.cols + 1);
+            RT_HIP(hipMemcpyAsync(cons_len2.data(), S2.cons_len.p, (size_t)n_packs * 4, hipMemcpyDeviceToHost, st));
+            if (S2.cols) RT_HIP(hipMemcpyAsync(cons2.data(), S2.cons_out.p, S2.cols, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+        }
+        S1.release();
+
+        // ---- per-cluster consensus (:489-556); POA #3 for clusters with more than one pack
+        std::vector<gather_desc> desc3;
+        S3.first.assign(1, 0);
+        S3.off.assign(1, 0);
+        for (uint32_t c = 0; c < n_clusters; ++c) {
+            if (cl_np[c] <= 1) continue;
+            for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) {
+                desc3.push_back(gather_desc{S2.coff[p], S3.off.back(), cons_len2[p], 0u});
+                S3.off.push_back(S3.off.back() + cons_len2[p]);
+            }
+            S3.first.push_back((uint32_t)S3.off.size() - 1);
             multi_cid.push_back(c);
         }
-    }
-    std::vector<std::string> multi_cons(multi.size());
-    if (!multi.empty()) {
-        std::vector<const std::vector<hread> *> groups;
-        for (auto &g : multi) groups.push_back(&g);
-        RT_TRY(poa_stage(ctx, groups, msas, counters));
-        parallel_for(multi.size(), P->n_threads, [&](size_t i) {
-            fix_msa_ends(multi[i], msas[i]);
-            std::vector<colinfo> cols;
-            std::string cons;
-            column_vote(multi[i], msas[i], V, cols, cons);
-            multi_cons[i] = strip_gaps(cons);
-        });
+        if (!multi_cid.empty()) {
+            phase_timer T("correct: stage 3");
+            RT_TRY(run_stage(ctx, S3, desc3, S2.cons_out.p, nullptr, 2, P, order, counters));
+            cons_len3.assign(multi_cid.size(), 0);
+            cons3.resize(S3.cols + 1);
+            RT_HIP(hipMemcpyAsync(cons_len3.data(), S3.cons_len.p, multi_cid.size() * 4, hipMemcpyDeviceToHost, st));
+            if (S3.cols) RT_HIP(hipMemcpyAsync(cons3.data(), S3.cons_out.p, S3.cols, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+        }
+        S2.release(); S3.release();
+    } else {
+        fill_set(R->corrected, {}, {}, {});
     }
     std::vector<hread> consensi;
     std::vector<int32_t> con_cid, con_n;
     size_t mi = 0;
     for (uint32_t c = 0; c < n_clusters; ++c) {
-        if (cluster_packs[c].empty()) continue;
+        if (cl_np[c] == 0) continue;
         int total = 0;
-        for (size_t pi : cluster_packs[c]) total += (int)packs[pi].reads.size();
+        for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) total += (int)(S1.first[p + 1] - S1.first[p]);
         std::string s;
-        if (cluster_packs[c].size() > 1) s = multi_cons[mi++];
-        else s = packs[cluster_packs[c][0]].consensus;
+        if (cl_np[c] > 1) { s.assign((const char *)cons3.data() + S3.coff[mi], cons_len3[mi]); ++mi; }
+        else s.assign((const char *)cons2.data() + S2.coff[cl_p0[c]], cons_len2[cl_p0[c]]);
         consensi.push_back(hread{s, std::string(s.size(), 'K'), -1});
         con_cid.push_back((int32_t)c);
         con_n.push_back(total);
     }
-    phase_timer T_fill("correct: fill results");
-    fill_set(R->corrected, corrected, cor_cid, {});
     fill_set(R->uncorrected, uncorrected, unc_cid, {});
     fill_set(R->consensi, consensi, con_cid, con_n);
     memcpy(R->counters, counters, sizeof(counters));

@@ -941,17 +941,15 @@ static int max_blocks_per_cu(size_t shm) {
     return nb;
 }
 
-int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n_seqs, const uint32_t *pack_first,
-                uint32_t n_packs, rattle_msa_set **out) {
+// Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
+// plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
+int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_off_in, const uint64_t *off, uint32_t n_seqs,
+                   const uint32_t *pack_first, uint32_t n_packs, uint32_t *d_col_out, uint32_t *d_width_out, uint32_t *h_width_out,
+                   unsigned long long *h_cnt) {
     hipStream_t st = ctx->stream;
-    rattle_msa_set *R = (rattle_msa_set *)calloc(1, sizeof(rattle_msa_set));
-    R->n_packs = n_packs;
-    R->width = (uint32_t *)calloc(std::max<uint32_t>(n_packs, 1), sizeof(uint32_t));
-    R->row_offset = (uint64_t *)calloc((size_t)n_seqs + 1, sizeof(uint64_t));
-    *out = R;
-    if (n_packs == 0 || n_seqs == 0) { R->rows = (char *)calloc(1, 1); return 0; }
+    for (int i = 0; i < 16; ++i) h_cnt[i] = 0;
+    if (n_packs == 0 || n_seqs == 0) { for (uint32_t p = 0; p < n_packs; ++p) h_width_out[p] = 0; return 0; }
     if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
-    const uint64_t total = off[n_seqs];
 
     // columns-per-thread class of each pack (256 threads x CPL columns cover the longest sequence)
     static const uint32_t class_cpl[5] = {4, 6, 8, 16, 24};
@@ -966,19 +964,17 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         if (m > 256u * 24u) { set_error("sequence too long for the int16 POA kernel (> 6144 nt)"); return RATTLE_ERR_ARG; }
         by_class[m <= 1024 ? 0 : m <= 1536 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 3 : 4].push_back(p);
     }
-    if (total && memchr(seq, 0, total)) { set_error("NUL byte in sequence"); return RATTLE_ERR_ARG; }
 
-    dbuf<uint8_t> d_seq; dbuf<uint64_t> d_off; dbuf<uint32_t> d_pf, d_queue, d_head, d_col, d_width, d_status;
+    dbuf<uint32_t> d_pf, d_queue, d_status;
     dbuf<unsigned long long> d_cnt;
-    RT_TRY(d_seq.reserve(total + 64)); RT_TRY(d_off.reserve(n_seqs + 1)); RT_TRY(d_pf.reserve(n_packs + 1));
-    RT_TRY(d_queue.reserve(n_packs)); RT_TRY(d_head.reserve(1)); RT_TRY(d_col.reserve(total + 64));
-    RT_TRY(d_width.reserve(n_packs)); RT_TRY(d_status.reserve(n_packs)); RT_TRY(d_cnt.reserve(16));
-    RT_HIP(hipMemcpyAsync(d_seq.p, seq, total, hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemcpyAsync(d_off.p, off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    RT_TRY(d_pf.reserve(n_packs + 1)); RT_TRY(d_queue.reserve(n_packs)); RT_TRY(d_status.reserve(n_packs)); RT_TRY(d_cnt.reserve(16));
+    struct view { const uint8_t *p; } d_seq{d_seq_in};
+    struct viewo { const uint64_t *p; } d_off{d_off_in};
+    struct viewc { uint32_t *p; } d_col{d_col_out}, d_width{d_width_out};
     RT_HIP(hipMemcpyAsync(d_pf.p, pack_first, (n_packs + 1) * 4, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemsetAsync(d_cnt.p, 0, 128, st));
     RT_HIP(hipMemsetAsync(d_status.p, 0xFF, n_packs * 4, st));
-    std::vector<uint32_t> h_status(n_packs), h_width(n_packs);
+    std::vector<uint32_t> h_status(n_packs);
 
     size_t free_b = 0, total_b = 0;
     RT_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1123,20 +1119,52 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         for (int c = 0; c < 5; ++c) left += C[c].todo.size();
         if (left) { set_error("poa: " + std::to_string(left) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
-    unsigned long long h_cnt[16] = {0};
+    if (rc == 0) {
+        hipError_t e = hipMemcpyAsync(h_width_out, d_width.p, n_packs * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 128, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
+    }
+    d_pf.release(); d_queue.release(); d_status.release(); d_cnt.release();
+    if (rc) return rc;
+#ifdef POA_HIST
+    fprintf(stderr, "[rattle] pred distance: d1 %llu d2 %llu d3-4 %llu d5-8 %llu d9-16 %llu d17-64 %llu d>64 %llu | extra preds %llu\n", h_cnt[8], h_cnt[9],
+            h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
+#endif
+    ctx->stats[K_POA].bytes += 6ull * h_cnt[0];
+    return 0;
+}
+
+// Host-buffer entry (rattle_hip_poa_msa): upload, run, read the per-base columns back and expand rows.
+int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n_seqs, const uint32_t *pack_first,
+                uint32_t n_packs, rattle_msa_set **out) {
+    hipStream_t st = ctx->stream;
+    rattle_msa_set *R = (rattle_msa_set *)calloc(1, sizeof(rattle_msa_set));
+    R->n_packs = n_packs;
+    R->width = (uint32_t *)calloc(std::max<uint32_t>(n_packs, 1), sizeof(uint32_t));
+    R->row_offset = (uint64_t *)calloc((size_t)n_seqs + 1, sizeof(uint64_t));
+    *out = R;
+    if (n_packs == 0 || n_seqs == 0) { R->rows = (char *)calloc(1, 1); return 0; }
+    if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
+    const uint64_t total = off[n_seqs];
+    if (total && memchr(seq, 0, total)) { set_error("NUL byte in sequence"); return RATTLE_ERR_ARG; }
+    dbuf<uint8_t> d_seq; dbuf<uint64_t> d_off; dbuf<uint32_t> d_col, d_width;
+    RT_TRY(d_seq.reserve(total + 64)); RT_TRY(d_off.reserve(n_seqs + 1)); RT_TRY(d_col.reserve(total + 64)); RT_TRY(d_width.reserve(n_packs));
+    RT_HIP(hipMemcpyAsync(d_seq.p, seq, total, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(d_off.p, off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    std::vector<uint32_t> h_width(n_packs);
+    unsigned long long h_cnt[16];
+    int rc = poa_device_run(ctx, d_seq.p, d_off.p, off, n_seqs, pack_first, n_packs, d_col.p, d_width.p, h_width.data(), h_cnt);
     if (rc == 0) {
         phase_timer T_d2h("    poa readback");
         rc = ctx->h_poa_col.reserve(total);
         if (rc == 0) {
             hipError_t e = hipMemcpyAsync(ctx->h_poa_col.p, d_col.p, total * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_width.data(), d_width.p, n_packs * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 128, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
         }
     }
-    d_seq.release(); d_off.release(); d_pf.release(); d_queue.release(); d_head.release(); d_col.release();
-    d_width.release(); d_status.release(); d_cnt.release();
+    d_seq.release(); d_off.release(); d_col.release(); d_width.release();
     if (rc) return rc;
 
     // expand rows on the host (one task per pack): row = '-' * width with each base at its column
@@ -1160,11 +1188,6 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         }
     });
     for (int i = 0; i < 8; ++i) R->counters[i] = h_cnt[i];
-#ifdef POA_HIST
-    fprintf(stderr, "[rattle] pred distance: d1 %llu d2 %llu d3-4 %llu d5-8 %llu d9-16 %llu d17-64 %llu d>64 %llu | extra preds %llu\n", h_cnt[8], h_cnt[9],
-            h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
-#endif
-    ctx->stats[K_POA].bytes += 6ull * h_cnt[0];
     return 0;
 }
 
