@@ -119,8 +119,11 @@ struct stage {
     }
 };
 
+// where a run of gather descriptors reads from
+struct gather_part { uint32_t begin, count; const uint8_t *src_seq, *src_qual; };
+
 // gather the stage's sequences (descriptors built by the caller, dst offsets = st.off) and run POA + kernel D
-int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, const uint8_t *src_seq, const uint8_t *src_qual,
+int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, const std::vector<gather_part> &parts,
               int mode, const rattle_correct_params *P, const char *order, uint64_t *counters) {
     hipStream_t st = ctx->stream;
     const uint32_t n = S.n(), np = S.n_packs();
@@ -135,7 +138,8 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     if (n) RT_HIP(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n * sizeof(gather_desc), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(S.d_off.p, S.off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(S.d_first.p, S.first.data(), (size_t)(np + 1) * 4, hipMemcpyHostToDevice, st));
-    RT_TRY(launch_gather(ctx, d_desc.p, n, src_seq, mode == 1 ? src_qual : nullptr, S.seq.p, mode == 1 ? S.qual.p : nullptr));
+    for (const gather_part &g : parts)
+        RT_TRY(launch_gather(ctx, d_desc.p + g.begin, g.count, g.src_seq, mode == 1 ? g.src_qual : nullptr, S.seq.p, mode == 1 ? S.qual.p : nullptr));
     unsigned long long h_cnt[16];
     {
         phase_timer T("  stage: POA");
@@ -247,12 +251,10 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     for (size_t i = 0; i < small.size(); ++i) { uncorrected.push_back(oriented_read(seq, qual, off, small[i], 0, 0)); unc_cid.push_back(small_cid[i]); }
 
     std::vector<uint32_t> olen(n1 + 1, 0), tfront(n1 + 1, 0), tback(n1 + 1, 0);
-    std::vector<uint32_t> cons_len2(n_packs + 1, 0);
-    std::vector<uint8_t> cons2;                      // pack consensi, concatenated at S2.coff
-    stage S2, S3;
-    std::vector<uint32_t> multi_cid;
-    std::vector<uint32_t> cons_len3;
-    std::vector<uint8_t> cons3;
+    std::vector<uint32_t> cons_len2, cons_len3, pk_slot, cl_slot(n_clusters, 0);
+    std::vector<uint8_t> cons2, cons3;               // consensi of stage 2b+3a / 3b, concatenated at the stage's coff
+    std::vector<std::string> cl_cons(n_clusters);
+    stage S2a, S2, S3;
     if (n_packs) {
         // ---- reads -> HBM, oriented pack members gathered into stage 1 (:343-346)
         const uint64_t total_in = off[n_reads];
@@ -273,7 +275,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         // ---- POA #1 (correct.cpp:398-405) + fix ends + correction (:407-409)
         {
             phase_timer T("correct: stage 1");
-            RT_TRY(run_stage(ctx, S1, desc, d_rseq.p, d_rqual.p, 1, P, order, counters));
+            RT_TRY(run_stage(ctx, S1, desc, {gather_part{0, n1, d_rseq.p, d_rqual.p}}, 1, P, order, counters));
             RT_HIP(hipMemcpyAsync(olen.data(), S1.olen.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
             RT_HIP(hipMemcpyAsync(tfront.data(), S1.tfront.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
             RT_HIP(hipMemcpyAsync(tback.data(), S1.tback.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
@@ -325,67 +327,112 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q)
                 if (olen[q] == 0) { uncorrected.push_back(oriented_read(seq, qual, off, S1r[q], tfront[q], tback[q])); unc_cid.push_back(pk_cid[p]); }
 
-        // ---- POA #2 over the corrected reads, stably sorted by length desc (:427-445), + consensus vote
+        // ---- POA #2 over the corrected reads, stably sorted by length desc (:427-445), + consensus vote;
+        // per-cluster consensus (:489-556) with POA #3 for clusters of more than one pack.
+        // A POA #3 pack is sequential in its number of packs, so the clusters with many packs would
+        // leave the device to one workgroup each at the end.  When there are enough of them, their
+        // packs go through POA #2 first (stage 2a) and their POA #3 shares a pass with the POA #2 of
+        // everything else (stage 2b+3a); the remaining small POA #3 groups follow (stage 3b).
+        // (RATTLE_BIG_CLUSTER_PACKS / RATTLE_BIG_MIN_PACKS override the two thresholds: tests force the split on small inputs)
+        const uint32_t BIG = std::max(2, getenv("RATTLE_BIG_CLUSTER_PACKS") ? atoi(getenv("RATTLE_BIG_CLUSTER_PACKS")) : 48);
+        const uint64_t big_min = getenv("RATTLE_BIG_MIN_PACKS") ? (uint64_t)atoll(getenv("RATTLE_BIG_MIN_PACKS")) : 1024;
+        std::vector<uint8_t> big(n_clusters, 0);
         {
-            phase_timer T("correct: stage 2");
-            std::vector<gather_desc> desc2;
-            S2.first.assign(1, 0);
-            S2.off.assign(1, 0);
-            std::vector<uint32_t> rows;
-            for (uint32_t p = 0; p < n_packs; ++p) {
-                rows.clear();
-                for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q) if (olen[q]) rows.push_back(q);
-                std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return olen[a] > olen[b]; });
-                for (uint32_t q : rows) {
-                    desc2.push_back(gather_desc{S1.moff[p] + (uint64_t)(q - S1.first[p]) * S1.width[p], S2.off.back(), olen[q], 0u});
-                    S2.off.push_back(S2.off.back() + olen[q]);
+            uint64_t big_packs = 0;
+            for (uint32_t c = 0; c < n_clusters; ++c) if (cl_np[c] >= BIG) big_packs += cl_np[c];
+            if (big_packs >= big_min) for (uint32_t c = 0; c < n_clusters; ++c) big[c] = cl_np[c] >= BIG;
+        }
+        std::vector<uint32_t> rows;
+        auto add_pack2 = [&](stage &S, std::vector<gather_desc> &d, uint32_t p) {       // pack p's corrected reads, length-sorted
+            rows.clear();
+            for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q) if (olen[q]) rows.push_back(q);
+            std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return olen[a] > olen[b]; });
+            for (uint32_t q : rows) {
+                d.push_back(gather_desc{S1.moff[p] + (uint64_t)(q - S1.first[p]) * S1.width[p], S.off.back(), olen[q], 0u});
+                S.off.push_back(S.off.back() + olen[q]);
+            }
+            S.first.push_back((uint32_t)S.off.size() - 1);
+        };
+        pk_slot.assign(n_packs, 0);
+        // stage 2a: packs of the big clusters
+        std::vector<uint32_t> len2a;
+        {
+            std::vector<gather_desc> d;
+            S2a.first.assign(1, 0); S2a.off.assign(1, 0);
+            for (uint32_t p = 0; p < n_packs; ++p) if (big[pk_cid[p]]) { pk_slot[p] = S2a.n_packs(); add_pack2(S2a, d, p); }
+            if (S2a.n_packs()) {
+                phase_timer T("correct: stage 2a");
+                RT_TRY(run_stage(ctx, S2a, d, {gather_part{0, (uint32_t)d.size(), S1.rowc.p, nullptr}}, 2, P, order, counters));
+                len2a.assign(S2a.n_packs(), 0);
+                RT_HIP(hipMemcpyAsync(len2a.data(), S2a.cons_len.p, (size_t)S2a.n_packs() * 4, hipMemcpyDeviceToHost, st));
+                RT_HIP(hipStreamSynchronize(st));
+            }
+        }
+        // stage 2b+3a: POA #3 groups of the big clusters first, then the packs of all other clusters
+        {
+            phase_timer T("correct: stage 2b+3a");
+            std::vector<gather_desc> d;
+            S2.first.assign(1, 0); S2.off.assign(1, 0);
+            for (uint32_t c = 0; c < n_clusters; ++c) {
+                if (!big[c]) continue;
+                cl_slot[c] = S2.n_packs();
+                for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) {
+                    d.push_back(gather_desc{S2a.coff[pk_slot[p]], S2.off.back(), len2a[pk_slot[p]], 0u});
+                    S2.off.push_back(S2.off.back() + len2a[pk_slot[p]]);
                 }
                 S2.first.push_back((uint32_t)S2.off.size() - 1);
             }
-            RT_TRY(run_stage(ctx, S2, desc2, S1.rowc.p, nullptr, 2, P, order, counters));
+            const uint32_t n3a = (uint32_t)d.size();
+            for (uint32_t p = 0; p < n_packs; ++p) if (!big[pk_cid[p]]) { pk_slot[p] = S2.n_packs(); add_pack2(S2, d, p); }
+            RT_TRY(run_stage(ctx, S2, d, {gather_part{0, n3a, S2a.cons_out.p, nullptr}, gather_part{n3a, (uint32_t)d.size() - n3a, S1.rowc.p, nullptr}},
+                             2, P, order, counters));
+            cons_len2.assign(S2.n_packs() + 1, 0);
             cons2.resize(S2.cols + 1);
-            RT_HIP(hipMemcpyAsync(cons_len2.data(), S2.cons_len.p, (size_t)n_packs * 4, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipMemcpyAsync(cons_len2.data(), S2.cons_len.p, (size_t)S2.n_packs() * 4, hipMemcpyDeviceToHost, st));
             if (S2.cols) RT_HIP(hipMemcpyAsync(cons2.data(), S2.cons_out.p, S2.cols, hipMemcpyDeviceToHost, st));
             RT_HIP(hipStreamSynchronize(st));
         }
-        S1.release();
-
-        // ---- per-cluster consensus (:489-556); POA #3 for clusters with more than one pack
-        std::vector<gather_desc> desc3;
-        S3.first.assign(1, 0);
-        S3.off.assign(1, 0);
-        for (uint32_t c = 0; c < n_clusters; ++c) {
-            if (cl_np[c] <= 1) continue;
-            for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) {
-                desc3.push_back(gather_desc{S2.coff[p], S3.off.back(), cons_len2[p], 0u});
-                S3.off.push_back(S3.off.back() + cons_len2[p]);
+        S1.release(); S2a.release();
+        // stage 3b: POA #3 of the other clusters with more than one pack
+        {
+            std::vector<gather_desc> d;
+            S3.first.assign(1, 0); S3.off.assign(1, 0);
+            for (uint32_t c = 0; c < n_clusters; ++c) {
+                if (cl_np[c] <= 1 || big[c]) continue;
+                cl_slot[c] = S3.n_packs();
+                for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) {
+                    d.push_back(gather_desc{S2.coff[pk_slot[p]], S3.off.back(), cons_len2[pk_slot[p]], 0u});
+                    S3.off.push_back(S3.off.back() + cons_len2[pk_slot[p]]);
+                }
+                S3.first.push_back((uint32_t)S3.off.size() - 1);
             }
-            S3.first.push_back((uint32_t)S3.off.size() - 1);
-            multi_cid.push_back(c);
-        }
-        if (!multi_cid.empty()) {
-            phase_timer T("correct: stage 3");
-            RT_TRY(run_stage(ctx, S3, desc3, S2.cons_out.p, nullptr, 2, P, order, counters));
-            cons_len3.assign(multi_cid.size(), 0);
-            cons3.resize(S3.cols + 1);
-            RT_HIP(hipMemcpyAsync(cons_len3.data(), S3.cons_len.p, multi_cid.size() * 4, hipMemcpyDeviceToHost, st));
-            if (S3.cols) RT_HIP(hipMemcpyAsync(cons3.data(), S3.cons_out.p, S3.cols, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipStreamSynchronize(st));
+            if (S3.n_packs()) {
+                phase_timer T("correct: stage 3b");
+                RT_TRY(run_stage(ctx, S3, d, {gather_part{0, (uint32_t)d.size(), S2.cons_out.p, nullptr}}, 2, P, order, counters));
+                cons_len3.assign(S3.n_packs(), 0);
+                cons3.resize(S3.cols + 1);
+                RT_HIP(hipMemcpyAsync(cons_len3.data(), S3.cons_len.p, (size_t)S3.n_packs() * 4, hipMemcpyDeviceToHost, st));
+                if (S3.cols) RT_HIP(hipMemcpyAsync(cons3.data(), S3.cons_out.p, S3.cols, hipMemcpyDeviceToHost, st));
+                RT_HIP(hipStreamSynchronize(st));
+            }
         }
         S2.release(); S3.release();
+        for (uint32_t c = 0; c < n_clusters; ++c) {          // where each cluster's consensus ended up
+            if (cl_np[c] == 0) continue;
+            if (big[c]) cl_cons[c] = std::string((const char *)cons2.data() + S2.coff[cl_slot[c]], cons_len2[cl_slot[c]]);
+            else if (cl_np[c] > 1) cl_cons[c] = std::string((const char *)cons3.data() + S3.coff[cl_slot[c]], cons_len3[cl_slot[c]]);
+            else cl_cons[c] = std::string((const char *)cons2.data() + S2.coff[pk_slot[cl_p0[c]]], cons_len2[pk_slot[cl_p0[c]]]);
+        }
     } else {
         fill_set(R->corrected, {}, {}, {});
     }
     std::vector<hread> consensi;
     std::vector<int32_t> con_cid, con_n;
-    size_t mi = 0;
     for (uint32_t c = 0; c < n_clusters; ++c) {
         if (cl_np[c] == 0) continue;
         int total = 0;
         for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) total += (int)(S1.first[p + 1] - S1.first[p]);
-        std::string s;
-        if (cl_np[c] > 1) { s.assign((const char *)cons3.data() + S3.coff[mi], cons_len3[mi]); ++mi; }
-        else s.assign((const char *)cons2.data() + S2.coff[cl_p0[c]], cons_len2[cl_p0[c]]);
+        const std::string &s = cl_cons[c];
         consensi.push_back(hread{s, std::string(s.size(), 'K'), -1});
         con_cid.push_back((int32_t)c);
         con_n.push_back(total);

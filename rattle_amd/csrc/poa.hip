@@ -509,7 +509,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 }
 
 template <int CPL, int WIN, int RING>
-__global__ __launch_bounds__(256) void poa_kernel(poa_args A) {
+__global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
     __shared__ uint32_t s_bc[8];

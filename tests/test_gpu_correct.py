@@ -1,4 +1,4 @@
-"""Parity of the HIP `correct` path (pack builder + kernel C x3 + post-MSA host logic) with the
+"""Parity of the HIP `correct` path (pack builder + kernel C x3 + kernel D post-MSA logic) with the
 oracle and with the reference's shipped consensi fixture."""
 import gzip
 import os
@@ -28,6 +28,22 @@ def test_correct_synthetic_cdna_matches_oracle(gpu_ctx, oracle):
     assert got[1] == want[1], "uncorrected.fq differs"
     assert got[2] == want[2], "consensi.fq differs"
     assert int(got[3][0]) == int(want[3][0])           # DP cells, exact
+
+
+def test_correct_big_cluster_stage_split_matches_oracle(gpu_ctx, oracle, monkeypatch):
+    """Clusters with many packs take POA #2 first and share a pass with the others' POA #2 for their
+    POA #3 (correct_driver.hip); forced here on a small input (thresholds are read per call)."""
+    seqs, quals, _, _ = synth.reads(900, 12, 1, True, seed=12)
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    want = oracle.correct(headers, seqs, quals, hps.encode(clusters), split=25)
+    sizes = sorted(len(mem) for _, mem in clusters)
+    assert sizes[-1] > 75 and sizes[0] < 50                     # clusters with >= 3 packs and with < 3 packs exist
+    monkeypatch.setenv("RATTLE_BIG_CLUSTER_PACKS", "3")
+    monkeypatch.setenv("RATTLE_BIG_MIN_PACKS", "0")
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=25)
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    assert int(got[3][0]) == int(want[3][0])
 
 
 def test_correct_toyset_subset_matches_reference_fixture(gpu_ctx, toyset, toyset_clusters):
