@@ -171,14 +171,20 @@ __device__ __forceinline__ void st_refill(poa_ws &S) {
 // mode 1: rank[] receives the MSA column of each node (final pass);  mode 2: srank[] receives
 // the spoa rank (tie-break of best rows).  The DP itself runs in the incrementally maintained
 // block order (see merge_order), which is a topological order with aligned groups contiguous.
-__device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emit, uint32_t &n_cols) {
+// mode 3: the marks of everything emitted before root `root0` are preset by the caller (tie_labels);
+// the sort resumes at root0 and stops at the first emitted node whose DP row is in tied[0..n_tied):
+// that row is returned in n_cols.
+__device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emit, uint32_t &n_cols, uint32_t root0 = 0,
+                         const uint32_t *tied = nullptr, uint32_t n_tied = 0) {
     const uint32_t n = S.n_nodes;
-    for (uint32_t t = threadIdx.x; t < (n + 31) / 32; t += 64) { S.done[t] = 0; S.nocheck[t] = 0; }
-    wave_sync();
+    if (mode != 3) {
+        for (uint32_t t = threadIdx.x; t < (n + 31) / 32; t += 64) { S.done[t] = 0; S.nocheck[t] = 0; }
+        wave_sync();
+    }
     n_emit = 0; n_cols = 0;
     S.sp = 0; S.spilled = 0;
     const bool l0 = threadIdx.x == 0;
-    for (uint32_t root = 0; root < n && !S.err; ++root) {
+    for (uint32_t root = root0; root < n && !S.err; ++root) {
         if (bit_get(S.done, root)) continue;
         st_push(S, A, root);
         while (!S.err) {
@@ -220,7 +226,10 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
             if (!check) continue;
             for (uint32_t g = 0; g <= n_al; ++g) {   // v, then its aligned group in list order
                 const uint32_t u = g == 0 ? v : u4_get(al, g - 1);
-                if (l0) {
+                if (mode == 3) {
+                    const uint32_t row = (uint32_t)S.rank[u] + 1;
+                    for (uint32_t t = 0; t < n_tied; ++t) if (tied[t] == row) { n_cols = row; return; }
+                } else if (l0) {
                     if (mode == 1) S.rank[u] = (int32_t)n_cols;
                     else S.srank[u] = (int32_t)n_emit;
                 }
@@ -230,6 +239,60 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
         }
     }
     wave_sync();
+}
+
+// ---- which tied row does spoa's sort emit first, without sorting --------------------------------
+// Graph::topological_sort tries the node ids 0..n-1 as DFS roots; the DFS of a root emits every
+// node of its closure (predecessors, and with a node its whole aligned group) that is still
+// unmarked.  So node x is emitted during root label(x) = the smallest node id whose closure
+// contains x, the marks when root r starts are exactly {x : label(x) < r}, and of two nodes with
+// different labels the smaller label comes first.  One backward sweep over the rows (block order:
+// successors and group mates of a row all lie at or after its group) gives every label:
+// label(group) = min over its members, then every predecessor of a member takes min(own, label).
+// lab[] lives in the LDS ring (unused outside the DP), 16 bits per row; wave 0 runs the sweep,
+// lanes 0..3 updating the first four predecessors in parallel.
+// Sweeps rows hi_start, hi_start-1, ... and returns the first row it did NOT process: it stops below
+// lo_stop (at a group boundary) -- a label is final once the sweep has reached its row, so the
+// labels of the tied rows only need the rows above the lowest of them.
+__device__ uint32_t tie_labels(poa_ws &S, uint16_t *lab, uint32_t hi_start, uint32_t lo_stop) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t in_group = 0;
+    for (int32_t hi = (int32_t)hi_start; hi >= 1; hi -= 64) {
+        const int32_t r = hi - (int32_t)lane;
+        uint4 pl = make_uint4(0, 0, POA_NONE, 0), plb = make_uint4(0, 0, 0, 0);
+        if (r >= 1) { pl = S.plan[r - 1]; plb = S.planb[r - 1]; }
+        const uint32_t cnt = (uint32_t)min(64, hi);
+        for (uint32_t l = 0; l < cnt; ++l) {
+            const uint32_t row = (uint32_t)hi - l;
+            if (row < lo_stop && in_group == 0) return row;
+            const uint32_t info = __builtin_amdgcn_readlane(pl.x, l);
+            const uint32_t n_in = rd_nin(info), n_al = rd_nal(info);
+            if (in_group) --in_group;
+            else if (n_al) {                      // last row of a group: rows row-n_al .. row share the minimum
+                uint32_t m = 0xFFFFu;
+                for (uint32_t g = 0; g <= n_al; ++g) m = min(m, (uint32_t)lab[row - 1 - g]);
+                wave_sync();
+                if (lane <= n_al) lab[row - 1 - lane] = (uint16_t)m;
+                wave_sync();
+                in_group = n_al;
+            }
+            if (n_in == 0) continue;
+            const uint32_t my = lab[row - 1];
+            const uint32_t p = lane == 0 ? __builtin_amdgcn_readlane(plb.x, l) : lane == 1 ? __builtin_amdgcn_readlane(plb.y, l)
+                             : lane == 2 ? __builtin_amdgcn_readlane(plb.z, l) : __builtin_amdgcn_readlane(plb.w, l);
+            if (lane < 4 && lane < n_in && p) { if ((uint32_t)lab[p - 1] > my) lab[p - 1] = (uint16_t)my; }
+            if (n_in > 4) {
+                uint32_t e = __builtin_amdgcn_readlane(pl.z, l);
+                for (uint32_t k = 4; k < n_in; ++k) {
+                    const uint2 ed = S.edges[e]; e = ed.y;
+                    const uint32_t q = (uint32_t)S.rank[ed.x] + 1;
+                    if (lane == 0 && (uint32_t)lab[q - 1] > my) lab[q - 1] = (uint16_t)my;
+                }
+            }
+            wave_sync();
+        }
+    }
+    return 0;
 }
 
 // ---- DP over all rows of one alignment: 4 wavefronts per pack ---------------------------------
@@ -292,8 +355,9 @@ struct dp_xchg {                 // LDS, double-buffered by row parity
     uint32_t best_row[4];
 };
 
-template <int CPL, int WIN, int RING>
+template <int CPL, int WIN, int RING, int NW>
 __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
+    constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c0 = (uint32_t)tid * CPL;
     const bool act = c0 < Lp;
@@ -340,7 +404,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                     else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
                 }
 #ifdef POA_HIST
-                if (tid == 0 && n_in) { const uint32_t d = row - prow; atomicAdd(&S.hist[8 + (d == 1 ? 0 : d == 2 ? 1 : d <= 4 ? 2 : d <= 8 ? 3 : d <= 16 ? 4 : d <= 64 ? 5 : 6)], 1ull); if (k > 0) atomicAdd(&S.hist[15], 1ull); }
+                if (tid == 0 && n_in) { const uint32_t d = row - prow; atomicAdd(&S.hist[(k == 0 ? 16 : 80) + (d < 63 ? d : 63)], 1ull); }
 #endif
                 if (n_in == 0) {
 #pragma unroll
@@ -353,14 +417,16 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
 #pragma unroll
                     for (int t = 0; t < CPL; ++t) { hp[t] = h2[t]; fp[t] = f2[t]; }
                     hl = hl2;
-                } else if (RING > 0 && row - prow <= (uint32_t)RING) {
+                } else if (RING > 0 && row - prow <= (uint32_t)(RING + WIN)) {
+                    // rows that left the register window wait in the LDS ring: 16 bits per cell, H (< 2^14 in the
+                    // classes that use the ring) and min(H - F, 2) -- enough for max(H+g, F+e) since g - e = -2
                     const uint32_t slot = prow & (uint32_t)(RING - 1);
-                    const uint32_t *rp = S.ring + ((size_t)slot * 256 + tid) * CPL;
+                    const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
 #pragma unroll
                     for (int u = 0; u < CPL / 2; ++u) {
-                        const uint32_t a = rp[u], b = rp[CPL / 2 + u];
-                        hp[2 * u] = (int16_t)(a & 0xFFFF); hp[2 * u + 1] = (int16_t)(a >> 16);
-                        fp[2 * u] = (int16_t)(b & 0xFFFF); fp[2 * u + 1] = (int16_t)(b >> 16);
+                        const uint32_t a = rp[u];
+                        hp[2 * u] = (int32_t)(a & 0x3FFFu); hp[2 * u + 1] = (int32_t)((a >> 16) & 0x3FFFu);
+                        fp[2 * u] = hp[2 * u] - (int32_t)((a >> 14) & 3u); fp[2 * u + 1] = hp[2 * u + 1] - (int32_t)(a >> 30);
                     }
                     hl = S.lh_ring[slot * 4 + wave];
                 } else {
@@ -394,14 +460,16 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             }
             const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
             const int32_t texcl = wave_shr1(wincl, POA_NEG);
-            if (lane == 63) { X.T[par][wave] = wincl; X.Tp[par][wave] = max(texcl, ex[CPL - 1]); X.Hn[par][wave] = hn[CPL - 1]; }
-            row_barrier();
+            if (NW > 1) {
+                if (lane == 63) { X.T[par][wave] = wincl; X.Tp[par][wave] = max(texcl, ex[CPL - 1]); X.Hn[par][wave] = hn[CPL - 1]; }
+                row_barrier();
+            }
             int32_t base = POA_G - POA_E;        // u_0
             int32_t hl_new = 0;
-            if (wave > 0) {
+            if (NW > 1 && wave > 0) {
                 int32_t bp = POA_G - POA_E;
 #pragma unroll
-                for (int w = 0; w < 3; ++w) {
+                for (int w = 0; w < NW - 1; ++w) {
                     if (w < wave - 1) bp = max(bp, X.T[par][w]);
                     if (w < wave) base = max(base, X.T[par][w]);
                 }
@@ -420,14 +488,19 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                 if (c0 + t < L) lane_max = max(lane_max, hv[t]);
             }
             if (RING > 0) {
-                const uint32_t slot = row & (uint32_t)(RING - 1);
-                uint32_t *rp = S.ring + ((size_t)slot * 256 + tid) * CPL;
+                // the row leaving the register window goes to the ring
+                const uint32_t orow = WIN > 1 ? row2 : row1;
+                if (orow != 0xFFFFFFFFu) {
+                    const uint32_t slot = orow & (uint32_t)(RING - 1);
+                    uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
 #pragma unroll
-                for (int u = 0; u < CPL / 2; ++u) {
-                    rp[u] = (uint32_t)(uint16_t)(int16_t)hv[2 * u] | ((uint32_t)(uint16_t)(int16_t)hv[2 * u + 1] << 16);
-                    rp[CPL / 2 + u] = (uint32_t)(uint16_t)(int16_t)fr[2 * u] | ((uint32_t)(uint16_t)(int16_t)fr[2 * u + 1] << 16);
+                    for (int u = 0; u < CPL / 2; ++u) {
+                        const int32_t ha = WIN > 1 ? h2[2 * u] : h1[2 * u], hb = WIN > 1 ? h2[2 * u + 1] : h1[2 * u + 1];
+                        const int32_t fa = WIN > 1 ? f2[2 * u] : f1[2 * u], fb = WIN > 1 ? f2[2 * u + 1] : f1[2 * u + 1];
+                        rp[u] = (uint32_t)ha | ((uint32_t)min(ha - fa, 2) << 14) | ((uint32_t)hb << 16) | ((uint32_t)min(hb - fb, 2) << 30);
+                    }
+                    if (lane == 0) S.lh_ring[slot * 4 + wave] = WIN > 1 ? hl2 : hl1;
                 }
-                if (lane == 0) S.lh_ring[slot * 4 + wave] = hl_new;
             }
             if (act) {
                 store_block<CPL>(S.H + (uint64_t)row * Lp + c0, hv);
@@ -443,7 +516,10 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             for (int t = 0; t < CPL; ++t) { h1[t] = hv[t]; f1[t] = fr[t]; }
             hl1 = hl_new; row1 = row;
             const int32_t row_max = wave_last(wave_scan_max(lane_max, 0));
-            if (lane == 0) S.rowmax[row * 4 + wave] = row_max;
+            if (lane == 0) {                     // [row][4]: entries of absent waves are zero
+                if (NW == 1) *(int4 *)(S.rowmax + row * 4) = make_int4(row_max, 0, 0, 0);
+                else { S.rowmax[row * 4 + wave] = row_max; if (NW == 2 && wave == 0) *(int2 *)(S.rowmax + row * 4 + 2) = make_int2(0, 0); }
+            }
             if (row_max > my_best) { my_best = row_max; my_best_row = row; }
         }
     }
@@ -451,7 +527,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
     __syncthreads();
     best = 0; best_row = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const int32_t b = X.best[w];
         const uint32_t r = X.best_row[w];
         if (b > best || (b == best && b > 0 && r < best_row)) { best = b; best_row = r; }
@@ -508,11 +584,13 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
-template <int CPL, int WIN, int RING>
-__global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A) {
+template <int CPL, int WIN, int RING, int NW>
+__global__ __launch_bounds__(64 * NW, (CPL == 4 && NW == 4 ? 5 : 1)) void poa_kernel(poa_args A) {
+    constexpr uint32_t NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
     __shared__ uint32_t s_bc[8];
+    __shared__ uint32_t s_tied[8];
     __shared__ dp_xchg X;
     const int tid = threadIdx.x;
     const bool w0 = tid < 64;                 // wave 0 runs the serial graph phases
@@ -529,7 +607,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * 256 * CPL);
+        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * CPL / 2);
         S.topo = nullptr;
     }
 
@@ -542,8 +620,8 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
         const uint32_t pk = A.queue[qi];
         const uint32_t q0 = A.pack_first[pk], q1 = A.pack_first[pk + 1];
         S.n_nodes = 0; S.n_edges = 0; S.err = 0; S.sp = 0; S.spilled = 0;
-        unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0;
-        (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add;
+        unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0, t_tie = 0;
+        (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add; (void)t_tie;
 
         for (uint32_t q = q0; q < q1 && !S.err; ++q) {
             const uint64_t so = A.off[q];
@@ -555,11 +633,11 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
             if (S.n_nodes > 0) {
                 const uint32_t n = S.n_nodes;
                 const uint32_t Lp = (L + CPL - 1) / CPL * CPL;
-                if ((uint64_t)(n + 1) * Lp > A.cell_cap || Lp > 256u * CPL) { S.err = POA_ERR_CELLS; break; }
+                if ((uint64_t)(n + 1) * Lp > A.cell_cap || Lp > NT * CPL) { S.err = POA_ERR_CELLS; break; }
                 // ---- 1. rows are taken in the incrementally maintained block order (merge_order) ----
                 unsigned long long t0 = PT_NOW();
                 // ---- 2. plan + sequence to LDS (all threads) ----
-                for (uint32_t r = tid; r < n; r += 256) {
+                for (uint32_t r = tid; r < n; r += NT) {
                     const uint32_t v = S.order[r];
                     const uint4 rec = S.nrec[v];
                     const uint32_t n_in = rd_nin(rec.x);
@@ -573,13 +651,13 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                     S.plan[r] = make_uint4(rec.x, v, e, 0);
                     S.planb[r] = pr;
                 }
-                for (uint32_t t = tid; t < Lp; t += 256) S.sq[t] = t < L ? s[t] : 0;
+                for (uint32_t t = tid; t < Lp; t += NT) S.sq[t] = t < L ? s[t] : 0;
                 __syncthreads();
                 unsigned long long t1 = PT_NOW();
                 t_topo += t1 - t0;
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
-                dp_rows<CPL, WIN, RING>(S, X, n, L, Lp, best, best_row);
+                dp_rows<CPL, WIN, RING, NW>(S, X, n, L, Lp, best, best_row);
                 cells += (unsigned long long)n * L;
                 rows += n;
                 unsigned long long t2 = PT_NOW();
@@ -591,7 +669,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                     __syncthreads();
                     {
                         uint32_t cnt = 0;
-                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
                             const int4 m = *(const int4 *)(S.rowmax + r * 4);
                             cnt += max(max(m.x, m.y), max(m.z, m.w)) == best ? 1u : 0u;
                         }
@@ -605,7 +683,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                     if (need_sort) {
                         if (tid == 0) s_bc[5] = 0;
                         __syncthreads();
-                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
                             const int4 m = *(const int4 *)(S.rowmax + r * 4);
                             if (max(max(m.x, m.y), max(m.z, m.w)) != best || r == best_row) continue;
                             const uint4 pl = S.plan[r - 1], plb = S.planb[r - 1];
@@ -626,7 +704,61 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                         if (tid == 0) { atomicAdd(&A.counters[4], 1ull << 32); if (need_sort) atomicAdd(&A.counters[4], 1ull); }
 #endif
                     }
+                    if (need_sort && RING > 0 && n <= (uint32_t)RING * NT * CPL && S.n_nodes <= 0xFFFFu) {
+                        // labels instead of the full sort (tie_labels)
+                        uint16_t *lab = (uint16_t *)S.ring;
+                        for (uint32_t r = tid; r < n; r += NT) lab[r] = (uint16_t)S.order[r];
+                        if (tid == 0) { s_bc[7] = 0xFFFFFFFFu; s_bc[5] = 0; s_bc[6] = 0xFFFFFFFFu; }
+                        __syncthreads();
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
+                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
+                            if (max(max(m.x, m.y), max(m.z, m.w)) == best) atomicMin(&s_bc[6], r);
+                        }
+                        __syncthreads();
+                        if (w0) { const uint32_t next = tie_labels(S, lab, n, s_bc[6]); if (tid == 0) s_bc[6] = next; }
+                        __syncthreads();
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
+                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
+                            if (max(max(m.x, m.y), max(m.z, m.w)) == best) atomicMin(&s_bc[7], (uint32_t)lab[r - 1]);
+                        }
+                        __syncthreads();
+                        const uint32_t root = s_bc[7];
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
+                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
+                            if (max(max(m.x, m.y), max(m.z, m.w)) == best && (uint32_t)lab[r - 1] == root) {
+                                const uint32_t slot = atomicAdd(&s_bc[5], 1u);
+                                if (slot < 8) s_tied[slot] = r;
+                            }
+                        }
+                        __syncthreads();
+                        const uint32_t n_tied = s_bc[5];
+                        __syncthreads();
+                        if (n_tied == 1) { best_row = s_tied[0]; need_sort = false; }
+                        else if (n_tied <= 8) {
+                            // several tied rows inside one root's DFS: finish the labels, replay only that DFS
+                            for (uint32_t t = tid; t < (S.n_nodes + 31) / 32; t += NT) { S.done[t] = 0; S.nocheck[t] = 0; }
+                            if (w0 && s_bc[6] >= 1) tie_labels(S, lab, s_bc[6], 0);
+                            __syncthreads();
+                            for (uint32_t r = tid; r < n; r += NT)
+                                if ((uint32_t)lab[r] < root) { const uint32_t u = S.order[r]; atomicOr(&S.done[u >> 5], 1u << (u & 31)); }
+                            __syncthreads();
+                            if (w0) {
+                                uint32_t n_emit, hit = 0;
+                                toposort(S, A, 3, n_emit, hit, root, s_tied, n_tied);
+                                if (!S.err && hit == 0) S.err = POA_ERR_GRAPH;
+                                if (tid == 0) { s_bc[4] = S.err; s_bc[7] = hit; }
+                            }
+                            __syncthreads();
+                            S.err = s_bc[4];
+                            if (S.err) break;
+                            best_row = s_bc[7];
+                            need_sort = false;
+                            __syncthreads();
+                        }
+                    }
                     if (need_sort) {
+                        if (tid == 0) s_bc[7] = 0xFFFFFFFFu;
+                        __syncthreads();
                         if (w0) {
                             uint32_t n_emit, n_cols;
                             toposort(S, A, 2, n_emit, n_cols);
@@ -636,14 +768,14 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                         __syncthreads();
                         S.err = s_bc[4];
                         if (S.err) break;
-                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
                             const int4 m = *(const int4 *)(S.rowmax + r * 4);
                             if (max(max(m.x, m.y), max(m.z, m.w)) == best) atomicMin(&s_bc[7], (uint32_t)S.srank[S.order[r - 1]]);
                         }
                         __syncthreads();
                         const uint32_t want = s_bc[7];
                         __syncthreads();
-                        for (uint32_t r = 1 + tid; r <= n; r += 256) {
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
                             const int4 m = *(const int4 *)(S.rowmax + r * 4);
                             if (max(max(m.x, m.y), max(m.z, m.w)) == best && (uint32_t)S.srank[S.order[r - 1]] == want) s_bc[7] = r;
                         }
@@ -651,10 +783,13 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                         best_row = s_bc[7];
                     }
                     // ---- 4. best cell + traceback ----
+#ifdef POA_PROFILE
+                    t_tie += PT_NOW() - t2;
+#endif
                     const int16_t *Hb = S.H + (uint64_t)best_row * Lp;
                     if (tid == 0) s_bc[5] = 0xFFFFFFFFu;
                     __syncthreads();
-                    for (uint32_t c = tid; c < L; c += 256) if ((int32_t)Hb[c] == best) { atomicMin(&s_bc[5], c + 1); break; }
+                    for (uint32_t c = tid; c < L; c += NT) if ((int32_t)Hb[c] == best) { atomicMin(&s_bc[5], c + 1); break; }
                     __syncthreads();
                     const uint32_t bj = s_bc[5];
                     if (tid == 0) {
@@ -667,24 +802,42 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                             if (cnt >= A.aln_cap) { err = POA_ERR_ALN; return; }
                             S.aln[2 * cnt] = node; S.aln[2 * cnt + 1] = pos; ++cnt;
                         };
-                        while (!err && Hat(i, j) != 0) {
-                            const int32_t Hij = Hat(i, j);
-                            bool found = false, ext_left = false, ext_up = false;
+                        // One dependent memory round trip per step in the common case: the H cells of the
+                        // first four predecessors at column j-1 are fetched together, along with the plan
+                        // records of the first predecessor (the usual next row); H(i,j) and the plan of row i
+                        // are carried from the previous step.  Order of the tests as in spoa: diagonal
+                        // (in-edge order), vertical (F extension before opening), horizontal.
+                        int32_t Hij = best;
+                        uint4 pl = S.plan[i - 1], plb = S.planb[i - 1];
+                        while (!err && Hij != 0) {                      // H != 0 implies i != 0 and j != 0
+                            bool found = false, ext_left = false, ext_up = false, have_next = false;
                             uint32_t pi = 0, pj = 0;
-                            uint4 pl = make_uint4(0, 0, POA_NONE, 0), plb = make_uint4(0, 0, 0, 0);
-                            if (i != 0) { pl = S.plan[i - 1]; plb = S.planb[i - 1]; }
+                            int32_t Hn = 0;
+                            uint4 npl = make_uint4(0, 0, POA_NONE, 0), nplb = make_uint4(0, 0, 0, 0);
                             const uint32_t n_in = rd_nin(pl.x);
                             const uint32_t npred = n_in ? n_in : 1u;
-                            if (i != 0 && j != 0) {
-                                const int32_t mc = rd_letter(pl.x) == s[j - 1] ? POA_M : POA_N;
-                                uint32_t e = pl.z;
-                                for (uint32_t k = 0; k < npred; ++k) {
-                                    uint32_t p = 0;
-                                    if (n_in) { if (k < 4) p = u4_get(plb, k); else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; } }
-                                    if (Hij == Hat(p, j - 1) + mc) { pi = p; pj = j - 1; found = true; break; }
+                            {
+                                const int32_t mc = rd_letter(pl.x) == S.sq[j - 1] ? POA_M : POA_N;
+                                const uint32_t q0 = n_in ? plb.x : 0u, q1 = npred > 1 ? plb.y : q0, q2 = npred > 2 ? plb.z : q0, q3 = npred > 3 ? plb.w : q0;
+                                const int32_t c0 = Hat(q0, j - 1), c1 = Hat(q1, j - 1), c2 = Hat(q2, j - 1), c3 = Hat(q3, j - 1);
+                                if (q0) { npl = S.plan[q0 - 1]; nplb = S.planb[q0 - 1]; }
+                                if (Hij == c0 + mc) { pi = q0; Hn = c0; found = true; have_next = q0 != 0; }
+                                else if (npred > 1 && Hij == c1 + mc) { pi = q1; Hn = c1; found = true; }
+                                else if (npred > 2 && Hij == c2 + mc) { pi = q2; Hn = c2; found = true; }
+                                else if (npred > 3 && Hij == c3 + mc) { pi = q3; Hn = c3; found = true; }
+                                else if (npred > 4) {
+                                    uint32_t e = pl.z;
+                                    for (uint32_t k = 4; k < npred; ++k) {
+                                        const uint2 ed = S.edges[e]; e = ed.y;
+                                        const uint32_t p = (uint32_t)S.rank[ed.x] + 1;
+                                        const int32_t c = Hat(p, j - 1);
+                                        if (Hij == c + mc) { pi = p; Hn = c; found = true; break; }
+                                    }
                                 }
+                                if (found) pj = j - 1;
                             }
-                            if (!found && i != 0) {
+                            const bool diag = found;
+                            if (!found) {
                                 uint32_t e = pl.z;
                                 for (uint32_t k = 0; k < npred; ++k) {
                                     uint32_t p = 0;
@@ -692,11 +845,12 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                                     if ((ext_up = (Hij == Fat(p, j) + POA_E)) || Hij == Hat(p, j) + POA_G) { pi = p; pj = j; found = true; break; }
                                 }
                             }
-                            if (!found && j != 0) {
+                            if (!found) {
                                 if ((ext_left = (Hij == Eat(i, j - 1) + POA_E)) || Hij == Hat(i, j - 1) + POA_G) { pi = i; pj = j - 1; found = true; }
                             }
                             if (!found) { err = POA_ERR_GRAPH; break; }
                             put(i == pi ? -1 : (int32_t)pl.y, j == pj ? -1 : (int32_t)(j - 1));
+                            const uint32_t oi = i;
                             i = pi; j = pj;
                             if (ext_left) {
                                 while (!err) {
@@ -722,6 +876,12 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                                     if (stop || i == 0) break;
                                 }
                             }
+                            // state of the next step
+                            if (diag) Hij = Hn; else Hij = Hat(i, j);
+                            if (i != oi && i != 0) {
+                                if (diag && have_next) { pl = npl; plb = nplb; }
+                                else { pl = S.plan[i - 1]; plb = S.planb[i - 1]; }
+                            }
                         }
                         s_bc[0] = cnt; s_bc[1] = err;
                     }
@@ -742,7 +902,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
             unsigned long long t3 = PT_NOW();
             const uint32_t n_old = S.n_nodes;
             enum { K_SKIP = 0, K_INS = 1, K_SAME = 2, K_SIB = 3, K_NEW = 4 };
-            for (uint32_t f = tid; f < n_aln; f += 256) {
+            for (uint32_t f = tid; f < n_aln; f += NT) {
                 const int32_t an = S.aln[2 * (n_aln - 1 - f)], pos = S.aln[2 * (n_aln - 1 - f) + 1];
                 uint4 inf = make_uint4(K_SKIP, 0, 0, 0);
                 if (pos != -1) {
@@ -859,7 +1019,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
             S.n_nodes = s_bc[2]; S.err = s_bc[4];
             if (!S.err) {
                 const uint32_t e_lo = s_bc[5], e_hi = s_bc[6];
-                for (uint32_t p = e_lo + tid; p <= e_hi && e_lo <= e_hi; p += 256) g_add_edge(S, A, path[p - 1], path[p], &s_bc[3], &s_bc[4]);
+                for (uint32_t p = e_lo + tid; p <= e_hi && e_lo <= e_hi; p += NT) g_add_edge(S, A, path[p - 1], path[p], &s_bc[3], &s_bc[4]);
             }
             __syncthreads();
             S.n_edges = s_bc[3]; S.err = s_bc[4];
@@ -869,20 +1029,20 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
                 const uint32_t T = S.n_nodes - n_old;
                 if (T > 0) {
                     const uint32_t first = S.nn[1];
-                    for (uint32_t r = first + tid; r < n_old; r += 256) {
+                    for (uint32_t r = first + tid; r < n_old; r += NT) {
                         uint32_t lo = 0, hi = T;                     // number of anchors <= r
                         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S.nn[2 * mid + 1] <= r) lo = mid + 1; else hi = mid; }
                         const uint32_t v = S.order[r];
                         S.order2[r + lo] = v;
                         S.rank[v] = (int32_t)(r + lo);
                     }
-                    for (uint32_t t = tid; t < T; t += 256) {
+                    for (uint32_t t = tid; t < T; t += NT) {
                         const uint32_t v = S.nn[2 * t], pos = S.nn[2 * t + 1] + t;
                         S.order2[pos] = v;
                         S.rank[v] = (int32_t)pos;
                     }
                     __syncthreads();
-                    for (uint32_t r = first + tid; r < n_old + T; r += 256) S.order[r] = S.order2[r];
+                    for (uint32_t r = first + tid; r < n_old + T; r += NT) S.order[r] = S.order2[r];
                     __syncthreads();
                 }
             }
@@ -904,7 +1064,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
             S.err = s_bc[4];
             if (!S.err) {
                 const uint64_t b0 = A.off[q0], b1 = A.off[q1];
-                for (uint64_t b = b0 + tid; b < b1; b += 256) A.out_col[b] = (uint32_t)S.rank[A.out_col[b]];
+                for (uint64_t b = b0 + tid; b < b1; b += NT) A.out_col[b] = (uint32_t)S.rank[A.out_col[b]];
             }
         }
         const uint32_t width = s_bc[6];
@@ -913,7 +1073,11 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
             A.status[pk] = S.err;
             atomicAdd(&A.counters[0], cells);
             atomicAdd(&A.counters[1], (unsigned long long)(q1 - q0));
+#ifdef POA_PROFILE
+            atomicAdd(&A.counters[2], t_tie);          // tie resolution (part of counters[6])
+#else
             atomicAdd(&A.counters[2], (unsigned long long)S.n_nodes);
+#endif
             atomicAdd(&A.counters[3], rows);
 #ifdef POA_PROFILE
             (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add;                              // counters[4]: ties << 32 | ties that needed the exact sort
@@ -926,20 +1090,34 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 5 : 1)) void poa_kernel(poa_args A
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-template <int CPL, int WIN, int RING>
+template <int CPL, int WIN, int RING, int NW>
 static hipError_t launch_poa(const poa_args &A, uint32_t n_slots, size_t shm, hipStream_t st) {
     if (shm > 60 * 1024)
-        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, WIN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((poa_kernel<CPL, WIN, RING>), dim3(n_slots), dim3(256), shm, st, A);
+        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, WIN, RING, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL((poa_kernel<CPL, WIN, RING, NW>), dim3(n_slots), dim3(64 * NW), shm, st, A);
     return hipGetLastError();
 }
 
-template <int CPL, int WIN, int RING>
+template <int CPL, int WIN, int RING, int NW>
 static int max_blocks_per_cu(size_t shm) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, WIN, RING>, 256, shm) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, WIN, RING, NW>, 64 * NW, shm) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
+
+// Kernel variants.  A pack is one workgroup of NW wavefronts, each thread owning CPL columns, so a
+// variant covers sequences up to 64*NW*CPL nt.  Four waves per pack minimise the time of one pack
+// (small inputs: fewer packs than the device has room for); one or two waves per pack need no (or a
+// cheaper) per-row rendezvous and leave room for more packs per CU (large inputs: throughput).
+struct poa_variant {
+    uint32_t cpl, ring, nw;
+    hipError_t (*launch)(const poa_args &, uint32_t, size_t, hipStream_t);
+    int (*max_blocks)(size_t);
+};
+#define POA_VARIANT(CPL, WIN, RING, NW) {CPL, RING, NW, &launch_poa<CPL, WIN, RING, NW>, &max_blocks_per_cu<CPL, WIN, RING, NW>}
+static const poa_variant k_latency[5] = {POA_VARIANT(4, 2, 8, 4), POA_VARIANT(6, 2, 8, 4), POA_VARIANT(8, 2, 8, 4), POA_VARIANT(16, 1, 0, 4),
+                                         POA_VARIANT(24, 1, 0, 4)};
+static const poa_variant k_throughput[3] = {POA_VARIANT(16, 1, 8, 1), POA_VARIANT(12, 1, 8, 2), POA_VARIANT(16, 1, 8, 2)};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -951,8 +1129,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     if (n_packs == 0 || n_seqs == 0) { for (uint32_t p = 0; p < n_packs; ++p) h_width_out[p] = 0; return 0; }
     if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
 
-    // columns-per-thread class of each pack (256 threads x CPL columns cover the longest sequence)
-    static const uint32_t class_cpl[5] = {4, 6, 8, 16, 24};
+    // length class of each pack: 1024 / 1536 / 2048 / 4096 / 6144 columns
     std::vector<uint64_t> pbases(n_packs);
     std::vector<uint32_t> pmaxL(n_packs);
     std::vector<uint32_t> by_class[5];
@@ -967,14 +1144,17 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
 
     dbuf<uint32_t> d_pf, d_queue, d_status;
     dbuf<unsigned long long> d_cnt;
-    RT_TRY(d_pf.reserve(n_packs + 1)); RT_TRY(d_queue.reserve(n_packs)); RT_TRY(d_status.reserve(n_packs)); RT_TRY(d_cnt.reserve(16));
+    RT_TRY(d_pf.reserve(n_packs + 1)); RT_TRY(d_queue.reserve(n_packs)); RT_TRY(d_status.reserve(n_packs)); RT_TRY(d_cnt.reserve(160));
     struct view { const uint8_t *p; } d_seq{d_seq_in};
     struct viewo { const uint64_t *p; } d_off{d_off_in};
     struct viewc { uint32_t *p; } d_col{d_col_out}, d_width{d_width_out};
     RT_HIP(hipMemcpyAsync(d_pf.p, pack_first, (n_packs + 1) * 4, hipMemcpyHostToDevice, st));
-    RT_HIP(hipMemsetAsync(d_cnt.p, 0, 128, st));
+    RT_HIP(hipMemsetAsync(d_cnt.p, 0, 160 * 8, st));
     RT_HIP(hipMemsetAsync(d_status.p, 0xFF, n_packs * 4, st));
     std::vector<uint32_t> h_status(n_packs);
+#ifdef POA_HIST
+    unsigned long long h_hist[160] = {0};
+#endif
 
     size_t free_b = 0, total_b = 0;
     RT_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1001,8 +1181,15 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         size_t shm = 0;
         uint32_t n_slots = 0;
         int bpc = 1;
+        const poa_variant *V = nullptr;
     } C[5];
-    for (int c = 0; c < 5; ++c) C[c].todo = by_class[c];
+    // RATTLE_POA_WAVES=1|4 forces the throughput / latency variants (default: by the number of packs)
+    const int force_waves = getenv("RATTLE_POA_WAVES") ? atoi(getenv("RATTLE_POA_WAVES")) : 0;
+    for (int c = 0; c < 5; ++c) {
+        C[c].todo = by_class[c];
+        C[c].V = &k_latency[c];
+        if (c < 3 && (force_waves == 1 || (force_waves == 0 && by_class[c].size() >= 4u * n_cu))) C[c].V = &k_throughput[c];
+    }
     // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas.
     // The column classes of one round run concurrently on their own streams.
     for (int round = 0; round < 6 && rc == 0; ++round) {
@@ -1013,7 +1200,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             P.n_slots = 0;
             if (P.todo.empty()) continue;
             any = true;
-            const uint32_t cpl = class_cpl[c];
+            const uint32_t cpl = P.V->cpl;
             std::sort(P.todo.begin(), P.todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
             uint64_t tb = 0; uint32_t tl = 0;
             for (uint32_t p : P.todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
@@ -1037,10 +1224,8 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
             // LDS ring of the last RING rows (packed H|F, thread-private): 8 rows cost a block per CU and
             // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.
-            static const uint32_t class_ring[5] = {4, 4, 4, 0, 0};
-            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)class_ring[c] * 256 * cpl * 4 + 8 * 4 * 4;
-            P.bpc = c == 0 ? max_blocks_per_cu<4, 2, 4>(P.shm) : c == 1 ? max_blocks_per_cu<6, 2, 4>(P.shm)
-                  : c == 2 ? max_blocks_per_cu<8, 2, 4>(P.shm) : c == 3 ? max_blocks_per_cu<16, 1, 0>(P.shm) : max_blocks_per_cu<24, 1, 0>(P.shm);
+            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)P.V->ring * 64 * P.V->nw * cpl * 2 + 8 * 4 * 4;
+            P.bpc = P.V->max_blocks(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
             A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
             want_bytes += P.per_slot * P.n_slots;
@@ -1076,8 +1261,8 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             aoff += P.per_slot * P.n_slots;
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
-                fprintf(stderr, "[rattle]     poa class %u round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n", class_cpl[c], round,
-                        P.todo.size(), P.n_slots, P.per_slot / 1e6, P.bpc);
+                fprintf(stderr, "[rattle]     poa class %u cols (%u waves x %u) round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
+                        64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, round, P.todo.size(), P.n_slots, P.per_slot / 1e6, P.bpc);
         }
         if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
         {
@@ -1089,9 +1274,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 hipStream_t cs = ctx->poa_st[c];
                 e = hipStreamWaitEvent(cs, ctx->poa_go, 0);
                 if (e != hipSuccess) break;
-                e = c == 0 ? launch_poa<4, 2, 4>(P.A, P.n_slots, P.shm, cs) : c == 1 ? launch_poa<6, 2, 4>(P.A, P.n_slots, P.shm, cs)
-                  : c == 2 ? launch_poa<8, 2, 4>(P.A, P.n_slots, P.shm, cs) : c == 3 ? launch_poa<16, 1, 0>(P.A, P.n_slots, P.shm, cs)
-                                                                             : launch_poa<24, 1, 0>(P.A, P.n_slots, P.shm, cs);
+                e = P.V->launch(P.A, P.n_slots, P.shm, cs);
                 if (e == hipSuccess) e = hipEventRecord(ctx->poa_ev[c], cs);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[c], 0);
             }
@@ -1122,14 +1305,17 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     if (rc == 0) {
         hipError_t e = hipMemcpyAsync(h_width_out, d_width.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 128, hipMemcpyDeviceToHost, st);
+#ifdef POA_HIST
+        if (e == hipSuccess) e = hipMemcpyAsync(h_hist, d_cnt.p, 160 * 8, hipMemcpyDeviceToHost, st);
+#endif
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
     }
     d_pf.release(); d_queue.release(); d_status.release(); d_cnt.release();
     if (rc) return rc;
 #ifdef POA_HIST
-    fprintf(stderr, "[rattle] pred distance: d1 %llu d2 %llu d3-4 %llu d5-8 %llu d9-16 %llu d17-64 %llu d>64 %llu | extra preds %llu\n", h_cnt[8], h_cnt[9],
-            h_cnt[10], h_cnt[11], h_cnt[12], h_cnt[13], h_cnt[14], h_cnt[15]);
+    fprintf(stderr, "[rattle] predecessor row distance histogram (first in-edge | further in-edges), d = 1..62, 63+:\n");
+    for (int d = 1; d < 64; ++d) fprintf(stderr, "  d%-2d %12llu %12llu\n", d, h_hist[16 + d], h_hist[80 + d]);
 #endif
     ctx->stats[K_POA].bytes += 6ull * h_cnt[0];
     return 0;
