@@ -348,9 +348,8 @@ __device__ __forceinline__ void store_block(int16_t *__restrict__ p, const int32
 }
 
 struct dp_xchg {                 // LDS, double-buffered by row parity
-    int32_t T[2][4];             // wave-inclusive max of u
-    int32_t Tp[2][4];            // same without the wave's last column
-    int32_t Hn[2][4];            // Hn of the wave's last column
+    int4 T[2];                   // per wave: inclusive max of u
+    int2 Q[2][4];                // for wave w: {max of u of wave w-1 without its last column, Hn of that column}
     int32_t best[4];
     uint32_t best_row[4];
 };
@@ -358,7 +357,7 @@ struct dp_xchg {                 // LDS, double-buffered by row parity
 template <int CPL, int WIN, int RING, int NW>
 __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
     constexpr int NT = 64 * NW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t c0 = (uint32_t)tid * CPL;
     const bool act = c0 < Lp;
     uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
@@ -460,22 +459,25 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             }
             const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
             const int32_t texcl = wave_shr1(wincl, POA_NEG);
-            if (NW > 1) {
-                if (lane == 63) { X.T[par][wave] = wincl; X.Tp[par][wave] = max(texcl, ex[CPL - 1]); X.Hn[par][wave] = hn[CPL - 1]; }
-                row_barrier();
-            }
             int32_t base = POA_G - POA_E;        // u_0
             int32_t hl_new = 0;
-            if (NW > 1 && wave > 0) {
-                int32_t bp = POA_G - POA_E;
-#pragma unroll
-                for (int w = 0; w < NW - 1; ++w) {
-                    if (w < wave - 1) bp = max(bp, X.T[par][w]);
-                    if (w < wave) base = max(base, X.T[par][w]);
+            if (NW > 1) {
+                if (lane == 63) {
+                    ((int32_t *)&X.T[par])[wave] = wincl;
+                    if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex[CPL - 1]), hn[CPL - 1]);
                 }
-                const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);            // 1-based index of the column left of the wave
-                hl_new = max(X.Hn[par][wave - 1], max(bp, X.Tp[par][wave - 1]) + c0w * POA_E);
-                if (lane == 0) S.lh[row * 4 + wave] = hl_new;
+                row_barrier();
+                const int4 T = X.T[par];         // both reads are in flight together; selects are scalar (wave is uniform)
+                const int2 q = X.Q[par][wave];
+                const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
+                const int32_t b0 = wave > 1 ? T.x : POA_NEG, b1 = wave > 2 ? T.y : POA_NEG;
+                base = max(max(base, t0), max(t1, t2));
+                if (wave > 0) {
+                    const int32_t bp = max(max(POA_G - POA_E, b0), b1);
+                    const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);        // 1-based index of the column left of the wave
+                    hl_new = max(q.y, max(bp, q.x) + c0w * POA_E);
+                    if (lane == 0) S.lh[row * 4 + wave] = hl_new;
+                }
             }
             base = max(base, texcl);
             int32_t hv[CPL], ev[CPL];
@@ -585,7 +587,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 }
 
 template <int CPL, int WIN, int RING, int NW>
-__global__ __launch_bounds__(64 * NW, (CPL == 4 && NW == 4 ? 5 : 1)) void poa_kernel(poa_args A) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL == 6 ? 4 : 1)) void poa_kernel(poa_args A) {
     constexpr uint32_t NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
