@@ -904,6 +904,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
             unsigned long long t3 = PT_NOW();
             const uint32_t n_old = S.n_nodes;
             enum { K_SKIP = 0, K_INS = 1, K_SAME = 2, K_SIB = 3, K_NEW = 4 };
+            // the kind of every pair also goes to LDS (bitmap / stack area, idle here) so that the sequential
+            // pass below touches global memory only for the pairs that create nodes
+            uint8_t *kind = (uint8_t *)S.done;
+            const bool use_kind = n_aln <= (((A.node_cap + 31) / 32) * 2 + POA_STACK) * 4;
             for (uint32_t f = tid; f < n_aln; f += NT) {
                 const int32_t an = S.aln[2 * (n_aln - 1 - f)], pos = S.aln[2 * (n_aln - 1 - f) + 1];
                 uint4 inf = make_uint4(K_SKIP, 0, 0, 0);
@@ -928,9 +932,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                         else if (hit != -1) { inf.x = K_SIB; inf.y = (uint32_t)hit; }
                         else { inf.x = K_NEW; inf.y = (uint32_t)an; }
                         inf.z = gs; inf.w = ge + 1;
+                        if (inf.x != K_NEW) path[pos] = inf.y;         // a reused node: nothing else to do for this position
                     }
                 }
                 S.ainfo[f] = inf;
+                if (use_kind) kind[f] = (uint8_t)inf.x;
             }
             __syncthreads();
             if (tid == 0) {
@@ -953,6 +959,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                     const uint32_t sufn = S.n_nodes - suf0;
                     uint32_t pb0 = 0, pbn = 0;                              // pending: current insertion run
                     for (uint32_t f = 0; f < n_aln && !S.err; ++f) {
+                        if (use_kind) {
+                            const uint32_t k = kind[f];
+                            if (k == K_SKIP) continue;
+                            if ((k == K_SAME || k == K_SIB) && pan + pbn == 0) continue;
+                        }
                         const uint4 inf = S.ainfo[f];
                         if (inf.x == K_SKIP) continue;
                         const int32_t pos = S.aln[2 * (n_aln - 1 - f) + 1];
@@ -1185,12 +1196,13 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         int bpc = 1;
         const poa_variant *V = nullptr;
     } C[5];
-    // RATTLE_POA_WAVES=1|4 forces the throughput / latency variants (default: by the number of packs)
+    // RATTLE_POA_WAVES=1 selects the one/two-wave variants (measured slower than four waves per pack even
+    // with thousands of packs in flight: 353 vs 401 GCUPS at 1 kb, 395 vs 429 at 1.4 kb; kept for experiments)
     const int force_waves = getenv("RATTLE_POA_WAVES") ? atoi(getenv("RATTLE_POA_WAVES")) : 0;
     for (int c = 0; c < 5; ++c) {
         C[c].todo = by_class[c];
         C[c].V = &k_latency[c];
-        if (c < 3 && (force_waves == 1 || (force_waves == 0 && by_class[c].size() >= 4u * n_cu))) C[c].V = &k_throughput[c];
+        if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
     }
     // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas.
     // The column classes of one round run concurrently on their own streams.
