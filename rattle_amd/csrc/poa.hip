@@ -295,19 +295,30 @@ __device__ uint32_t tie_labels(poa_ws &S, uint16_t *lab, uint32_t hi_start, uint
     return 0;
 }
 
-// ---- DP over all rows of one alignment: 4 wavefronts per pack ---------------------------------
+// ---- DP over all rows of one alignment ---------------------------------------------------------
 // Rows are 1..n (rank+1); column j (1..L) is stored at index j-1, rows are Lp wide (multiple of
-// CPL).  Thread tid of the 256-thread block owns the CPL consecutive columns j = tid*CPL+1 ..
-// tid*CPL+CPL of every row; the last WIN rows stay in registers.
+// CPL).  Thread tid of the block (NW wavefronts) owns the CPL consecutive columns
+// j = tid*CPL+1 .. tid*CPL+CPL of every row.
 //
 // Horizontal affine gaps, exactly: E[j] = max(H[j-1]+g, E[j-1]+e) with E[0] = -inf, H[0] = 0 is
 // E[j] = j*e + max_{k<j} u_k with u_k = Hn[k] + g - (k+1)*e, Hn = max(diagonal, F, 0) (H without
 // its E term; valid because e >= g), u_0 = g - e.  So a row is: Hn from the predecessor rows,
-// an exclusive prefix-max of u (in-thread, DPP wave scan, one LDS exchange of the four wave
-// totals = ONE workgroup barrier per row), then H = max(Hn, E).
+// an exclusive prefix-max of u (in-thread, DPP wave scan, one LDS exchange of the wave totals =
+// ONE workgroup barrier per row), then H = max(Hn, E).
 // The column left of a wave's first column belongs to the previous wave; its H value is
-// rebuilt after the barrier from three published numbers (wave total without its last
-// column, Hn of that column) so later rows can use it as the diagonal source.
+// rebuilt after the barrier from published numbers (wave total without its last column, Hn of
+// that column) so later rows can use it as the diagonal source.
+//
+// Predecessor rows: the previous row is in registers (two register sets alternate, the row loop
+// is unrolled by two so nothing is copied); rows r-1 .. r-RINGN wait in a thread-private LDS
+// ring, 16 bits per cell: H (< 2^14 in the classes that use the ring) and min(H - F, 2), which
+// is all max(H+g, F+e) needs because g - e = -2; older rows (1-2 % of the fetches) are read back
+// from the H / F matrices.  Measured distance of predecessor rows in block order: <= 2: 35 %,
+// <= 4: 71 %, <= 6: 89 %, <= 8: 96 %, <= 10: 98.7 %.
+//
+// Best cell: every thread keeps the maximum of its columns, the first row where it occurs and
+// in how many rows it occurs; cells of columns >= L are strictly smaller than some valid cell, so
+// they need no masking.  Rows are compared for ties (kernel body) only when that is not unique.
 template <int CPL>
 __device__ __forceinline__ void load_block(const int16_t *__restrict__ p, int32_t *v) {
     if (CPL % 4 == 0) {
@@ -328,34 +339,36 @@ __device__ __forceinline__ void load_block(const int16_t *__restrict__ p, int32_
     }
 }
 
+// low halves of two registers in one (v_perm_b32)
+__device__ __forceinline__ uint32_t pack16(int32_t lo, int32_t hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
+
 template <int CPL>
-__device__ __forceinline__ void store_block(int16_t *__restrict__ p, const int32_t *v) {
+__device__ __forceinline__ void store_packed(int16_t *__restrict__ p, const uint32_t *pk) {
     if (CPL % 4 == 0) {
         uint2 *q = (uint2 *)p;
 #pragma unroll
-        for (int u = 0; u < CPL / 4; ++u) {
-            uint2 a;
-            a.x = (uint32_t)(uint16_t)(int16_t)v[4 * u] | ((uint32_t)(uint16_t)(int16_t)v[4 * u + 1] << 16);
-            a.y = (uint32_t)(uint16_t)(int16_t)v[4 * u + 2] | ((uint32_t)(uint16_t)(int16_t)v[4 * u + 3] << 16);
-            q[u] = a;
-        }
+        for (int u = 0; u < CPL / 4; ++u) q[u] = make_uint2(pk[2 * u], pk[2 * u + 1]);
     } else {
         uint32_t *q = (uint32_t *)p;
 #pragma unroll
-        for (int u = 0; u < CPL / 2; ++u)
-            q[u] = (uint32_t)(uint16_t)(int16_t)v[2 * u] | ((uint32_t)(uint16_t)(int16_t)v[2 * u + 1] << 16);
+        for (int u = 0; u < CPL / 2; ++u) q[u] = pk[u];
     }
 }
 
-struct dp_xchg {                 // LDS, double-buffered by row parity
-    int4 T[2];                   // per wave: inclusive max of u
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+struct dp_xchg {                 // LDS
+    int4 T[2];                   // double-buffered by row parity: per wave, inclusive max of u
     int2 Q[2][4];                // for wave w: {max of u of wave w-1 without its last column, Hn of that column}
     int32_t best[4];
-    uint32_t best_row[4];
+    uint32_t brow;               // first row that reaches the best score
+    uint32_t multi;              // 1: more than one row may reach it
+    uint32_t ntl;                // number of threads whose columns reach it
+    uint32_t tl[16];             // the first 16 of them
 };
 
-template <int CPL, int WIN, int RING, int NW>
-__device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row) {
+template <int CPL, int RINGN, int NW>
+__device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t c0 = (uint32_t)tid * CPL;
@@ -368,173 +381,192 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
 #pragma unroll
         for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
     }
-    int32_t h1[CPL], f1[CPL], h2[WIN > 1 ? CPL : 1], f2[WIN > 1 ? CPL : 1];
+    int32_t hA[CPL], fA[CPL], hB[CPL], fB[CPL];  // the two register sets of "the previous row"
 #pragma unroll
-    for (int t = 0; t < CPL; ++t) { h1[t] = 0; f1[t] = POA_NEG; }
-    if (WIN > 1) {
+    for (int t = 0; t < CPL; ++t) { hA[t] = 0; fA[t] = POA_NEG; hB[t] = 0; fB[t] = POA_NEG; }
+    int32_t hlA = 0, hlB = 0;                    // H of the column left of the thread's block in that row
+    uint32_t rowA = 0xFFFFFFFFu, rowB = 0xFFFFFFFFu;
+    int32_t lbest = 0;
+    uint32_t lrow = 0, lcnt = 0;
+    uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
+    uint32_t r0 = 0;
+
+    // one row: predecessor registers (hP, fP, hlP, rowP) -> new row in (hN, fN, hlN, rowN)
+    auto step = [&](const uint32_t i, const int32_t (&hP)[CPL], const int32_t (&fP)[CPL], const int32_t hlP, const uint32_t rowP,
+                    int32_t (&hN)[CPL], int32_t (&fN)[CPL], int32_t &hlN, uint32_t &rowN) __attribute__((always_inline)) {
+        const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
+        const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
+                                (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
+        const uint32_t row = r0 + i + 1;
+        const uint32_t par = row & 1u;
+        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+        int32_t sc[CPL], hn[CPL], fr[CPL];
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) { h2[t] = 0; f2[t] = POA_NEG; }
-    }
-    int32_t hl1 = 0, hl2 = 0;                    // H[row1][c0], H[row2][c0] (column left of the block)
-    uint32_t row1 = 0xFFFFFFFFu, row2 = 0xFFFFFFFFu;
-    int32_t my_best = 0;
-    uint32_t my_best_row = 0;
-    for (uint32_t r0 = 0; r0 < n; r0 += 64) {
-        const uint32_t nb = min(64u, n - r0);
-        uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
-        for (uint32_t i = 0; i < nb; ++i) {
-            const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
-            const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
-                                    (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
-            const uint32_t row = r0 + i + 1;
-            const uint32_t par = row & 1u;
-            const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
-            int32_t hn[CPL], fr[CPL];
+        for (int t = 0; t < CPL; ++t) {
+            sc[t] = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+            hn[t] = POA_NEG; fr[t] = POA_NEG;
+        }
+        uint32_t e = more;
+        for (uint32_t k = 0; k < (n_in ? n_in : 1u); ++k) {
+            uint32_t prow = 0;
+            if (n_in) {
+                if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
+                else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
+            }
+            if (n_in == 0) {
+                // virtual start row: H = 0, F = -inf
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { hn[t] = POA_NEG; fr[t] = POA_NEG; }
-            uint32_t e = more;
-            for (uint32_t k = 0; k < (n_in ? n_in : 1u); ++k) {
-                int32_t hp[CPL], fp[CPL];
-                int32_t hl = 0;                  // H[p][c0] for lane 0 of waves 1..3
-                uint32_t prow = 0;
-                if (n_in) {
-                    if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
-                    else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
+                for (int t = 0; t < CPL; ++t) { hn[t] = max(hn[t], sc[t]); fr[t] = max(fr[t], POA_G); }
+            } else if (prow == rowP) {
+                const int32_t hleft = wave_shr1(hP[CPL - 1], hlP);      // H[p][j-1] of the thread's first column
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const int32_t hd = t == 0 ? hleft : hP[t - 1];
+                    hn[t] = max(hn[t], hd + sc[t]);
+                    fr[t] = max(fr[t], max(hP[t] + POA_G, fP[t] + POA_E));
                 }
-#ifdef POA_HIST
-                if (tid == 0 && n_in) { const uint32_t d = row - prow; atomicAdd(&S.hist[(k == 0 ? 16 : 80) + (d < 63 ? d : 63)], 1ull); }
-#endif
-                if (n_in == 0) {
+            } else if (RINGN > 0 && row - prow <= (uint32_t)RINGN) {
+                const uint32_t slot = prow % (uint32_t)(RINGN > 0 ? RINGN : 1);
+                const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
+                int32_t hp[CPL], fd[CPL];
 #pragma unroll
-                    for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
-                } else if (prow == row1) {
-#pragma unroll
-                    for (int t = 0; t < CPL; ++t) { hp[t] = h1[t]; fp[t] = f1[t]; }
-                    hl = hl1;
-                } else if (WIN > 1 && prow == row2) {
-#pragma unroll
-                    for (int t = 0; t < CPL; ++t) { hp[t] = h2[t]; fp[t] = f2[t]; }
-                    hl = hl2;
-                } else if (RING > 0 && row - prow <= (uint32_t)(RING + WIN)) {
-                    // rows that left the register window wait in the LDS ring: 16 bits per cell, H (< 2^14 in the
-                    // classes that use the ring) and min(H - F, 2) -- enough for max(H+g, F+e) since g - e = -2
-                    const uint32_t slot = prow & (uint32_t)(RING - 1);
-                    const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
-#pragma unroll
-                    for (int u = 0; u < CPL / 2; ++u) {
-                        const uint32_t a = rp[u];
-                        hp[2 * u] = (int32_t)(a & 0x3FFFu); hp[2 * u + 1] = (int32_t)((a >> 16) & 0x3FFFu);
-                        fp[2 * u] = hp[2 * u] - (int32_t)((a >> 14) & 3u); fp[2 * u + 1] = hp[2 * u + 1] - (int32_t)(a >> 30);
-                    }
-                    hl = S.lh_ring[slot * 4 + wave];
-                } else {
-                    const int16_t *Hp = S.H + (uint64_t)prow * Lp;
-                    const int16_t *Fp = S.F + (uint64_t)prow * Lp;
-                    if (act) {
-                        load_block<CPL>(Hp + c0, hp);
-                        load_block<CPL>(Fp + c0, fp);
-                        if (lane == 0 && wave > 0) hl = S.lh[prow * 4 + wave];
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
-                    }
+                for (int u = 0; u < CPL / 2; ++u) {
+                    const uint32_t a = rp[u];
+                    hp[2 * u] = (int32_t)(a & 0x3FFFu); hp[2 * u + 1] = (int32_t)((a >> 16) & 0x3FFFu);
+                    fd[2 * u] = hp[2 * u] - (int32_t)((a >> 14) & 3u); fd[2 * u + 1] = hp[2 * u + 1] - (int32_t)(a >> 30);
                 }
-                const int32_t hleft = wave_shr1(hp[CPL - 1], hl);      // H[p][j-1] of the thread's first column
+                const int32_t hleft = wave_shr1(hp[CPL - 1], S.lh_ring[slot * 4 + wave]);
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) {
                     const int32_t hd = t == 0 ? hleft : hp[t - 1];
-                    const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-                    hn[t] = max(hn[t], hd + sc);
+                    hn[t] = max(hn[t], hd + sc[t]);
+                    fr[t] = max(fr[t], fd[t] + POA_E);                  // = max(H+g, F+e): fd = H - min(H-F, 2), g - e = -2
+                }
+            } else {
+                int32_t hp[CPL], fp[CPL];
+                int32_t hl = 0;
+                if (act) {
+                    load_block<CPL>(S.H + (uint64_t)prow * Lp + c0, hp);
+                    load_block<CPL>(S.F + (uint64_t)prow * Lp + c0, fp);
+                    if (lane == 0 && wave > 0) hl = S.lh[prow * 4 + wave];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
+                }
+                const int32_t hleft = wave_shr1(hp[CPL - 1], hl);
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const int32_t hd = t == 0 ? hleft : hp[t - 1];
+                    hn[t] = max(hn[t], hd + sc[t]);
                     fr[t] = max(fr[t], max(hp[t] + POA_G, fp[t] + POA_E));
                 }
             }
-            int32_t ex[CPL];                     // in-thread exclusive prefix max of u
-            int32_t run = POA_NEG;
+        }
+        int32_t ex[CPL];                         // in-thread exclusive prefix max of u
+        int32_t run = POA_NEG;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) {
-                hn[t] = max(max(hn[t], fr[t]), 0);
-                ex[t] = run;
-                run = max(run, hn[t] + POA_G - ((int32_t)(c0 + t) + 2) * POA_E);     // u_j, j = c0+t+1
+        for (int t = 0; t < CPL; ++t) {
+            hn[t] = max(max(hn[t], fr[t]), 0);
+            ex[t] = run;
+            run = max(run, hn[t] + POA_G - ((int32_t)(c0 + t) + 2) * POA_E);     // u_j, j = c0+t+1
+        }
+        const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
+        const int32_t texcl = wave_shr1(wincl, POA_NEG);
+        int32_t base = POA_G - POA_E;            // u_0
+        int32_t hl_new = 0;
+        if (NW > 1) {
+            if (lane == 63) {
+                ((int32_t *)&X.T[par])[wave] = wincl;
+                if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex[CPL - 1]), hn[CPL - 1]);
             }
-            const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
-            const int32_t texcl = wave_shr1(wincl, POA_NEG);
-            int32_t base = POA_G - POA_E;        // u_0
-            int32_t hl_new = 0;
-            if (NW > 1) {
-                if (lane == 63) {
-                    ((int32_t *)&X.T[par])[wave] = wincl;
-                    if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex[CPL - 1]), hn[CPL - 1]);
-                }
-                row_barrier();
-                const int4 T = X.T[par];         // both reads are in flight together; selects are scalar (wave is uniform)
-                const int2 q = X.Q[par][wave];
-                const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
-                const int32_t b0 = wave > 1 ? T.x : POA_NEG, b1 = wave > 2 ? T.y : POA_NEG;
-                base = max(max(base, t0), max(t1, t2));
-                if (wave > 0) {
-                    const int32_t bp = max(max(POA_G - POA_E, b0), b1);
-                    const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);        // 1-based index of the column left of the wave
-                    hl_new = max(q.y, max(bp, q.x) + c0w * POA_E);
-                    if (lane == 0) S.lh[row * 4 + wave] = hl_new;
-                }
+            row_barrier();
+            const int4 T = X.T[par];             // both reads are in flight together; selects are scalar (wave is uniform)
+            const int2 q = X.Q[par][wave];
+            const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
+            const int32_t b0 = wave > 1 ? T.x : POA_NEG, b1 = wave > 2 ? T.y : POA_NEG;
+            base = max(max(base, t0), max(t1, t2));
+            if (wave > 0) {
+                const int32_t bp = max(max(POA_G - POA_E, b0), b1);
+                const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);        // 1-based index of the column left of the wave
+                hl_new = max(q.y, max(bp, q.x) + c0w * POA_E);
+                if (lane == 0) S.lh[row * 4 + wave] = hl_new;
             }
-            base = max(base, texcl);
-            int32_t hv[CPL], ev[CPL];
-            int32_t lane_max = 0;
+        }
+        base = max(base, texcl);
+        int32_t ev[CPL];
+        int32_t lm = 0;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) {
-                const int32_t j = (int32_t)(c0 + t) + 1;
-                ev[t] = max(base, ex[t]) + j * POA_E;
-                hv[t] = max(hn[t], ev[t]);
-                if (c0 + t < L) lane_max = max(lane_max, hv[t]);
-            }
-            if (RING > 0) {
-                // the row leaving the register window goes to the ring
-                const uint32_t orow = WIN > 1 ? row2 : row1;
-                if (orow != 0xFFFFFFFFu) {
-                    const uint32_t slot = orow & (uint32_t)(RING - 1);
-                    uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
+        for (int t = 0; t < CPL; ++t) {
+            const int32_t j = (int32_t)(c0 + t) + 1;
+            ev[t] = max(base, ex[t]) + j * POA_E;
+            hN[t] = max(hn[t], ev[t]);
+            fN[t] = fr[t];
+            lm = max(lm, hN[t]);
+        }
+        hlN = hl_new; rowN = row;
+        {                                        // per-thread best: value, first row, number of rows
+            const bool gt = lm > lbest, eq = lm == lbest;
+            lcnt = gt ? 1u : lcnt + (eq ? 1u : 0u);
+            lrow = gt ? row : lrow;
+            lbest = gt ? lm : lbest;
+        }
+        uint32_t pkH[CPL / 2], pkF[CPL / 2], pkE[CPL / 2];
 #pragma unroll
-                    for (int u = 0; u < CPL / 2; ++u) {
-                        const int32_t ha = WIN > 1 ? h2[2 * u] : h1[2 * u], hb = WIN > 1 ? h2[2 * u + 1] : h1[2 * u + 1];
-                        const int32_t fa = WIN > 1 ? f2[2 * u] : f1[2 * u], fb = WIN > 1 ? f2[2 * u + 1] : f1[2 * u + 1];
-                        rp[u] = (uint32_t)ha | ((uint32_t)min(ha - fa, 2) << 14) | ((uint32_t)hb << 16) | ((uint32_t)min(hb - fb, 2) << 30);
-                    }
-                    if (lane == 0) S.lh_ring[slot * 4 + wave] = WIN > 1 ? hl2 : hl1;
-                }
-            }
-            if (act) {
-                store_block<CPL>(S.H + (uint64_t)row * Lp + c0, hv);
-                store_block<CPL>(S.F + (uint64_t)row * Lp + c0, fr);
-                store_block<CPL>(S.E + (uint64_t)row * Lp + c0, ev);
-            }
-            if (WIN > 1) {
+        for (int u = 0; u < CPL / 2; ++u) {
+            pkH[u] = pack16(hN[2 * u], hN[2 * u + 1]);
+            pkF[u] = pack16(fr[2 * u], fr[2 * u + 1]);       // F >= g: every row has a (possibly virtual) predecessor with H >= 0
+            pkE[u] = pack16(ev[2 * u], ev[2 * u + 1]);
+        }
+        if (RINGN > 0) {
+            const uint32_t slot = row % (uint32_t)(RINGN > 0 ? RINGN : 1);
+            uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
 #pragma unroll
-                for (int t = 0; t < CPL; ++t) { h2[t] = h1[t]; f2[t] = f1[t]; }
-                hl2 = hl1; row2 = row1;
+            for (int u = 0; u < CPL / 2; ++u) {
+                s16x2 hh, ff;
+                __builtin_memcpy(&hh, &pkH[u], 4); __builtin_memcpy(&ff, &pkF[u], 4);
+                const s16x2 two = {2, 2};
+                const s16x2 d = __builtin_elementwise_min(hh - ff, two);
+                uint32_t dw;
+                __builtin_memcpy(&dw, &d, 4);
+                rp[u] = pkH[u] | (dw << 14);
             }
-#pragma unroll
-            for (int t = 0; t < CPL; ++t) { h1[t] = hv[t]; f1[t] = fr[t]; }
-            hl1 = hl_new; row1 = row;
-            const int32_t row_max = wave_last(wave_scan_max(lane_max, 0));
-            if (lane == 0) {                     // [row][4]: entries of absent waves are zero
-                if (NW == 1) *(int4 *)(S.rowmax + row * 4) = make_int4(row_max, 0, 0, 0);
-                else { S.rowmax[row * 4 + wave] = row_max; if (NW == 2 && wave == 0) *(int2 *)(S.rowmax + row * 4 + 2) = make_int2(0, 0); }
-            }
-            if (row_max > my_best) { my_best = row_max; my_best_row = row; }
+            if (lane == 0) S.lh_ring[slot * 4 + wave] = hl_new;
+        }
+        if (act) {
+            store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, pkH);
+            store_packed<CPL>(S.F + (uint64_t)row * Lp + c0, pkF);
+            store_packed<CPL>(S.E + (uint64_t)row * Lp + c0, pkE);
+        }
+    };
+
+    for (r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t nb = min(64u, n - r0);
+        my = make_uint4(0, 0, 0, 0); myb = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
+        for (uint32_t i = 0; i < nb; i += 2) {
+            step(i, hA, fA, hlA, rowA, hB, fB, hlB, rowB);
+            if (i + 1 < nb) step(i + 1, hB, fB, hlB, rowB, hA, fA, hlA, rowA);
         }
     }
-    if (lane == 0) { X.best[wave] = my_best; X.best_row[wave] = my_best_row; }
+    // block-wide: best score, the first row that reaches it, and whether other rows may reach it too
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wave] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 0; X.ntl = 0; }
     __syncthreads();
-    best = 0; best_row = 0;
+    best = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const int32_t b = X.best[w];
-        const uint32_t r = X.best_row[w];
-        if (b > best || (b == best && b > 0 && r < best_row)) { best = b; best_row = r; }
+    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
+    const bool mine = best > 0 && lbest == best;
+    if (mine) atomicMin(&X.brow, lrow);
+    __syncthreads();
+    best_row = best > 0 ? X.brow : 0u;
+    if (mine) {
+        if (lcnt != 1 || lrow != best_row) X.multi = 1;
+        const uint32_t slot = atomicAdd(&X.ntl, 1u);
+        if (slot < 16) X.tl[slot] = (uint32_t)tid;
     }
     __syncthreads();
+    multi = X.multi != 0;
 }
 
 // ---- graph update helpers (lane 0) --------------------------------------------------------------
@@ -586,7 +618,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
-template <int CPL, int WIN, int RING, int NW>
+template <int CPL, int RING, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL == 6 ? 4 : 1)) void poa_kernel(poa_args A) {
     constexpr uint32_t NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -609,7 +641,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * CPL / 2);
+        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (CPL / 2));
         S.topo = nullptr;
     }
 
@@ -659,22 +691,42 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                 t_topo += t1 - t0;
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
-                dp_rows<CPL, WIN, RING, NW>(S, X, n, L, Lp, best, best_row);
+                bool multi = false;
+                dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 cells += (unsigned long long)n * L;
                 rows += n;
                 unsigned long long t2 = PT_NOW();
                 t_dp += t2 - t1;
                 if (best > 0) {
-                    // spoa takes the first maximum in ITS rank order: when several rows reach the best
-                    // score, run its topological sort and keep the row with the smallest rank
+                    // spoa takes the first maximum in ITS rank order.  dp_rows found the first row (block order)
+                    // that reaches the best score; only if other rows may reach it too are the rows compared:
+                    // rowmax[r] != 0 marks the rows that do (the H cells of the threads that saw the score).
                     if (tid == 0) { s_bc[5] = 0; s_bc[7] = 0xFFFFFFFFu; }
-                    __syncthreads();
-                    {
-                        uint32_t cnt = 0;
-                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
-                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
-                            cnt += max(max(m.x, m.y), max(m.z, m.w)) == best ? 1u : 0u;
+                    if (multi) {
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) S.rowmax[r] = 0;
+                        __syncthreads();
+                        const uint32_t ntl = X.ntl;
+                        if (ntl <= 16) {
+                            for (uint32_t idx = tid; idx < n * ntl; idx += NT) {
+                                const uint32_t r = idx / ntl + 1, t = X.tl[idx % ntl];
+                                int32_t v[CPL];
+                                load_block<CPL>(S.H + (uint64_t)r * Lp + t * CPL, v);
+                                bool hit = false;
+#pragma unroll
+                                for (int u = 0; u < CPL; ++u) hit |= v[u] == best;
+                                if (hit) S.rowmax[r] = 1;
+                            }
+                        } else {
+                            for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NW) {
+                                const int16_t *Hr = S.H + (uint64_t)r * Lp;
+                                bool hit = false;
+                                for (uint32_t c = tid & 63; c < Lp; c += 64) hit |= (int32_t)Hr[c] == best;
+                                if (hit) S.rowmax[r] = 1;
+                            }
                         }
+                        __syncthreads();
+                        uint32_t cnt = 0;
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) cnt += S.rowmax[r] != 0 ? 1u : 0u;
                         if (cnt) atomicAdd(&s_bc[5], cnt);
                     }
                     __syncthreads();
@@ -686,16 +738,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                         if (tid == 0) s_bc[5] = 0;
                         __syncthreads();
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
-                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
-                            if (max(max(m.x, m.y), max(m.z, m.w)) != best || r == best_row) continue;
+                            if (S.rowmax[r] == 0 || r == best_row) continue;
                             const uint4 pl = S.plan[r - 1], plb = S.planb[r - 1];
                             const uint32_t n_in = rd_nin(pl.x);
                             bool ok = false;
                             for (uint32_t k = 0; k < n_in && k < 4; ++k) {
                                 const uint32_t p = u4_get(plb, k);
                                 if (p == 0) continue;
-                                const int4 pm = *(const int4 *)(S.rowmax + p * 4);
-                                if (max(max(pm.x, pm.y), max(pm.z, pm.w)) == best) ok = true;
+                                if (S.rowmax[p] != 0) ok = true;
                             }
                             if (!ok) s_bc[5] = 1;
                         }
@@ -713,21 +763,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                         if (tid == 0) { s_bc[7] = 0xFFFFFFFFu; s_bc[5] = 0; s_bc[6] = 0xFFFFFFFFu; }
                         __syncthreads();
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
-                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
-                            if (max(max(m.x, m.y), max(m.z, m.w)) == best) atomicMin(&s_bc[6], r);
+                            if (S.rowmax[r] != 0) atomicMin(&s_bc[6], r);
                         }
                         __syncthreads();
                         if (w0) { const uint32_t next = tie_labels(S, lab, n, s_bc[6]); if (tid == 0) s_bc[6] = next; }
                         __syncthreads();
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
-                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
-                            if (max(max(m.x, m.y), max(m.z, m.w)) == best) atomicMin(&s_bc[7], (uint32_t)lab[r - 1]);
+                            if (S.rowmax[r] != 0) atomicMin(&s_bc[7], (uint32_t)lab[r - 1]);
                         }
                         __syncthreads();
                         const uint32_t root = s_bc[7];
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
-                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
-                            if (max(max(m.x, m.y), max(m.z, m.w)) == best && (uint32_t)lab[r - 1] == root) {
+                            if (S.rowmax[r] != 0 && (uint32_t)lab[r - 1] == root) {
                                 const uint32_t slot = atomicAdd(&s_bc[5], 1u);
                                 if (slot < 8) s_tied[slot] = r;
                             }
@@ -771,15 +818,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                         S.err = s_bc[4];
                         if (S.err) break;
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
-                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
-                            if (max(max(m.x, m.y), max(m.z, m.w)) == best) atomicMin(&s_bc[7], (uint32_t)S.srank[S.order[r - 1]]);
+                            if (S.rowmax[r] != 0) atomicMin(&s_bc[7], (uint32_t)S.srank[S.order[r - 1]]);
                         }
                         __syncthreads();
                         const uint32_t want = s_bc[7];
                         __syncthreads();
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
-                            const int4 m = *(const int4 *)(S.rowmax + r * 4);
-                            if (max(max(m.x, m.y), max(m.z, m.w)) == best && (uint32_t)S.srank[S.order[r - 1]] == want) s_bc[7] = r;
+                            if (S.rowmax[r] != 0 && (uint32_t)S.srank[S.order[r - 1]] == want) s_bc[7] = r;
                         }
                         __syncthreads();
                         best_row = s_bc[7];
@@ -1103,18 +1148,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-template <int CPL, int WIN, int RING, int NW>
+template <int CPL, int RING, int NW>
 static hipError_t launch_poa(const poa_args &A, uint32_t n_slots, size_t shm, hipStream_t st) {
     if (shm > 60 * 1024)
-        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, WIN, RING, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((poa_kernel<CPL, WIN, RING, NW>), dim3(n_slots), dim3(64 * NW), shm, st, A);
+        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, RING, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL((poa_kernel<CPL, RING, NW>), dim3(n_slots), dim3(64 * NW), shm, st, A);
     return hipGetLastError();
 }
 
-template <int CPL, int WIN, int RING, int NW>
+template <int CPL, int RING, int NW>
 static int max_blocks_per_cu(size_t shm) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, WIN, RING, NW>, 64 * NW, shm) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, RING, NW>, 64 * NW, shm) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
@@ -1127,10 +1172,9 @@ struct poa_variant {
     hipError_t (*launch)(const poa_args &, uint32_t, size_t, hipStream_t);
     int (*max_blocks)(size_t);
 };
-#define POA_VARIANT(CPL, WIN, RING, NW) {CPL, RING, NW, &launch_poa<CPL, WIN, RING, NW>, &max_blocks_per_cu<CPL, WIN, RING, NW>}
-static const poa_variant k_latency[5] = {POA_VARIANT(4, 2, 8, 4), POA_VARIANT(6, 2, 8, 4), POA_VARIANT(8, 2, 8, 4), POA_VARIANT(16, 1, 0, 4),
-                                         POA_VARIANT(24, 1, 0, 4)};
-static const poa_variant k_throughput[3] = {POA_VARIANT(16, 1, 8, 1), POA_VARIANT(12, 1, 8, 2), POA_VARIANT(16, 1, 8, 2)};
+#define POA_VARIANT(CPL, RING, NW) {CPL, RING, NW, &launch_poa<CPL, RING, NW>, &max_blocks_per_cu<CPL, RING, NW>}
+static const poa_variant k_latency[5] = {POA_VARIANT(4, 10, 4), POA_VARIANT(6, 10, 4), POA_VARIANT(8, 10, 4), POA_VARIANT(16, 0, 4), POA_VARIANT(24, 0, 4)};
+static const poa_variant k_throughput[3] = {POA_VARIANT(16, 8, 1), POA_VARIANT(12, 8, 2), POA_VARIANT(16, 8, 2)};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -1238,7 +1282,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
             // LDS ring of the last RING rows (packed H|F, thread-private): 8 rows cost a block per CU and
             // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.
-            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)P.V->ring * 64 * P.V->nw * cpl * 2 + 8 * 4 * 4;
+            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)P.V->ring * 64 * P.V->nw * cpl * 2 + (size_t)P.V->ring * 16 + 64;
             P.bpc = P.V->max_blocks(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
             A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
