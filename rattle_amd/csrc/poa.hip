@@ -5,26 +5,26 @@
 // (spoa is an absent, unpinned submodule; behaviour restated in oracle/orc_poa.hpp and pinned
 // there against toyset/rna/output/consensi.fq).
 //
-// One WAVEFRONT per pack (persistent blocks pull packs from a queue, largest first).  For every
-// sequence of the pack, in order:
-//   1. toposort: spoa's Graph::topological_sort (iterative DFS over in-edges from node ids
-//      0..n-1, aligned groups ranked consecutively) runs wave-uniformly with its mark bits and
-//      stack in LDS -> rank order (which decides best-cell ties and the MSA column order).
-//   2. plan: 64 rows at a time, every lane gathers one row's (letter, in-degree, first
-//      predecessor row, further in-edges) into a 16-byte record, so the DP loop below has no
+// One workgroup of NW wavefronts per pack (persistent blocks pull packs from a queue, largest
+// first).  For every sequence of the pack, in order:
+//   1. rows: the DP runs in an incrementally maintained BLOCK ORDER (a topological order with
+//      aligned groups contiguous; step 6).  DP values per graph node do not depend on the order the
+//      rows are taken in; spoa's own order (DFS from node ids 0..n-1) matters only for best-score
+//      ties between rows and for the MSA columns, and is derived only there.
+//   2. plan: every thread gathers one row's (letter, in-degree, rows of the first four
+//      predecessors, tail of the in-edge list) into two 16-byte records, so the DP loop has no
 //      dependent pointer chasing.
-//   3. DP: a row = 64 lanes x 16 consecutive columns per 1024-column segment.  The previous
-//      row's H/F stay in registers (the common predecessor); other predecessors are read
-//      back as aligned 32-byte blocks.  The horizontal affine recurrence
-//      E[j] = max(H[j-1]+g, E[j-1]+e) is solved exactly as a prefix-max of Hn[j-1]+g-j*e
-//      (in-lane pass + wave scan).  H/F/E rows are written as int16 for the traceback.
-//   4. best cell = first maximum in (rank, column) order; traceback in spoa's order
-//      (diagonal, vertical, horizontal; predecessors in in-edge insertion order; affine
-//      extension runs followed inside F / E) by lane 0.
-//   5. add_alignment by lane 0: prefix/suffix chains, node reuse, aligned-group siblings,
-//      edge insertion in order; the node path of the sequence is recorded.
-// At the end one more toposort assigns MSA columns (a group shares a column) and every
-// base's column index is written out; the host expands rows ('-' elsewhere).
+//   3. DP (dp_rows): a row = NW x 64 lanes x CPL consecutive columns; exact affine gaps through a
+//      prefix-max, one barrier per row; H/F/E rows are written as int16 for the traceback.
+//   4. best cell = first maximum in (spoa rank, column) order (tie_labels); traceback in spoa's
+//      order (diagonal, vertical, horizontal; predecessors in in-edge insertion order; affine
+//      extension runs followed inside F / E) by thread 0.
+//   5. add_alignment: prefix/suffix chains, node reuse, aligned-group siblings, edge insertion in
+//      order; the node path of the sequence is recorded.
+//   6. merge_order: the new nodes are merged into the row order (stable parallel merge keyed by
+//      the row each must precede).
+// At the end spoa's topological sort assigns MSA columns (a group shares a column) and every
+// base's column index is written out (kernel D or the host expands rows, '-' elsewhere).
 //
 // HBM traffic (algorithmic): 6 B per DP cell written (H,E,F int16).
 #include <algorithm>
