@@ -28,6 +28,7 @@
 //
 // HBM traffic (algorithmic): 6 B per DP cell written (H,E,F int16).
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
@@ -400,48 +401,37 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
         const uint32_t row = r0 + i + 1;
         const uint32_t par = row & 1u;
         const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
-        int32_t sc[CPL], hn[CPL], fr[CPL];
-#pragma unroll
-        for (int t = 0; t < CPL; ++t) {
-            sc[t] = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-            hn[t] = POA_NEG; fr[t] = POA_NEG;
-        }
-        uint32_t e = more;
-        for (uint32_t k = 0; k < (n_in ? n_in : 1u); ++k) {
-            uint32_t prow = 0;
-            if (n_in) {
-                if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
-                else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
-            }
+        // Over the predecessor rows p only two per-column maxima are needed: hm = max H[p][j-1] (the match
+        // score of the row is the same for every p) and fm = max of max(H[p][j] + g - e, F[p][j]), so that
+        // diagonal = hm + score and F = fm + e.  The first predecessor assigns, the others take the max.
+        int32_t hm[CPL], fm[CPL];
+        auto pred = [&](auto first_tag, const uint32_t prow) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            int32_t hd[CPL], fd[CPL];
             if (n_in == 0) {
                 // virtual start row: H = 0, F = -inf
 #pragma unroll
-                for (int t = 0; t < CPL; ++t) { hn[t] = max(hn[t], sc[t]); fr[t] = max(fr[t], POA_G); }
+                for (int t = 0; t < CPL; ++t) { hd[t] = 0; fd[t] = POA_G - POA_E; }
             } else if (prow == rowP) {
                 const int32_t hleft = wave_shr1(hP[CPL - 1], hlP);      // H[p][j-1] of the thread's first column
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) {
-                    const int32_t hd = t == 0 ? hleft : hP[t - 1];
-                    hn[t] = max(hn[t], hd + sc[t]);
-                    fr[t] = max(fr[t], max(hP[t] + POA_G, fP[t] + POA_E));
+                    hd[t] = t == 0 ? hleft : hP[t - 1];
+                    fd[t] = max(hP[t] + (POA_G - POA_E), fP[t]);
                 }
             } else if (RINGN > 0 && row - prow <= (uint32_t)RINGN) {
                 const uint32_t slot = prow % (uint32_t)(RINGN > 0 ? RINGN : 1);
                 const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
-                int32_t hp[CPL], fd[CPL];
+                int32_t hp[CPL];
 #pragma unroll
                 for (int u = 0; u < CPL / 2; ++u) {
                     const uint32_t a = rp[u];
                     hp[2 * u] = (int32_t)(a & 0x3FFFu); hp[2 * u + 1] = (int32_t)((a >> 16) & 0x3FFFu);
-                    fd[2 * u] = hp[2 * u] - (int32_t)((a >> 14) & 3u); fd[2 * u + 1] = hp[2 * u + 1] - (int32_t)(a >> 30);
+                    fd[2 * u] = hp[2 * u] - (int32_t)((a >> 14) & 3u); fd[2 * u + 1] = hp[2 * u + 1] - (int32_t)(a >> 30);   // H - min(H-F, 2)
                 }
                 const int32_t hleft = wave_shr1(hp[CPL - 1], S.lh_ring[slot * 4 + wave]);
 #pragma unroll
-                for (int t = 0; t < CPL; ++t) {
-                    const int32_t hd = t == 0 ? hleft : hp[t - 1];
-                    hn[t] = max(hn[t], hd + sc[t]);
-                    fr[t] = max(fr[t], fd[t] + POA_E);                  // = max(H+g, F+e): fd = H - min(H-F, 2), g - e = -2
-                }
+                for (int t = 0; t < CPL; ++t) hd[t] = t == 0 ? hleft : hp[t - 1];
             } else {
                 int32_t hp[CPL], fp[CPL];
                 int32_t hl = 0;
@@ -456,11 +446,37 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                 const int32_t hleft = wave_shr1(hp[CPL - 1], hl);
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) {
-                    const int32_t hd = t == 0 ? hleft : hp[t - 1];
-                    hn[t] = max(hn[t], hd + sc[t]);
-                    fr[t] = max(fr[t], max(hp[t] + POA_G, fp[t] + POA_E));
+                    hd[t] = t == 0 ? hleft : hp[t - 1];
+                    fd[t] = max(hp[t] + (POA_G - POA_E), fp[t]);
                 }
             }
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                hm[t] = FIRST ? hd[t] : max(hm[t], hd[t]);
+                fm[t] = FIRST ? fd[t] : max(fm[t], fd[t]);
+            }
+        };
+        pred(std::true_type{}, pw[0]);
+        if (n_in > 1) {
+            pred(std::false_type{}, pw[1]);
+            if (n_in > 2) {
+                pred(std::false_type{}, pw[2]);
+                if (n_in > 3) {
+                    pred(std::false_type{}, pw[3]);
+                    uint32_t e = more;
+                    for (uint32_t k = 4; k < n_in; ++k) {
+                        const uint2 ed = S.edges[e]; e = ed.y;
+                        pred(std::false_type{}, (uint32_t)S.rank[ed.x] + 1);
+                    }
+                }
+            }
+        }
+        int32_t hn[CPL], fr[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+            fr[t] = fm[t] + POA_E;
+            hn[t] = hm[t] + sc;
         }
         int32_t ex[CPL];                         // in-thread exclusive prefix max of u
         int32_t run = POA_NEG;
