@@ -4,6 +4,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <memory>
+
 #include "common.h"
 
 namespace rattle {
@@ -186,20 +188,35 @@ int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_
     *out = nullptr;
     RT_HIP(hipSetDevice(c->device));
     phase_timer T_all("cluster_unsorted: total");
+    // main.cpp:254-262: stable sort by length, longest first (counting sort; lengths are small integers)
     std::vector<uint32_t> order(n);
-    for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [off](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
-    std::vector<uint8_t> cat(off[n] - off[0]);
-    std::vector<uint64_t> soff(n + 1);
-    uint64_t p = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t a = off[order[i]], L = off[order[i] + 1] - a;
-        soff[i] = p;
-        memcpy(cat.data() + p, seq + a, L);
-        p += L;
+    {
+        phase_timer T("cluster: sort + gather");
+        uint64_t max_len = 0;
+        for (uint32_t i = 0; i < n; ++i) max_len = std::max<uint64_t>(max_len, off[i + 1] - off[i]);
+        if (max_len <= (1u << 24)) {
+            std::vector<uint32_t> start(max_len + 2, 0);
+            for (uint32_t i = 0; i < n; ++i) ++start[max_len - (off[i + 1] - off[i]) + 1];      // bucket 0 = longest
+            for (uint64_t b = 0; b <= max_len; ++b) start[b + 1] += start[b];
+            for (uint32_t i = 0; i < n; ++i) order[start[max_len - (off[i + 1] - off[i])]++] = i;
+        } else {
+            for (uint32_t i = 0; i < n; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [off](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+        }
     }
-    soff[n] = p;
-    { phase_timer T("cluster: build_index"); RT_TRY(build_index(c, cat.data(), soff.data(), n, k, P->is_rna ? 0 : 1)); }
+    std::unique_ptr<uint8_t[]> cat(new uint8_t[off[n] - off[0] + 1]);
+    std::vector<uint64_t> soff(n + 1);
+    {
+        uint64_t p = 0;
+        for (uint32_t i = 0; i < n; ++i) { soff[i] = p; p += off[order[i] + 1] - off[order[i]]; }
+        soff[n] = p;
+        const size_t chunk = 2048;
+        parallel_for((n + chunk - 1) / chunk, 0, [&](size_t c) {
+            for (size_t i = c * chunk; i < std::min<size_t>(n, (c + 1) * chunk); ++i)
+                memcpy(cat.get() + soff[i], seq + off[order[i]], soff[i + 1] - soff[i]);
+        });
+    }
+    { phase_timer T("cluster: build_index"); RT_TRY(build_index(c, cat.get(), soff.data(), n, k, P->is_rna ? 0 : 1)); }
     { phase_timer T("cluster: greedy driver"); RT_TRY(cluster_driver(c, P, nullptr, 0, out)); }
     rattle_cluster_set *cs = *out;
     const uint32_t nm = cs->offsets[cs->n_clusters];
