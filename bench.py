@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("RATTLE_BENCH_READS", 1000000)), help="reads per GPU")
     ap.add_argument("--genes", type=int, default=0, help="transcripts per GPU shard (default reads/200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage", action="store_true", help="hand the reads over as host buffers every step (PCIe-inclusive rate)")
     a = ap.parse_args()
 
     import torch
@@ -110,6 +111,8 @@ def main():
             dist.all_gather(parts, mine)
         return cl, res
 
+    if not a.no_stage:     # inputs resident in HBM before the timed region (BASELINE metric definition)
+        ctx.stage_reads(cat, qcat, off)
     for _ in range(a.warmup):
         step()
     ctx.reset_stats()
@@ -137,7 +140,7 @@ def main():
             "metric": "reads/sec for `cluster`+`correct` on 1e6\u00d71kb synthetic ONT reads, 1\u21928 GPU",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16", "data": "synthetic",
+            "dtype": "int16", "data": "synthetic", "inputs": "host buffers per step (PCIe inclusive)" if a.no_stage else "resident in HBM (rattle_hip_stage_reads)",
             "config": {"workload": f"{a.reads} synthetic cDNA reads per GPU (mean 1 kb, 10% err, both strands, {genes} transcripts, "
                                    "Zipf abundance), `rattle cluster` k=10 gene level + `rattle correct` "
                                    "(BASELINE metric size; configs[1]/[3] shape on one GPU)",

@@ -106,6 +106,16 @@ typedef struct {
     uint64_t counters[8];
 } rattle_cluster_set;
 
+/* Keep a copy of the reads (and, if not NULL, their qualities) in HBM.  Later calls of
+ * rattle_hip_cluster_unsorted / rattle_hip_correct_reads that are handed the SAME host buffers
+ * (pointer, read count, total bases) use the resident copy instead of uploading the bases again;
+ * the host buffers must stay unchanged until rattle_hip_unstage_reads.  This is how a caller that
+ * runs `cluster` and `correct` on one read set (main.cpp reads the same fastq twice) pays the PCIe
+ * transfer once. */
+int rattle_hip_stage_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const uint8_t *qual_concat, const uint64_t *offsets,
+                           uint32_t n_reads);
+int rattle_hip_unstage_reads(rattle_ctx *ctx);
+
 int rattle_hip_cluster_reads(rattle_ctx *ctx, const rattle_cluster_params *params, rattle_cluster_set **out);
 /* Same, restricted to a subset of the loaded reads given in processing order (the --iso
  * second level, main.cpp:281-318).  Ids in the result are positions in `subset`. */

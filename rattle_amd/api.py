@@ -80,6 +80,14 @@ class Context:
         cat, off = pack_reads(seqs)
         self.load_packed(cat, off, k, both_strands)
 
+    def stage_reads(self, cat: np.ndarray, qcat: Optional[np.ndarray], off: np.ndarray):
+        """Keep the reads (and qualities) resident in HBM; later calls given the same arrays skip the upload."""
+        q = _ptr(qcat, C.c_uint8) if qcat is not None else None
+        check(self.lib.rattle_hip_stage_reads(self.h, _ptr(cat, C.c_uint8), q, _ptr(off, C.c_uint64), len(off) - 1))
+
+    def unstage_reads(self):
+        check(self.lib.rattle_hip_unstage_reads(self.h))
+
     def load_packed(self, cat: np.ndarray, off: np.ndarray, k: int, both_strands: bool):
         n = len(off) - 1
         check(self.lib.rattle_hip_load_reads(self.h, _ptr(cat, C.c_uint8), _ptr(off, C.c_uint64), n, k, int(both_strands)))
@@ -168,9 +176,10 @@ class Context:
         return self._take_clusters(out)
 
     def correct_packed(self, cat: np.ndarray, qcat: np.ndarray, off: np.ndarray, cl: Clusters, min_occ=0.3, gap_occ=0.3,
-                       split=200, min_reads=5, n_threads=0, vote_order: bytes = b""):
+                       split=200, min_reads=5, n_threads=0, vote_order: bytes = b"", digest: bool = False):
         """correct_reads on packed arrays; returns (n_corrected, n_uncorrected, n_consensi, counters)
-        without materialising Python objects (the library still builds every output record)."""
+        without materialising Python objects (the library still builds every output record).
+        digest=True appends a CRC over every output array (ids, offsets, bases, qualities)."""
         P = CorrectParams(min_occ, gap_occ, 30.0, split, min_reads, n_threads, vote_order)
         out = C.POINTER(Correction)()
         mid = cl.member_id if len(cl.member_id) else np.zeros(1, np.int32)
@@ -180,6 +189,19 @@ class Context:
                                                 _ptr(mid, C.c_int32), _ptr(mrev, C.c_uint8), C.byref(P), C.byref(out)))
         R = out.contents
         res = (R.corrected.n, R.uncorrected.n, R.consensi.n, np.array(list(R.counters), dtype=np.uint64))
+        if digest:
+            import zlib
+            crc = 0
+            for S in (R.corrected, R.uncorrected, R.consensi):
+                n = S.n
+                o = np.ctypeslib.as_array(S.off, (n + 1,))
+                tot = int(o[n])
+                crc = zlib.crc32(o.tobytes(), crc)
+                for arr in (S.read_id, S.cluster_id, S.n_reads):
+                    crc = zlib.crc32(np.ctypeslib.as_array(arr, (max(n, 1),))[:n].tobytes(), crc)
+                crc = zlib.crc32(C.string_at(S.seq, tot), crc)
+                crc = zlib.crc32(C.string_at(S.qual, tot), crc)
+            res = res + (crc,)
         self.lib.rattle_hip_correction_free(out)
         return res
 

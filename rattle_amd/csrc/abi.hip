@@ -68,6 +68,7 @@ void rattle_hip_ctx_destroy(rattle_ctx *c) {
     for (int i = 0; i < 5; ++i) { if (c->poa_st[i]) (void)hipStreamDestroy(c->poa_st[i]); if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]); }
     if (c->poa_go) (void)hipEventDestroy(c->poa_go);
     c->h_poa_col.release();
+    c->d_staged_seq.release(); c->d_staged_qual.release();
     c->d_phred_lo.release(); c->d_perr.release(); c->d_exc_bits.release(); c->d_exc_val.release();
     c->h_surv.release(); c->h_res.release(); c->h_var.release(); c->h_counter.release();
     (void)hipEventDestroy(c->ev0);
@@ -182,6 +183,29 @@ int rattle_hip_cluster_subset(rattle_ctx *c, const rattle_cluster_params *P, con
     return cluster_driver(c, P, n_subset ? subset : &none, n_subset, out);
 }
 
+int rattle_hip_stage_reads(rattle_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n) {
+    if (!c || !off || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    RT_HIP(hipSetDevice(c->device));
+    const uint64_t total = off[n] - off[0];
+    c->staged_seq_key = nullptr; c->staged_qual_key = nullptr;
+    RT_TRY(c->d_staged_seq.reserve(total + 64));
+    RT_HIP(hipMemcpy(c->d_staged_seq.p, seq + off[0], total, hipMemcpyHostToDevice));
+    if (qual) {
+        RT_TRY(c->d_staged_qual.reserve(total + 64));
+        RT_HIP(hipMemcpy(c->d_staged_qual.p, qual + off[0], total, hipMemcpyHostToDevice));
+        c->staged_qual_key = qual;
+    }
+    c->staged_seq_key = seq; c->staged_n = n; c->staged_total = total;
+    return 0;
+}
+
+int rattle_hip_unstage_reads(rattle_ctx *c) {
+    if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
+    c->staged_seq_key = nullptr; c->staged_qual_key = nullptr; c->staged_n = 0; c->staged_total = 0;
+    c->d_staged_seq.release(); c->d_staged_qual.release();
+    return 0;
+}
+
 int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k,
                                 const rattle_cluster_params *P, rattle_cluster_set **out) {
     if (!c || !off || !P || !out || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
@@ -204,19 +228,39 @@ int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_
             std::stable_sort(order.begin(), order.end(), [off](uint32_t a, uint32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
         }
     }
-    std::unique_ptr<uint8_t[]> cat(new uint8_t[off[n] - off[0] + 1]);
     std::vector<uint64_t> soff(n + 1);
     {
         uint64_t p = 0;
         for (uint32_t i = 0; i < n; ++i) { soff[i] = p; p += off[order[i] + 1] - off[order[i]]; }
         soff[n] = p;
-        const size_t chunk = 2048;
-        parallel_for((n + chunk - 1) / chunk, 0, [&](size_t c) {
-            for (size_t i = c * chunk; i < std::min<size_t>(n, (c + 1) * chunk); ++i)
-                memcpy(cat.get() + soff[i], seq + off[order[i]], soff[i + 1] - soff[i]);
-        });
     }
-    { phase_timer T("cluster: build_index"); RT_TRY(build_index(c, cat.get(), soff.data(), n, k, P->is_rna ? 0 : 1)); }
+    if (n && c->staged_seq_key == seq && c->staged_n == n && c->staged_total == off[n] - off[0] && off[0] == 0) {
+        // the reads are resident (rattle_hip_stage_reads): gather them into processing order on the device
+        phase_timer T("cluster: device gather + build_index");
+        std::vector<gather_desc> desc(n);
+        for (uint32_t i = 0; i < n; ++i) desc[i] = gather_desc{off[order[i]], soff[i], (uint32_t)(soff[i + 1] - soff[i]), 0u};
+        dbuf<gather_desc> d_desc;
+        dbuf<uint8_t> d_cat;
+        RT_TRY(d_desc.reserve(n)); RT_TRY(d_cat.reserve(soff[n] + 64));
+        RT_HIP(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n * sizeof(gather_desc), hipMemcpyHostToDevice, c->stream));
+        RT_TRY(launch_gather(c, d_desc.p, n, c->d_staged_seq.p, nullptr, d_cat.p, nullptr));
+        int rc = build_index(c, d_cat.p, soff.data(), n, k, P->is_rna ? 0 : 1);
+        RT_HIP(hipStreamSynchronize(c->stream));
+        d_desc.release(); d_cat.release();
+        if (rc) return rc;
+    } else {
+        std::unique_ptr<uint8_t[]> cat(new uint8_t[off[n] - off[0] + 1]);
+        {
+            phase_timer T("cluster: host gather");
+            const size_t chunk = 2048;
+            parallel_for((n + chunk - 1) / chunk, 0, [&](size_t ch) {
+                for (size_t i = ch * chunk; i < std::min<size_t>(n, (ch + 1) * chunk); ++i)
+                    memcpy(cat.get() + soff[i], seq + off[order[i]], soff[i + 1] - soff[i]);
+            });
+        }
+        phase_timer T("cluster: build_index");
+        RT_TRY(build_index(c, cat.get(), soff.data(), n, k, P->is_rna ? 0 : 1));
+    }
     { phase_timer T("cluster: greedy driver"); RT_TRY(cluster_driver(c, P, nullptr, 0, out)); }
     rattle_cluster_set *cs = *out;
     const uint32_t nm = cs->offsets[cs->n_clusters];

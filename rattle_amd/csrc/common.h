@@ -208,6 +208,11 @@ struct rattle_ctx {
     hipEvent_t poa_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t poa_go = nullptr;
     rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns
+    // reads staged in HBM by rattle_hip_stage_reads (keys: the host buffers they were copied from)
+    const uint8_t *staged_seq_key = nullptr, *staged_qual_key = nullptr;
+    uint32_t staged_n = 0;
+    uint64_t staged_total = 0;
+    rattle::dbuf<uint8_t> d_staged_seq, d_staged_qual;
     // post-MSA kernel constants (built on first use)
     rattle::phred_table phred;
     rattle::dbuf<double> d_phred_lo, d_perr;

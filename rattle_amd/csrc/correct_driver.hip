@@ -259,11 +259,15 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         // ---- reads -> HBM, oriented pack members gathered into stage 1 (:343-346)
         const uint64_t total_in = off[n_reads];
         dbuf<uint8_t> d_rseq, d_rqual;
-        {
-            phase_timer T("correct: upload + gather");
+        const uint8_t *dev_seq, *dev_qual;
+        if (ctx->staged_seq_key == seq && ctx->staged_qual_key == qual && ctx->staged_n == n_reads && ctx->staged_total == total_in && off[0] == 0) {
+            dev_seq = ctx->d_staged_seq.p; dev_qual = ctx->d_staged_qual.p;       // resident (rattle_hip_stage_reads)
+        } else {
+            phase_timer T("correct: upload");
             RT_TRY(d_rseq.reserve(total_in + 64)); RT_TRY(d_rqual.reserve(total_in + 64));
             RT_HIP(hipMemcpyAsync(d_rseq.p, seq, total_in, hipMemcpyHostToDevice, st));
             RT_HIP(hipMemcpyAsync(d_rqual.p, qual, total_in, hipMemcpyHostToDevice, st));
+            dev_seq = d_rseq.p; dev_qual = d_rqual.p;
         }
         std::vector<gather_desc> desc(n1);
         S1.off.assign(n1 + 1, 0);
@@ -275,7 +279,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         // ---- POA #1 (correct.cpp:398-405) + fix ends + correction (:407-409)
         {
             phase_timer T("correct: stage 1");
-            RT_TRY(run_stage(ctx, S1, desc, {gather_part{0, n1, d_rseq.p, d_rqual.p}}, 1, P, order, counters));
+            RT_TRY(run_stage(ctx, S1, desc, {gather_part{0, n1, dev_seq, dev_qual}}, 1, P, order, counters));
             RT_HIP(hipMemcpyAsync(olen.data(), S1.olen.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
             RT_HIP(hipMemcpyAsync(tfront.data(), S1.tfront.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
             RT_HIP(hipMemcpyAsync(tback.data(), S1.tback.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));

@@ -175,7 +175,7 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         RT_TRY(X.pc[s].reserve(n));
     }
     hipStream_t st = ctx->stream;
-    RT_HIP(hipMemcpyAsync(X.seq.p, seq, X.total_bases, hipMemcpyHostToDevice, st));
+    RT_HIP(hipMemcpyAsync(X.seq.p, seq, X.total_bases, hipMemcpyDefault, st));      // host buffer or a device-resident gather
     RT_HIP(hipMemcpyAsync(X.off.p, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(X.koff.p, X.h_koff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(X.len.p, X.h_len.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
