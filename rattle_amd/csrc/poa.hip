@@ -41,7 +41,7 @@ namespace rattle {
 #define POA_G (-8)
 #define POA_E (-6)
 #define POA_NEG (-(1 << 28))
-#define POA_STACK 1024
+#define POA_STACK 512
 #define POA_NONE 0xFFFFFFFFu
 
 // node record (uint4): x = letter | n_al << 8 | n_in << 16, y = first in-edge's begin node,
@@ -1190,7 +1190,7 @@ struct poa_variant {
 };
 #define POA_VARIANT(CPL, RING, NW) {CPL, RING, NW, &launch_poa<CPL, RING, NW>, &max_blocks_per_cu<CPL, RING, NW>}
 static const poa_variant k_latency[5] = {POA_VARIANT(4, 10, 4), POA_VARIANT(6, 10, 4), POA_VARIANT(8, 10, 4), POA_VARIANT(16, 0, 4), POA_VARIANT(24, 0, 4)};
-static const poa_variant k_throughput[3] = {POA_VARIANT(16, 8, 1), POA_VARIANT(12, 8, 2), POA_VARIANT(16, 8, 2)};
+static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2), POA_VARIANT(12, 10, 2), POA_VARIANT(16, 10, 2)};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
