@@ -855,36 +855,80 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                     for (uint32_t c = tid; c < L; c += NT) if ((int32_t)Hb[c] == best) { atomicMin(&s_bc[5], c + 1); break; }
                     __syncthreads();
                     const uint32_t bj = s_bc[5];
-                    if (tid == 0) {
+                    // Traceback by wave 0, in spoa's order of tests: diagonal (predecessors in in-edge order),
+                    // vertical (F extension before opening), horizontal.  The common move -- diagonal to the FIRST
+                    // predecessor -- is verified 16 steps at a time: the chain of first predecessors and the row
+                    // letters sit in LDS (areas idle here), lane t fetches the H cell of step t+1, and one
+                    // ballot tells how many consecutive steps hold; the first step that does not is replayed
+                    // by the general code (all lanes uniformly, lane 0 writes).  aln[] receives (row | -1, pos | -1);
+                    // rows become node ids in add_alignment.
+                    uint16_t *tq0 = (uint16_t *)S.done;                   // [n+1] row of the first in-edge (0: none / virtual)
+                    const uint32_t tb_bytes = (2u * ((A.node_cap + 31) / 32) + POA_STACK) * 4u + (uint32_t)RING * NT * (CPL / 2) * 4u + (uint32_t)RING * 16u;
+                    const bool fast_tb = 3u * (n + 2u) <= tb_bytes && n < 0xFFFFu;
+                    uint8_t *tlet = (uint8_t *)(tq0 + (n + 2u));          // [n+1] letter of the row's node
+                    if (fast_tb) {
+                        for (uint32_t r = 1 + tid; r <= n; r += NT) {
+                            const uint32_t info = S.plan[r - 1].x;
+                            tq0[r] = (uint16_t)(rd_nin(info) ? S.planb[r - 1].x : 0u);
+                            tlet[r] = (uint8_t)rd_letter(info);
+                        }
+                        if (tid == 0) { tq0[0] = 0; tlet[0] = 0; }
+                        __syncthreads();
+                    }
+                    if (w0) {
+                        const uint32_t lane = (uint32_t)tid;
                         uint32_t i = best_row, j = bj, cnt = 0, err = 0;
                         const int16_t *H = S.H, *F = S.F, *E = S.E;
                         auto Hat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? 0 : (int32_t)H[(uint64_t)r * Lp + c - 1]; };
                         auto Fat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? POA_NEG : (int32_t)F[(uint64_t)r * Lp + c - 1]; };
                         auto Eat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? POA_NEG : (int32_t)E[(uint64_t)r * Lp + c - 1]; };
-                        auto put = [&](int32_t node, int32_t pos) {
+                        auto put = [&](int32_t row, int32_t pos) {
                             if (cnt >= A.aln_cap) { err = POA_ERR_ALN; return; }
-                            S.aln[2 * cnt] = node; S.aln[2 * cnt + 1] = pos; ++cnt;
+                            if (lane == 0) { S.aln[2 * cnt] = row; S.aln[2 * cnt + 1] = pos; }
+                            ++cnt;
                         };
-                        // One dependent memory round trip per step in the common case: the H cells of the
-                        // first four predecessors at column j-1 are fetched together, along with the plan
-                        // records of the first predecessor (the usual next row); H(i,j) and the plan of row i
-                        // are carried from the previous step.  Order of the tests as in spoa: diagonal
-                        // (in-edge order), vertical (F extension before opening), horizontal.
                         int32_t Hij = best;
-                        uint4 pl = S.plan[i - 1], plb = S.planb[i - 1];
                         while (!err && Hij != 0) {                      // H != 0 implies i != 0 and j != 0
-                            bool found = false, ext_left = false, ext_up = false, have_next = false;
+                            if (fast_tb) {
+                                constexpr uint32_t K = 16;
+                                uint32_t my_i = 0, my_next = 0, cur = i;
+#pragma unroll
+                                for (uint32_t h = 0; h < K; ++h) {
+                                    const uint32_t nx = tq0[cur];
+                                    if (lane == h) { my_i = cur; my_next = nx; }
+                                    cur = nx;
+                                }
+                                const bool in = lane < K && j > lane;       // column of my step: j - lane >= 1
+                                const uint32_t my_j = in ? j - lane : 1u;
+                                int32_t c = 0;
+                                if (in && my_next != 0 && my_j > 1) c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2];
+                                const int32_t hcur = wave_shr1(c, Hij);     // H of my step's own cell = the cell lane-1 fetched
+                                const int32_t mc = tlet[my_i] == S.sq[my_j - 1] ? POA_M : POA_N;
+                                const bool ok = in && my_i != 0 && hcur != 0 && hcur == c + mc;
+                                const unsigned long long okm = __ballot(ok);
+                                const uint32_t m = (uint32_t)__builtin_ctzll(~okm);         // consecutive verified steps
+                                if (m) {
+                                    if (cnt + m > A.aln_cap) { err = POA_ERR_ALN; break; }
+                                    if (lane < m) { S.aln[2 * (cnt + lane)] = (int32_t)my_i; S.aln[2 * (cnt + lane) + 1] = (int32_t)(my_j - 1); }
+                                    cnt += m;
+                                    i = (uint32_t)__builtin_amdgcn_readlane((int)my_next, (int)(m - 1));
+                                    Hij = __builtin_amdgcn_readlane(c, (int)(m - 1));
+                                    j -= m;
+                                    if (m == K || Hij == 0) continue;
+                                }
+                            }
+                            // general step
+                            bool found = false, ext_left = false, ext_up = false;
                             uint32_t pi = 0, pj = 0;
                             int32_t Hn = 0;
-                            uint4 npl = make_uint4(0, 0, POA_NONE, 0), nplb = make_uint4(0, 0, 0, 0);
+                            const uint4 pl = S.plan[i - 1], plb = S.planb[i - 1];
                             const uint32_t n_in = rd_nin(pl.x);
                             const uint32_t npred = n_in ? n_in : 1u;
                             {
                                 const int32_t mc = rd_letter(pl.x) == S.sq[j - 1] ? POA_M : POA_N;
                                 const uint32_t q0 = n_in ? plb.x : 0u, q1 = npred > 1 ? plb.y : q0, q2 = npred > 2 ? plb.z : q0, q3 = npred > 3 ? plb.w : q0;
                                 const int32_t c0 = Hat(q0, j - 1), c1 = Hat(q1, j - 1), c2 = Hat(q2, j - 1), c3 = Hat(q3, j - 1);
-                                if (q0) { npl = S.plan[q0 - 1]; nplb = S.planb[q0 - 1]; }
-                                if (Hij == c0 + mc) { pi = q0; Hn = c0; found = true; have_next = q0 != 0; }
+                                if (Hij == c0 + mc) { pi = q0; Hn = c0; found = true; }
                                 else if (npred > 1 && Hij == c1 + mc) { pi = q1; Hn = c1; found = true; }
                                 else if (npred > 2 && Hij == c2 + mc) { pi = q2; Hn = c2; found = true; }
                                 else if (npred > 3 && Hij == c3 + mc) { pi = q3; Hn = c3; found = true; }
@@ -912,8 +956,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                                 if ((ext_left = (Hij == Eat(i, j - 1) + POA_E)) || Hij == Hat(i, j - 1) + POA_G) { pi = i; pj = j - 1; found = true; }
                             }
                             if (!found) { err = POA_ERR_GRAPH; break; }
-                            put(i == pi ? -1 : (int32_t)pl.y, j == pj ? -1 : (int32_t)(j - 1));
-                            const uint32_t oi = i;
+                            put(i == pi ? -1 : (int32_t)i, j == pj ? -1 : (int32_t)(j - 1));
                             i = pi; j = pj;
                             if (ext_left) {
                                 while (!err) {
@@ -934,19 +977,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                                         if (k < 4) p = u4_get(ulb, k); else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; }
                                         if ((stop = (Fij == Hat(p, j) + POA_G)) || Fij == Fat(p, j) + POA_E) { np = p; break; }
                                     }
-                                    put((int32_t)ul.y, -1);
+                                    put((int32_t)i, -1);
                                     i = np;
                                     if (stop || i == 0) break;
                                 }
                             }
-                            // state of the next step
                             if (diag) Hij = Hn; else Hij = Hat(i, j);
-                            if (i != oi && i != 0) {
-                                if (diag && have_next) { pl = npl; plb = nplb; }
-                                else { pl = S.plan[i - 1]; plb = S.planb[i - 1]; }
-                            }
                         }
-                        s_bc[0] = cnt; s_bc[1] = err;
+                        if (lane == 0) { s_bc[0] = cnt; s_bc[1] = err; }
                     }
                     __syncthreads();
                     n_aln = s_bc[0];
@@ -970,7 +1008,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
             uint8_t *kind = (uint8_t *)S.done;
             const bool use_kind = n_aln <= (((A.node_cap + 31) / 32) * 2 + POA_STACK) * 4;
             for (uint32_t f = tid; f < n_aln; f += NT) {
-                const int32_t an = S.aln[2 * (n_aln - 1 - f)], pos = S.aln[2 * (n_aln - 1 - f) + 1];
+                const int32_t ar = S.aln[2 * (n_aln - 1 - f)], pos = S.aln[2 * (n_aln - 1 - f) + 1];
+                const int32_t an = ar < 0 ? -1 : (int32_t)S.order[ar - 1];      // traceback recorded rows
                 uint4 inf = make_uint4(K_SKIP, 0, 0, 0);
                 if (pos != -1) {
                     if (an == -1) {
