@@ -107,25 +107,29 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
         return;
     }
     __syncthreads();
-    if (lane != 0) return;
 
     // ---- stage 2: similarity.cpp:10-31 patience LIS (strict on pos2, ceil-mid search) ---
+    // The tails tv[1..l] are strictly increasing, so the reference's binary search returns
+    // lo = 1 + #{idx <= l : tv[idx] < x}: the wave counts that with one read per 64 tails instead of
+    // ~log2(l) dependent reads by one lane.  The elements themselves stay sequential.
     const int M = (int)total;
     const int k = A.k;
     int l = 0;
-    m[0] = 0;
+    if (lane == 0) m[0] = 0;
     for (int i = 0; i < M; ++i) {
-        uint32_t x = pos2[i];
-        int lo = 1, hi = l;
-        while (lo <= hi) {
-            int mid = (lo + hi + 1) >> 1;
-            if (tv[mid] < x) lo = mid + 1; else hi = mid - 1;     // tv[mid] == pos2[m[mid]]
+        const uint32_t x = pos2[i];
+        int lt = 0;
+        for (int base = 0; base < l; base += 64) {
+            const int idx = base + (int)lane + 1;
+            const bool f = idx <= l && tv[idx] < x;
+            lt += (int)__popcll(__ballot(f));
         }
-        pp[i] = m[lo - 1];
-        m[lo] = (uint32_t)i;
-        tv[lo] = x;
+        const int lo = lt + 1;
+        if (lane == 0) { pp[i] = m[lo - 1]; m[lo] = (uint32_t)i; tv[lo] = x; }
         if (lo > l) l = lo;
+        __syncthreads();
     }
+    if (lane != 0) return;
     int bases = 0, hc = 0, nd = 0;
     double variance = 0.0;
     if (l > 0) {

@@ -7,6 +7,7 @@ import numpy as np
 from rattle_amd.api import Context, K_POA, MsaSet, _ptr, check, pack_reads
 
 LEN = int(sys.argv[1]); PACKS = int(sys.argv[2]); DEPTH = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+ERR = float(sys.argv[4]) if len(sys.argv) > 4 else 0.10      # total error rate (del : sub : ins = 3 : 4 : 3)
 rng = np.random.default_rng(5)
 ACGT = np.frombuffer(b"ACGT", np.uint8)
 distinct = []
@@ -14,10 +15,10 @@ for t in range(16):
     tx = ACGT[rng.integers(0, 4, LEN - 20 * t)]
     mem = []
     for _ in range(DEPTH):
-        r = rng.random(len(tx)); keep = r >= 0.03
-        s = tx.copy(); sub = (r >= 0.03) & (r < 0.07); s[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+        r = rng.random(len(tx)); keep = r >= 0.3 * ERR
+        s = tx.copy(); sub = (r >= 0.3 * ERR) & (r < 0.7 * ERR); s[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
         out = []
-        ins = rng.random(len(tx)) < 0.03
+        ins = rng.random(len(tx)) < 0.3 * ERR
         pieces = np.where(ins)[0]
         s2 = s[keep]
         # insertions: splice random bases at random places
