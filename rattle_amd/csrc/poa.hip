@@ -585,6 +585,235 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
     multi = X.multi != 0;
 }
 
+// ---- the same row recurrence on packed int16 pairs (classes up to 2048 columns) -------------------
+// Two columns per register (v_pk_add/max/min/sub_i16): H <= 5*2048, u = Hn + g - (j+1)e <= 22526 and
+// j*e >= -12288 all fit 16 bits; F never drops below g (every row has a predecessor with H >= 0, the
+// virtual one included) so -16384 can stand for "no F".  Shifted neighbours come from v_alignbit on
+// adjacent pairs (the left thread's last pair arrives by DPP), stores and ring words need no packing.
+// Same results as dp_rows, ~15 % fewer VALU instructions and half the register window.
+__device__ __forceinline__ s16x2 as_pk(uint32_t v) { s16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ uint32_t as_u(s16x2 v) { uint32_t r; __builtin_memcpy(&r, &v, 4); return r; }
+__device__ __forceinline__ s16x2 pk_splat(int v) { const s16x2 r = {(short)v, (short)v}; return r; }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+// (prev.hi, cur.lo): the pair one column to the left of `cur`
+__device__ __forceinline__ s16x2 pk_left(uint32_t cur, uint32_t prev) { return as_pk(__builtin_amdgcn_alignbit(cur, prev, 16)); }
+
+template <int CPL, int RINGN, int NW>
+__device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
+    constexpr int NT = 64 * NW, NP = CPL / 2;
+    static_assert(RINGN > 0 && NT * CPL <= 2048, "packed rows: ring classes only");
+    constexpr int NEGF = -16384;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t c0 = (uint32_t)tid * CPL;
+    const bool act = c0 < Lp;
+    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
+    {
+        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
+#pragma unroll
+        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
+#pragma unroll
+        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
+    }
+    s16x2 JE[NP], UC[NP];                        // per column: j*e and g - (j+1)*e
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int j0 = (int)c0 + 2 * u + 1, j1 = j0 + 1;
+        const s16x2 je = {(short)(j0 * POA_E), (short)(j1 * POA_E)};
+        const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
+        JE[u] = je; UC[u] = uc;
+    }
+    s16x2 HA[NP], FA[NP], HB[NP], FB[NP];        // the two register sets of "the previous row"
+#pragma unroll
+    for (int u = 0; u < NP; ++u) { HA[u] = pk_splat(0); FA[u] = pk_splat(NEGF); HB[u] = pk_splat(0); FB[u] = pk_splat(NEGF); }
+    uint32_t hlA = 0, hlB = 0;                   // H of the column left of the thread's block, in the HIGH half
+    uint32_t rowA = 0xFFFFFFFFu, rowB = 0xFFFFFFFFu;
+    int32_t lbest = 0;
+    uint32_t lrow = 0, lcnt = 0;
+    uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
+    uint32_t r0 = 0;
+
+    auto step = [&](const uint32_t i, const s16x2 (&HP)[NP], const s16x2 (&FP)[NP], const uint32_t hlP, const uint32_t rowP,
+                    s16x2 (&HN)[NP], s16x2 (&FN)[NP], uint32_t &hlN, uint32_t &rowN) __attribute__((always_inline)) {
+        const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
+        const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
+                                (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
+        const uint32_t row = r0 + i + 1;
+        const uint32_t par = row & 1u;
+        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+        s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
+        auto pred = [&](auto first_tag, const uint32_t prow) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            s16x2 HD[NP], FD[NP];
+            if (n_in == 0) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { HD[u] = pk_splat(0); FD[u] = pk_splat(POA_G - POA_E); }
+            } else if (prow == rowP) {
+                const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HP[NP - 1]), (int32_t)hlP);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    HD[u] = pk_left(as_u(HP[u]), u == 0 ? left : as_u(HP[u - 1]));
+                    FD[u] = pk_max(HP[u] + pk_splat(POA_G - POA_E), FP[u]);
+                }
+            } else if (row - prow <= (uint32_t)RINGN) {
+                const uint32_t slot = prow % (uint32_t)RINGN;
+                const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * NP;
+                uint32_t hp[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const uint32_t a = rp[u];
+                    hp[u] = a & 0x3FFF3FFFu;
+                    FD[u] = as_pk(hp[u]) - as_pk((a >> 14) & 0x00030003u);       // H - min(H-F, 2)
+                }
+                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], S.lh_ring[slot * 4 + wave]);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) HD[u] = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
+            } else {
+                uint32_t hp[NP], fp[NP];
+                uint32_t hl = 0;
+                if (act) {
+                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
+                    const uint32_t *fq = (const uint32_t *)(S.F + (uint64_t)prow * Lp + c0);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) { hp[u] = hq[u]; fp[u] = fq[u]; }
+                    if (lane == 0 && wave > 0) hl = (uint32_t)S.lh[prow * 4 + wave] << 16;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) { hp[u] = 0; fp[u] = as_u(pk_splat(NEGF)); }
+                }
+                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)hl);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    HD[u] = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
+                    FD[u] = pk_max(as_pk(hp[u]) + pk_splat(POA_G - POA_E), as_pk(fp[u]));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                HM[u] = FIRST ? HD[u] : pk_max(HM[u], HD[u]);
+                FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
+            }
+        };
+        pred(std::true_type{}, pw[0]);
+        if (n_in > 1) {
+            pred(std::false_type{}, pw[1]);
+            if (n_in > 2) {
+                pred(std::false_type{}, pw[2]);
+                if (n_in > 3) {
+                    pred(std::false_type{}, pw[3]);
+                    uint32_t e = more;
+                    for (uint32_t k = 4; k < n_in; ++k) {
+                        const uint2 ed = S.edges[e]; e = ed.y;
+                        pred(std::false_type{}, (uint32_t)S.rank[ed.x] + 1);
+                    }
+                }
+            }
+        }
+        // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
+        s16x2 HNp[NP], EX[NP];
+        s16x2 RUN = pk_splat(-32768);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+            const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+            FN[u] = FM[u] + pk_splat(POA_E);
+            HNp[u] = pk_max(pk_max(HM[u] + as_pk(pack16(s0, s1)), FN[u]), pk_splat(0));
+            const uint32_t uu = as_u(HNp[u] + UC[u]);
+            EX[u] = pk_max(RUN, as_pk((uu << 16) | 0x8000u));              // (run, max(run, u_a))
+            RUN = pk_max(RUN, pk_max(as_pk(uu), as_pk(__builtin_amdgcn_alignbit(uu, uu, 16))));
+        }
+        const int32_t run = (int32_t)(int16_t)(as_u(RUN) & 0xFFFFu);
+        const int32_t ex_last = (int32_t)as_u(EX[NP - 1]) >> 16, hn_last = (int32_t)as_u(HNp[NP - 1]) >> 16;
+        const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
+        const int32_t texcl = wave_shr1(wincl, POA_NEG);
+        int32_t base = POA_G - POA_E;            // u_0
+        int32_t hl_new = 0;
+        if (NW > 1) {
+            if (lane == 63) {
+                ((int32_t *)&X.T[par])[wave] = wincl;
+                if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex_last), hn_last);
+            }
+            row_barrier();
+            const int4 T = X.T[par];
+            const int2 q = X.Q[par][wave];
+            const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
+            const int32_t b0 = wave > 1 ? T.x : POA_NEG, b1 = wave > 2 ? T.y : POA_NEG;
+            base = max(max(base, t0), max(t1, t2));
+            if (wave > 0) {
+                const int32_t bp = max(max(POA_G - POA_E, b0), b1);
+                const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);
+                hl_new = max(q.y, max(bp, q.x) + c0w * POA_E);
+                if (lane == 0) S.lh[row * 4 + wave] = hl_new;
+            }
+        }
+        base = max(base, texcl);
+        const s16x2 BASE = as_pk(pack16(base, base));
+        s16x2 EV[NP];
+        s16x2 MX = pk_splat(0);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            EV[u] = pk_max(BASE, EX[u]) + JE[u];
+            HN[u] = pk_max(HNp[u], EV[u]);
+            MX = pk_max(MX, HN[u]);
+        }
+        hlN = (uint32_t)hl_new << 16; rowN = row;
+        {
+            const int32_t lm = max((int32_t)(int16_t)(as_u(MX) & 0xFFFFu), (int32_t)as_u(MX) >> 16);
+            const bool gt = lm > lbest, eq = lm == lbest;
+            lcnt = gt ? 1u : lcnt + (eq ? 1u : 0u);
+            lrow = gt ? row : lrow;
+            lbest = gt ? lm : lbest;
+        }
+        {
+            const uint32_t slot = row % (uint32_t)RINGN;
+            uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * NP;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) rp[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(2))) << 14);
+            if (lane == 0) S.lh_ring[slot * 4 + wave] = (int32_t)((uint32_t)hl_new << 16);
+        }
+        if (act) {
+            uint32_t pk[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) pk[u] = as_u(HN[u]);
+            store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, pk);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) pk[u] = as_u(FN[u]);
+            store_packed<CPL>(S.F + (uint64_t)row * Lp + c0, pk);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) pk[u] = as_u(EV[u]);
+            store_packed<CPL>(S.E + (uint64_t)row * Lp + c0, pk);
+        }
+    };
+
+    for (r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t nb = min(64u, n - r0);
+        my = make_uint4(0, 0, 0, 0); myb = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
+        for (uint32_t i = 0; i < nb; i += 2) {
+            step(i, HA, FA, hlA, rowA, HB, FB, hlB, rowB);
+            if (i + 1 < nb) step(i + 1, HB, FB, hlB, rowB, HA, FA, hlA, rowA);
+        }
+    }
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wave] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 0; X.ntl = 0; }
+    __syncthreads();
+    best = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
+    const bool mine = best > 0 && lbest == best;
+    if (mine) atomicMin(&X.brow, lrow);
+    __syncthreads();
+    best_row = best > 0 ? X.brow : 0u;
+    if (mine) {
+        if (lcnt != 1 || lrow != best_row) X.multi = 1;
+        const uint32_t slot = atomicAdd(&X.ntl, 1u);
+        if (slot < 16) X.tl[slot] = (uint32_t)tid;
+    }
+    __syncthreads();
+    multi = X.multi != 0;
+}
+
 // ---- graph update helpers (lane 0) --------------------------------------------------------------
 __device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
     if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return 0; }
@@ -634,8 +863,8 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
-template <int CPL, int RING, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL == 6 ? 4 : 1)) void poa_kernel(poa_args A) {
+template <int CPL, int RING, int NW, int PK>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW == 4 && CPL == 6 ? (PK ? 5 : 4) : 1)) void poa_kernel(poa_args A) {
     constexpr uint32_t NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
@@ -708,7 +937,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
                 bool multi = false;
-                dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
+                if constexpr (PK != 0) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
+                else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 cells += (unsigned long long)n * L;
                 rows += n;
                 unsigned long long t2 = PT_NOW();
@@ -1203,18 +1433,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? 5 : NW == 4 && CPL 
 }
 
 // ---- host side ------------------------------------------------------------------------------------
-template <int CPL, int RING, int NW>
+template <int CPL, int RING, int NW, int PK>
 static hipError_t launch_poa(const poa_args &A, uint32_t n_slots, size_t shm, hipStream_t st) {
     if (shm > 60 * 1024)
-        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, RING, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((poa_kernel<CPL, RING, NW>), dim3(n_slots), dim3(64 * NW), shm, st, A);
+        (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, RING, NW, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL((poa_kernel<CPL, RING, NW, PK>), dim3(n_slots), dim3(64 * NW), shm, st, A);
     return hipGetLastError();
 }
 
-template <int CPL, int RING, int NW>
+template <int CPL, int RING, int NW, int PK>
 static int max_blocks_per_cu(size_t shm) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, RING, NW>, 64 * NW, shm) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, RING, NW, PK>, 64 * NW, shm) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
@@ -1227,9 +1457,10 @@ struct poa_variant {
     hipError_t (*launch)(const poa_args &, uint32_t, size_t, hipStream_t);
     int (*max_blocks)(size_t);
 };
-#define POA_VARIANT(CPL, RING, NW) {CPL, RING, NW, &launch_poa<CPL, RING, NW>, &max_blocks_per_cu<CPL, RING, NW>}
-static const poa_variant k_latency[5] = {POA_VARIANT(4, 10, 4), POA_VARIANT(6, 10, 4), POA_VARIANT(8, 10, 4), POA_VARIANT(16, 0, 4), POA_VARIANT(24, 0, 4)};
-static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2), POA_VARIANT(12, 10, 2), POA_VARIANT(16, 10, 2)};
+#define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
+static const poa_variant k_latency[5] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0)};
+static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
+static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -1302,6 +1533,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         C[c].todo = by_class[c];
         C[c].V = &k_latency[c];
         if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
+        if (c < 3 && getenv("RATTLE_POA_UNPACKED")) C[c].V = &k_unpacked[c];
     }
     // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas.
     // The column classes of one round run concurrently on their own streams.
