@@ -632,6 +632,10 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     uint32_t lrow = 0, lcnt = 0;
     uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
     uint32_t r0 = 0;
+#ifdef POA_BARPROF
+    long long bar_cycles = 0;
+    const long long dp0 = clock64();
+#endif
 
     auto step = [&](const uint32_t i, const s16x2 (&HP)[NP], const s16x2 (&FP)[NP], const uint32_t hlP, const uint32_t rowP,
                     s16x2 (&HN)[NP], s16x2 (&FN)[NP], uint32_t &hlN, uint32_t &rowN) __attribute__((always_inline)) {
@@ -733,7 +737,13 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 ((int32_t *)&X.T[par])[wave] = wincl;
                 if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex_last), hn_last);
             }
+#ifdef POA_BARPROF
+            const long long tb0 = clock64();
+#endif
             row_barrier();
+#ifdef POA_BARPROF
+            bar_cycles += clock64() - tb0;
+#endif
             const int4 T = X.T[par];
             const int2 q = X.Q[par][wave];
             const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
@@ -794,6 +804,9 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             if (i + 1 < nb) step(i + 1, HB, FB, hlB, rowB, HA, FA, hlA, rowA);
         }
     }
+#ifdef POA_BARPROF
+    if (lane == 0) { atomicAdd(&S.hist[8 + wave], (unsigned long long)bar_cycles); atomicAdd(&S.hist[12 + wave], (unsigned long long)(clock64() - dp0)); }
+#endif
     const int32_t wb = wave_last(wave_scan_max(lbest, 0));
     if (lane == 0) X.best[wave] = wb;
     if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 0; X.ntl = 0; }
@@ -1661,6 +1674,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
 #ifdef POA_HIST
     fprintf(stderr, "[rattle] predecessor row distance histogram (first in-edge | further in-edges), d = 1..62, 63+:\n");
     for (int d = 1; d < 64; ++d) fprintf(stderr, "  d%-2d %12llu %12llu\n", d, h_hist[16 + d], h_hist[80 + d]);
+#endif
+#ifdef POA_BARPROF
+    fprintf(stderr, "[rattle] barrier cycles / dp cycles per wave: %.3f %.3f %.3f %.3f  (dp cycles per row, wave 0: %.0f)\n", (double)h_cnt[8] / h_cnt[12], (double)h_cnt[9] / h_cnt[13],
+            (double)h_cnt[10] / h_cnt[14], (double)h_cnt[11] / h_cnt[15], (double)h_cnt[12] / (double)h_cnt[3]);
 #endif
     ctx->stats[K_POA].bytes += 6ull * h_cnt[0];
     return 0;

@@ -71,3 +71,27 @@ def test_multi_segment_rows(gpu_ctx, oracle):
     rows, width, _ = gpu_ctx.poa_msa([pack])
     want, _ = oracle.poa_msa(pack)
     assert rows[0] == want
+
+
+@pytest.mark.parametrize("length,depth", [(700, 40), (1300, 30), (1800, 25), (2600, 16), (4500, 10)])
+def test_length_classes_match_oracle(gpu_ctx, oracle, length, depth):
+    """One pack per column class of kernel C (1024 / 1536 / 2048 packed int16 rows, 4096 / 6144 32-bit rows):
+    noisy copies (sub / ins / del) of one random transcript, deep enough for bubbles, ties and far predecessors."""
+    rng = np.random.default_rng(length)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    tx = acgt[rng.integers(0, 4, length)]
+    pack = []
+    for _ in range(depth):
+        r = rng.random(len(tx))
+        s = tx.copy()
+        sub = (r >= 0.03) & (r < 0.06)
+        s[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        s = s[r >= 0.03]
+        pos = np.sort(rng.integers(0, len(s) + 1, int(0.03 * len(s))))
+        s = np.insert(s, pos, acgt[rng.integers(0, 4, len(pos))])
+        pack.append(s[int(rng.integers(0, 30)):].tobytes())
+    pack.sort(key=lambda x: -len(x))
+    rows, width, counters = gpu_ctx.poa_msa([pack, pack[::-1]])
+    for got, p in zip(rows, (pack, pack[::-1])):
+        want, _ = oracle.poa_msa(p)
+        assert got == want
