@@ -65,6 +65,7 @@ struct poa_args {
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
     uint32_t lds_topo;             // 1: compact node topology (first in-edge, degrees) mirrored in LDS
+    uint32_t debug;                // tests: bit 0 = resolve ties with the full sort, bit 1 = traceback without the LDS fast path
     uint32_t *out_col;             // per base: node id during the run, MSA column at the end
     uint32_t *out_width;           // per pack
     uint32_t *status;              // per pack: 0 ok, else error code
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                         if (tid == 0) { atomicAdd(&A.counters[4], 1ull << 32); if (need_sort) atomicAdd(&A.counters[4], 1ull); }
 #endif
                     }
-                    if (need_sort && RING > 0 && n <= (uint32_t)RING * NT * CPL && S.n_nodes <= 0xFFFFu) {
+                    if (need_sort && RING > 0 && n <= (uint32_t)RING * NT * CPL && S.n_nodes <= 0xFFFFu && !(A.debug & 1u)) {
                         // labels instead of the full sort (tie_labels)
                         uint16_t *lab = (uint16_t *)S.ring;
                         for (uint32_t r = tid; r < n; r += NT) lab[r] = (uint16_t)S.order[r];
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                     // rows become node ids in add_alignment.
                     uint16_t *tq0 = (uint16_t *)S.done;                   // [n+1] row of the first in-edge (0: none / virtual)
                     const uint32_t tb_bytes = (2u * ((A.node_cap + 31) / 32) + POA_STACK) * 4u + (uint32_t)RING * NT * (CPL / 2) * 4u + (uint32_t)RING * 16u;
-                    const bool fast_tb = 3u * (n + 2u) <= tb_bytes && n < 0xFFFFu;
+                    const bool fast_tb = 3u * (n + 2u) <= tb_bytes && n < 0xFFFFu && !(A.debug & 2u);
                     uint8_t *tlet = (uint8_t *)(tq0 + (n + 2u));          // [n+1] letter of the row's node
                     if (fast_tb) {
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
@@ -1530,7 +1531,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     RT_TRY(d_heads.reserve(8));
     struct cls_plan {
         std::vector<uint32_t> todo;
-        uint32_t node_cap = 10240;
+        uint32_t node_cap = getenv("RATTLE_POA_NODE_CAP") ? (uint32_t)std::max(64, atoi(getenv("RATTLE_POA_NODE_CAP"))) : 10240u;   // first-round capacity (tests lower it to force re-runs)
         uint64_t cell_cap = 24ull << 20;           // elements per matrix
         poa_args A;
         uint64_t per_slot = 0;
@@ -1579,6 +1580,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
             A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
+            A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
             A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
             // LDS ring of the last RING rows (packed H|F, thread-private): 8 rows cost a block per CU and
             // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.

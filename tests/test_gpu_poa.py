@@ -95,3 +95,18 @@ def test_length_classes_match_oracle(gpu_ctx, oracle, length, depth):
     for got, p in zip(rows, (pack, pack[::-1])):
         want, _ = oracle.poa_msa(p)
         assert got == want
+
+
+@pytest.mark.parametrize("env", [{"RATTLE_POA_DEBUG": "1"}, {"RATTLE_POA_DEBUG": "2"}, {"RATTLE_POA_DEBUG": "3"},
+                                 {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_WAVES": "1"}, {"RATTLE_POA_UNPACKED": "1"}])
+def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
+    """The slow paths behind the fast ones stay exact: full topological sort for ties (bit 0), traceback without
+    the LDS chain (bit 1), packs re-run with a larger arena after a node-capacity overflow, two-wave and 32-bit
+    row kernels."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    packs = _packs_from_synth(400, 10, seed=11)
+    rows, width, counters = gpu_ctx.poa_msa(packs)
+    for p, pack in enumerate(packs):
+        want, _ = oracle.poa_msa(pack)
+        assert rows[p] == want, p
