@@ -43,6 +43,7 @@ namespace rattle {
 #define POA_NEG (-(1 << 28))
 #define POA_STACK 512
 #define POA_NONE 0xFFFFFFFFu
+#define POA_MAX_LEN (1u << 20)           // H <= 5 * length must stay far below 2^28 (POA_NEG)
 
 // node record (uint4): x = letter | n_al << 8 | n_in << 16, y = first in-edge's begin node,
 // z = head / w = tail of the list of further in-edges (indices into edges[]).
@@ -828,6 +829,109 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     multi = X.multi != 0;
 }
 
+// ---- rows longer than any register class (PK == 2): int32 cells, 1024-column segments ---------------
+// Reads beyond 6144 nt are rare (the tail of a cDNA run) but must not fail the call.  Same recurrence,
+// no register window and no ring: every predecessor row comes back from the int32 H / F matrices
+// (the column left of a thread's block too, so a full __syncthreads() orders the rows), a row is a
+// loop over segments of NT*4 columns, and the running prefix maximum of u is carried from segment to
+// segment.  Speed is not the point here.
+template <int NW>
+__device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row,
+                             bool &multi) {
+    constexpr int CPL = 4, NT = 64 * NW;
+    constexpr uint32_t SEG = (uint32_t)NT * CPL;
+    int32_t *H = (int32_t *)S.H, *F = (int32_t *)S.F, *E = (int32_t *)S.E;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t lbest = 0;
+    uint32_t lrow = 0, lcnt = 0, stepc = 0;
+    for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+        const uint32_t nb = min(64u, n - r0);
+        uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
+            const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
+                                    (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
+            const uint32_t row = r0 + i + 1;
+            const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+            int32_t carry = POA_G - POA_E;           // max of u over the columns of all previous segments (u_0 first)
+            int32_t rowmax = 0;
+            for (uint32_t seg0 = 0; seg0 < Lp; seg0 += SEG, ++stepc) {
+                const uint32_t par = stepc & 1u;
+                const uint32_t c0 = seg0 + (uint32_t)tid * CPL;
+                const bool act = c0 < Lp;
+                int32_t hm[CPL], fm[CPL];
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) { hm[t] = n_in ? POA_NEG : 0; fm[t] = n_in ? POA_NEG : POA_G - POA_E; }
+                uint32_t e = more;
+                for (uint32_t k = 0; k < n_in; ++k) {
+                    uint32_t prow;
+                    if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
+                    else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
+                    if (!act) continue;
+                    const int32_t *hp = H + (uint64_t)prow * Lp + c0, *fp = F + (uint64_t)prow * Lp + c0;
+                    const int4 h = *(const int4 *)hp, f = *(const int4 *)fp;
+                    const int32_t hleft = c0 ? hp[-1] : 0;
+                    hm[0] = max(hm[0], hleft); hm[1] = max(hm[1], h.x); hm[2] = max(hm[2], h.y); hm[3] = max(hm[3], h.z);
+                    fm[0] = max(fm[0], max(h.x + (POA_G - POA_E), f.x)); fm[1] = max(fm[1], max(h.y + (POA_G - POA_E), f.y));
+                    fm[2] = max(fm[2], max(h.z + (POA_G - POA_E), f.z)); fm[3] = max(fm[3], max(h.w + (POA_G - POA_E), f.w));
+                }
+                int32_t hn[CPL], fr[CPL], ex[CPL];
+                int32_t run = POA_NEG;
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const uint32_t col = c0 + t;
+                    const int32_t sc = (col < L ? s[col] : 0) == letter ? POA_M : POA_N;
+                    fr[t] = act ? fm[t] + POA_E : POA_G;
+                    hn[t] = act ? max(max(hm[t] + sc, fr[t]), 0) : 0;
+                    ex[t] = run;
+                    run = max(run, hn[t] + POA_G - ((int32_t)col + 2) * POA_E);
+                }
+                const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
+                const int32_t texcl = wave_shr1(wincl, POA_NEG);
+                if (lane == 63) ((int32_t *)&X.T[par])[wave] = wincl;
+                __syncthreads();                     // also orders this block's H / F stores of earlier rows
+                const int4 T = X.T[par];
+                const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
+                const int32_t base = max(max(max(carry, t0), max(t1, t2)), texcl);
+                int4 hv, ev;
+                ev.x = max(base, ex[0]) + ((int32_t)c0 + 1) * POA_E; ev.y = max(base, ex[1]) + ((int32_t)c0 + 2) * POA_E;
+                ev.z = max(base, ex[2]) + ((int32_t)c0 + 3) * POA_E; ev.w = max(base, ex[3]) + ((int32_t)c0 + 4) * POA_E;
+                hv.x = max(hn[0], ev.x); hv.y = max(hn[1], ev.y); hv.z = max(hn[2], ev.z); hv.w = max(hn[3], ev.w);
+                if (act) {
+                    *(int4 *)(H + (uint64_t)row * Lp + c0) = hv;
+                    *(int4 *)(F + (uint64_t)row * Lp + c0) = make_int4(fr[0], fr[1], fr[2], fr[3]);
+                    *(int4 *)(E + (uint64_t)row * Lp + c0) = ev;
+                    rowmax = max(rowmax, max(max(hv.x, hv.y), max(hv.z, hv.w)));
+                }
+                carry = max(max(carry, T.x), max(max(T.y, T.z), NW > 3 ? T.w : POA_NEG));
+            }
+            const bool gt = rowmax > lbest, eq = rowmax == lbest;
+            lcnt = gt ? 1u : lcnt + (eq ? 1u : 0u);
+            lrow = gt ? row : lrow;
+            lbest = gt ? rowmax : lbest;
+        }
+    }
+    __syncthreads();
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wave] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 0; X.ntl = 0; }
+    __syncthreads();
+    best = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
+    const bool mine = best > 0 && lbest == best;
+    if (mine) atomicMin(&X.brow, lrow);
+    __syncthreads();
+    best_row = best > 0 ? X.brow : 0u;
+    if (mine) {
+        if (lcnt != 1 || lrow != best_row) X.multi = 1;
+        X.ntl = 17;                                  // a thread's columns are spread over the segments: ties rescan whole rows
+    }
+    __syncthreads();
+    multi = X.multi != 0;
+}
+
 // ---- graph update helpers (lane 0) --------------------------------------------------------------
 __device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
     if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return 0; }
@@ -878,8 +982,9 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 }
 
 template <int CPL, int RING, int NW, int PK>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW == 4 && CPL == 6 ? (PK ? 5 : 4) : 1)) void poa_kernel(poa_args A) {
+__global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW == 4 && CPL == 6 ? (PK ? 5 : 4) : 1)) void poa_kernel(poa_args A) {
     constexpr uint32_t NT = 64 * NW;
+    using cell_t = typename std::conditional<PK == 2, int32_t, int16_t>::type;      // DP matrix cell
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
     __shared__ uint32_t s_bc[8];
@@ -926,7 +1031,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
             if (S.n_nodes > 0) {
                 const uint32_t n = S.n_nodes;
                 const uint32_t Lp = (L + CPL - 1) / CPL * CPL;
-                if ((uint64_t)(n + 1) * Lp > A.cell_cap || Lp > NT * CPL) { S.err = POA_ERR_CELLS; break; }
+                if ((uint64_t)(n + 1) * Lp > A.cell_cap || (PK != 2 && Lp > NT * CPL)) { S.err = POA_ERR_CELLS; break; }
                 // ---- 1. rows are taken in the incrementally maintained block order (merge_order) ----
                 unsigned long long t0 = PT_NOW();
                 // ---- 2. plan + sequence to LDS (all threads) ----
@@ -944,14 +1049,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                     S.plan[r] = make_uint4(rec.x, v, e, 0);
                     S.planb[r] = pr;
                 }
-                for (uint32_t t = tid; t < Lp; t += NT) S.sq[t] = t < L ? s[t] : 0;
+                if (PK != 2) for (uint32_t t = tid; t < Lp; t += NT) S.sq[t] = t < L ? s[t] : 0;       // long rows read the sequence in place
                 __syncthreads();
                 unsigned long long t1 = PT_NOW();
                 t_topo += t1 - t0;
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
                 bool multi = false;
-                if constexpr (PK != 0) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
+                if constexpr (PK == 2) dp_rows_long<NW>(S, X, s, n, L, Lp, best, best_row, multi);
+                else if constexpr (PK == 1) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 cells += (unsigned long long)n * L;
                 rows += n;
@@ -966,7 +1072,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                         for (uint32_t r = 1 + tid; r <= n; r += NT) S.rowmax[r] = 0;
                         __syncthreads();
                         const uint32_t ntl = X.ntl;
-                        if (ntl <= 16) {
+                        if (PK != 2 && ntl <= 16) {
                             for (uint32_t idx = tid; idx < n * ntl; idx += NT) {
                                 const uint32_t r = idx / ntl + 1, t = X.tl[idx % ntl];
                                 int32_t v[CPL];
@@ -978,7 +1084,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                             }
                         } else {
                             for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NW) {
-                                const int16_t *Hr = S.H + (uint64_t)r * Lp;
+                                const cell_t *Hr = (const cell_t *)S.H + (uint64_t)r * Lp;
                                 bool hit = false;
                                 for (uint32_t c = tid & 63; c < Lp; c += 64) hit |= (int32_t)Hr[c] == best;
                                 if (hit) S.rowmax[r] = 1;
@@ -1093,7 +1199,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
 #ifdef POA_PROFILE
                     t_tie += PT_NOW() - t2;
 #endif
-                    const int16_t *Hb = S.H + (uint64_t)best_row * Lp;
+                    const cell_t *Hb = (const cell_t *)S.H + (uint64_t)best_row * Lp;
                     if (tid == 0) s_bc[5] = 0xFFFFFFFFu;
                     __syncthreads();
                     for (uint32_t c = tid; c < L; c += NT) if ((int32_t)Hb[c] == best) { atomicMin(&s_bc[5], c + 1); break; }
@@ -1122,7 +1228,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                     if (w0) {
                         const uint32_t lane = (uint32_t)tid;
                         uint32_t i = best_row, j = bj, cnt = 0, err = 0;
-                        const int16_t *H = S.H, *F = S.F, *E = S.E;
+                        const cell_t *H = (const cell_t *)S.H, *F = (const cell_t *)S.F, *E = (const cell_t *)S.E;
                         auto Hat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? 0 : (int32_t)H[(uint64_t)r * Lp + c - 1]; };
                         auto Fat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? POA_NEG : (int32_t)F[(uint64_t)r * Lp + c - 1]; };
                         auto Eat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? POA_NEG : (int32_t)E[(uint64_t)r * Lp + c - 1]; };
@@ -1147,7 +1253,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                                 int32_t c = 0;
                                 if (in && my_next != 0 && my_j > 1) c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2];
                                 const int32_t hcur = wave_shr1(c, Hij);     // H of my step's own cell = the cell lane-1 fetched
-                                const int32_t mc = tlet[my_i] == S.sq[my_j - 1] ? POA_M : POA_N;
+                                const int32_t mc = tlet[my_i] == (PK == 2 ? s[my_j - 1] : S.sq[my_j - 1]) ? POA_M : POA_N;
                                 const bool ok = in && my_i != 0 && hcur != 0 && hcur == c + mc;
                                 const unsigned long long okm = __ballot(ok);
                                 const uint32_t m = (uint32_t)__builtin_ctzll(~okm);         // consecutive verified steps
@@ -1169,7 +1275,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW =
                             const uint32_t n_in = rd_nin(pl.x);
                             const uint32_t npred = n_in ? n_in : 1u;
                             {
-                                const int32_t mc = rd_letter(pl.x) == S.sq[j - 1] ? POA_M : POA_N;
+                                const int32_t mc = rd_letter(pl.x) == (PK == 2 ? s[j - 1] : S.sq[j - 1]) ? POA_M : POA_N;
                                 const uint32_t q0 = n_in ? plb.x : 0u, q1 = npred > 1 ? plb.y : q0, q2 = npred > 2 ? plb.z : q0, q3 = npred > 3 ? plb.w : q0;
                                 const int32_t c0 = Hat(q0, j - 1), c1 = Hat(q1, j - 1), c2 = Hat(q2, j - 1), c3 = Hat(q3, j - 1);
                                 if (Hij == c0 + mc) { pi = q0; Hn = c0; found = true; }
@@ -1472,7 +1578,8 @@ struct poa_variant {
     int (*max_blocks)(size_t);
 };
 #define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
-static const poa_variant k_latency[5] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0)};
+static const poa_variant k_latency[6] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0),
+                                         POA_VARIANT(4, 0, 4, 2) /* longer than 6144: int32 cells, segmented rows */};
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
 
@@ -1486,17 +1593,17 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     if (n_packs == 0 || n_seqs == 0) { for (uint32_t p = 0; p < n_packs; ++p) h_width_out[p] = 0; return 0; }
     if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
 
-    // length class of each pack: 1024 / 1536 / 2048 / 4096 / 6144 columns
+    // length class of each pack: 1024 / 1536 / 2048 / 4096 / 6144 columns, or longer (segmented int32 rows)
     std::vector<uint64_t> pbases(n_packs);
     std::vector<uint32_t> pmaxL(n_packs);
-    std::vector<uint32_t> by_class[5];
+    std::vector<uint32_t> by_class[6];
     for (uint32_t p = 0; p < n_packs; ++p) {
         uint32_t m = 0;
         for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) m = std::max<uint32_t>(m, (uint32_t)(off[q + 1] - off[q]));
         pbases[p] = off[pack_first[p + 1]] - off[pack_first[p]];
         pmaxL[p] = m;
-        if (m > 256u * 24u) { set_error("sequence too long for the int16 POA kernel (> 6144 nt)"); return RATTLE_ERR_ARG; }
-        by_class[m <= 1024 ? 0 : m <= 1536 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 3 : 4].push_back(p);
+        if (m > POA_MAX_LEN) { set_error("sequence longer than " + std::to_string(POA_MAX_LEN) + " nt in a POA pack"); return RATTLE_ERR_ARG; }
+        by_class[m <= 1024 ? 0 : m <= 1536 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 3 : m <= 6144 ? 4 : 5].push_back(p);
     }
 
     dbuf<uint32_t> d_pf, d_queue, d_status;
@@ -1522,7 +1629,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     int rc = 0;
     if (!ctx->poa_go) {
         RT_HIP(hipEventCreateWithFlags(&ctx->poa_go, hipEventDisableTiming));
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 6; ++i) {
             RT_HIP(hipStreamCreateWithFlags(&ctx->poa_st[i], hipStreamNonBlocking));
             RT_HIP(hipEventCreateWithFlags(&ctx->poa_ev[i], hipEventDisableTiming));
         }
@@ -1539,11 +1646,11 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         uint32_t n_slots = 0;
         int bpc = 1;
         const poa_variant *V = nullptr;
-    } C[5];
+    } C[6];
     // RATTLE_POA_WAVES=1 selects the one/two-wave variants (measured slower than four waves per pack even
     // with thousands of packs in flight: 353 vs 401 GCUPS at 1 kb, 395 vs 429 at 1.4 kb; kept for experiments)
     const int force_waves = getenv("RATTLE_POA_WAVES") ? atoi(getenv("RATTLE_POA_WAVES")) : 0;
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < 6; ++c) {
         C[c].todo = by_class[c];
         C[c].V = &k_latency[c];
         if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
@@ -1554,7 +1661,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     for (int round = 0; round < 6 && rc == 0; ++round) {
         bool any = false;
         uint64_t want_bytes = 0;
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < 6; ++c) {
             cls_plan &P = C[c];
             P.n_slots = 0;
             if (P.todo.empty()) continue;
@@ -1563,6 +1670,11 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             std::sort(P.todo.begin(), P.todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
             uint64_t tb = 0; uint32_t tl = 0;
             for (uint32_t p : P.todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
+            const bool long_rows = c == 5;     // int32 cells, sequence read in place (no LDS copy)
+            if (long_rows && round == 0) {     // long reads outgrow the default first-round capacities at once
+                P.node_cap = std::max<uint32_t>(P.node_cap, (uint32_t)std::min<uint64_t>(4ull * tl, 1u << 20));
+                P.cell_cap = std::max<uint64_t>(P.cell_cap, (uint64_t)(std::min<uint64_t>(P.node_cap, tb + 1) + 64) * (tl + 16));
+            }
             uint32_t ncap = (uint32_t)std::min<uint64_t>(P.node_cap, tb + 1);
             ncap = (ncap + 31u) & ~31u;
             const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
@@ -1577,17 +1689,19 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
             A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
             A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
-            A.o_H = take(ccap * 2); A.o_F = take(ccap * 2); A.o_E = take(ccap * 2);
+            const uint64_t cell_bytes = long_rows ? 4 : 2;
+            A.o_H = take(ccap * cell_bytes); A.o_F = take(ccap * cell_bytes); A.o_E = take(ccap * cell_bytes);
             A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
             A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
             A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
             // LDS ring of the last RING rows (packed H|F, thread-private): 8 rows cost a block per CU and
             // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.
-            P.shm = (size_t)qcap + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)P.V->ring * 64 * P.V->nw * cpl * 2 + (size_t)P.V->ring * 16 + 64;
+            const uint32_t lds_seq = long_rows ? 16u : qcap;
+            P.shm = (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)P.V->ring * 64 * P.V->nw * cpl * 2 + (size_t)P.V->ring * 16 + 64;
             P.bpc = P.V->max_blocks(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
-            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = qcap;
+            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = lds_seq;
             want_bytes += P.per_slot * P.n_slots;
         }
         if (!any) break;
@@ -1595,7 +1709,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (want_bytes > budget) {             // scale every class down proportionally (at least one slot each)
             const double f = (double)budget / (double)want_bytes;
             want_bytes = 0;
-            for (int c = 0; c < 5; ++c) if (C[c].n_slots) {
+            for (int c = 0; c < 6; ++c) if (C[c].n_slots) {
                 C[c].n_slots = std::max<uint32_t>(1, (uint32_t)(C[c].n_slots * f));
                 want_bytes += C[c].per_slot * C[c].n_slots;
             }
@@ -1610,7 +1724,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         hipError_t e = hipMemsetAsync(d_heads.p, 0, 32, st);
         uint64_t aoff = 0;
         uint32_t qoff = 0;
-        for (int c = 0; c < 5 && e == hipSuccess; ++c) {
+        for (int c = 0; c < 6 && e == hipSuccess; ++c) {
             cls_plan &P = C[c];
             if (!P.n_slots) continue;
             e = hipMemcpyAsync(d_queue.p + qoff, P.todo.data(), P.todo.size() * 4, hipMemcpyHostToDevice, st);
@@ -1628,7 +1742,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         {
             ktimer T(ctx, K_POA, 0);
             e = hipEventRecord(ctx->poa_go, st);
-            for (int c = 0; c < 5 && e == hipSuccess; ++c) {
+            for (int c = 0; c < 6 && e == hipSuccess; ++c) {
                 cls_plan &P = C[c];
                 if (!P.n_slots) continue;
                 hipStream_t cs = ctx->poa_st[c];
@@ -1642,7 +1756,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
-        for (int c = 0; c < 5 && rc == 0; ++c) {
+        for (int c = 0; c < 6 && rc == 0; ++c) {
             cls_plan &P = C[c];
             if (!P.n_slots) continue;
             std::vector<uint32_t> again;
@@ -1659,7 +1773,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     d_heads.release();
     if (rc == 0) {
         size_t left = 0;
-        for (int c = 0; c < 5; ++c) left += C[c].todo.size();
+        for (int c = 0; c < 6; ++c) left += C[c].todo.size();
         if (left) { set_error("poa: " + std::to_string(left) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
     if (rc == 0) {

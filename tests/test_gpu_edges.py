@@ -74,7 +74,33 @@ def test_poa_unalignable_and_single_sequence_packs(gpu_ctx, oracle):
         assert rows[p] == want
 
 
-def test_sequence_longer_than_kernel_limit_is_an_error(gpu_ctx):
+def test_reads_longer_than_the_register_classes(gpu_ctx, oracle):
+    """Reads beyond 6144 nt take the segmented int32 rows of kernel C (rare tail of a cDNA run); mixed with
+    short packs in one call, and a pack whose first read alone exceeds the first-round node capacity."""
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def noisy(tx, n):
+        out = []
+        for _ in range(n):
+            r = rng.random(len(tx))
+            s = tx.copy()
+            sub = (r >= 0.02) & (r < 0.05)
+            s[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+            s = s[r >= 0.02]
+            pos = np.sort(rng.integers(0, len(s) + 1, int(0.02 * len(s))))
+            out.append(np.insert(s, pos, acgt[rng.integers(0, 4, len(pos))]).tobytes())
+        return sorted(out, key=lambda x: -len(x))
+
+    packs = [noisy(acgt[rng.integers(0, 4, 7000)], 5), noisy(acgt[rng.integers(0, 4, 900)], 12),
+             noisy(acgt[rng.integers(0, 4, 12500)], 3)]
+    rows, width, _ = gpu_ctx.poa_msa(packs)
+    for p, pack in enumerate(packs):
+        want, _ = oracle.poa_msa(pack)
+        assert rows[p] == want, p
+
+
+def test_absurdly_long_sequence_is_an_error(gpu_ctx):
     from rattle_amd._lib import RattleError
     with pytest.raises(RattleError):
-        gpu_ctx.poa_msa([[b"ACGT" * 1600, b"ACGT" * 1600]])      # 6400 nt > 6144
+        gpu_ctx.poa_msa([[b"ACGT" * 300000, b"ACGT" * 300000]])      # 1.2 Mnt > POA_MAX_LEN
