@@ -80,3 +80,25 @@ def test_staged_reads_give_identical_results(gpu_ctx):
     assert cl_a.as_list() == cl_b.as_list()
     assert res_a[:3] == res_b[:3] == res_c[:3] and res_a[4] == res_b[4] == res_c[4]
     assert np.array_equal(res_a[3][:3], res_b[3][:3])
+
+
+def test_correct_with_a_cluster_of_long_reads(gpu_ctx, oracle):
+    """A cluster of ~7 kb reads (segmented int32 POA rows) next to ordinary ones, through cluster + correct."""
+    rng = np.random.default_rng(23)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs, quals, _, _ = synth.reads(150, 3, 1, True, seed=2)
+    tx = acgt[rng.integers(0, 4, 7000)]
+    for _ in range(8):
+        r = rng.random(len(tx))
+        s = tx.copy()
+        sub = (r >= 0.02) & (r < 0.05)
+        s[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        s = s[r >= 0.02]
+        seqs.append(s.tobytes())
+        quals.append(bytes(rng.integers(40, 70, len(s)).astype(np.uint8)))
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    assert any(len(mem) >= 8 and len(seqs[mem[0][0]]) > 6144 for _, mem in clusters)
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters)
+    want = oracle.correct(headers, seqs, quals, hps.encode(clusters))
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
