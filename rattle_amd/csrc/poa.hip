@@ -373,6 +373,8 @@ struct dp_xchg {                 // LDS
 template <int CPL, int RINGN, int NW>
 __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
     constexpr int NT = 64 * NW;
+    constexpr bool WIDE = NT * CPL > 2048;       // H may need 15 bits: the ring takes a dword per cell (H | min(H-F,2) << 16)
+    constexpr int RW = WIDE ? CPL : CPL / 2;     // ring dwords per thread and row
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t c0 = (uint32_t)tid * CPL;
     const bool act = c0 < Lp;
@@ -423,13 +425,22 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                 }
             } else if (RINGN > 0 && row - prow <= (uint32_t)RINGN) {
                 const uint32_t slot = prow % (uint32_t)(RINGN > 0 ? RINGN : 1);
-                const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
+                const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * RW;
                 int32_t hp[CPL];
+                if (WIDE) {
 #pragma unroll
-                for (int u = 0; u < CPL / 2; ++u) {
-                    const uint32_t a = rp[u];
-                    hp[2 * u] = (int32_t)(a & 0x3FFFu); hp[2 * u + 1] = (int32_t)((a >> 16) & 0x3FFFu);
-                    fd[2 * u] = hp[2 * u] - (int32_t)((a >> 14) & 3u); fd[2 * u + 1] = hp[2 * u + 1] - (int32_t)(a >> 30);   // H - min(H-F, 2)
+                    for (int t = 0; t < CPL; ++t) {
+                        const uint32_t a = rp[t];
+                        hp[t] = (int32_t)(a & 0xFFFFu);
+                        fd[t] = hp[t] - (int32_t)(a >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CPL / 2; ++u) {
+                        const uint32_t a = rp[u];
+                        hp[2 * u] = (int32_t)(a & 0x3FFFu); hp[2 * u + 1] = (int32_t)((a >> 16) & 0x3FFFu);
+                        fd[2 * u] = hp[2 * u] - (int32_t)((a >> 14) & 3u); fd[2 * u + 1] = hp[2 * u + 1] - (int32_t)(a >> 30);   // H - min(H-F, 2)
+                    }
                 }
                 const int32_t hleft = wave_shr1(hp[CPL - 1], S.lh_ring[slot * 4 + wave]);
 #pragma unroll
@@ -537,16 +548,21 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
         }
         if (RINGN > 0) {
             const uint32_t slot = row % (uint32_t)(RINGN > 0 ? RINGN : 1);
-            uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * (CPL / 2);
+            uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * RW;
+            if (WIDE) {
 #pragma unroll
-            for (int u = 0; u < CPL / 2; ++u) {
-                s16x2 hh, ff;
-                __builtin_memcpy(&hh, &pkH[u], 4); __builtin_memcpy(&ff, &pkF[u], 4);
-                const s16x2 two = {2, 2};
-                const s16x2 d = __builtin_elementwise_min(hh - ff, two);
-                uint32_t dw;
-                __builtin_memcpy(&dw, &d, 4);
-                rp[u] = pkH[u] | (dw << 14);
+                for (int t = 0; t < CPL; ++t) rp[t] = (uint32_t)hN[t] | ((uint32_t)min(hN[t] - fr[t], 2) << 16);
+            } else {
+#pragma unroll
+                for (int u = 0; u < CPL / 2; ++u) {
+                    s16x2 hh, ff;
+                    __builtin_memcpy(&hh, &pkH[u], 4); __builtin_memcpy(&ff, &pkF[u], 4);
+                    const s16x2 two = {2, 2};
+                    const s16x2 d = __builtin_elementwise_min(hh - ff, two);
+                    uint32_t dw;
+                    __builtin_memcpy(&dw, &d, 4);
+                    rp[u] = pkH[u] | (dw << 14);
+                }
             }
             if (lane == 0) S.lh_ring[slot * 4 + wave] = hl_new;
         }
@@ -1005,7 +1021,7 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (CPL / 2));
+        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (NT * CPL > 2048 ? CPL : CPL / 2));
         S.topo = nullptr;
     }
 
@@ -1578,8 +1594,9 @@ struct poa_variant {
     int (*max_blocks)(size_t);
 };
 #define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
-static const poa_variant k_latency[6] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0),
+static const poa_variant k_latency[6] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(16, 4, 4, 0), POA_VARIANT(24, 5, 4, 0),
                                          POA_VARIANT(4, 0, 4, 2) /* longer than 6144: int32 cells, segmented rows */};
+static const poa_variant k_noring[2] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
 
@@ -1671,9 +1688,11 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             uint64_t tb = 0; uint32_t tl = 0;
             for (uint32_t p : P.todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
             const bool long_rows = c == 5;     // int32 cells, sequence read in place (no LDS copy)
-            if (long_rows && round == 0) {     // long reads outgrow the default first-round capacities at once
-                P.node_cap = std::max<uint32_t>(P.node_cap, (uint32_t)std::min<uint64_t>(4ull * tl, 1u << 20));
-                P.cell_cap = std::max<uint64_t>(P.cell_cap, (uint64_t)(std::min<uint64_t>(P.node_cap, tb + 1) + 64) * (tl + 16));
+            if (round == 0 && !getenv("RATTLE_POA_NODE_CAP")) {
+                // first-round capacity: a pack of ~200 reads at 10 % error grows to ~5 nodes per base of its
+                // longest read; packs that still outgrow it are re-run with 4x nodes
+                P.node_cap = std::max<uint32_t>(P.node_cap, (uint32_t)std::min<uint64_t>(6ull * tl, 1u << 20));
+                P.cell_cap = std::max<uint64_t>(P.cell_cap, (uint64_t)(std::min<uint64_t>(P.node_cap, tb + 1) + 64) * (tl + 32));
             }
             uint32_t ncap = (uint32_t)std::min<uint64_t>(P.node_cap, tb + 1);
             ncap = (ncap + 31u) & ~31u;
@@ -1698,7 +1717,12 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             // LDS ring of the last RING rows (packed H|F, thread-private): 8 rows cost a block per CU and
             // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.
             const uint32_t lds_seq = long_rows ? 16u : qcap;
-            P.shm = (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)P.V->ring * 64 * P.V->nw * cpl * 2 + (size_t)P.V->ring * 16 + 64;
+            auto lds_bytes = [&](const poa_variant *V) {
+                const size_t cell = 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
+                return (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 16 + 64;
+            };
+            if ((c == 3 || c == 4) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 3];
+            P.shm = lds_bytes(P.V);
             P.bpc = P.V->max_blocks(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
             A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = lds_seq;
@@ -1735,8 +1759,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             aoff += P.per_slot * P.n_slots;
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
-                fprintf(stderr, "[rattle]     poa class %u cols (%u waves x %u) round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, round, P.todo.size(), P.n_slots, P.per_slot / 1e6, P.bpc);
+                fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, ring %u) round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
+                        c == 5 ? "> 6144: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, round, P.todo.size(), P.n_slots,
+                        P.per_slot / 1e6, P.bpc);
         }
         if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
         {
