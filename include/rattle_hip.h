@@ -121,6 +121,12 @@ int rattle_hip_cluster_reads(rattle_ctx *ctx, const rattle_cluster_params *param
  * second level, main.cpp:281-318).  Ids in the result are positions in `subset`. */
 int rattle_hip_cluster_subset(rattle_ctx *ctx, const rattle_cluster_params *params, const uint32_t *subset,
                               uint32_t n_subset, rattle_cluster_set **out);
+/* Several subsets in one call (all gene clusters of the --iso level): subset i is
+ * subset_ids[subset_offsets[i] .. subset_offsets[i+1]); outs[i] receives its clusters.  The subsets
+ * are independent, so they run concurrently on n_workers host threads (0: default) with one stream
+ * each.  Results are identical to n_subsets calls of rattle_hip_cluster_subset. */
+int rattle_hip_cluster_subsets(rattle_ctx *ctx, const rattle_cluster_params *params, const uint32_t *subset_ids,
+                               const uint64_t *subset_offsets, uint32_t n_subsets, rattle_cluster_set **outs, int n_workers);
 /* The `rattle cluster` flow around cluster_reads for reads in FILE order (main.cpp:254-277):
  * stable length-descending sort (sort_read_set, fasta.cpp:458-464), index, gene-level
  * cluster_reads, then ids translated back to positions in the caller's order. */

@@ -153,6 +153,18 @@ class Context:
         self.lib.rattle_hip_cluster_set_free(out)
         return res
 
+    def cluster_subsets(self, subsets: Sequence[np.ndarray], t_s=0.2, t_v=1000000.0, bv_threshold=0.4, min_bv_threshold=0.2,
+                        bv_falloff=0.05, repr_percentile=0.15, is_rna=False, n_workers=0) -> List[Clusters]:
+        """cluster_reads restricted to each subset (ids in processing order), all subsets in one call."""
+        P = ClusterParams(t_s, t_v, bv_threshold, min_bv_threshold, bv_falloff, 0, 0, repr_percentile, int(is_rna))
+        n = len(subsets)
+        offs = np.zeros(n + 1, np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in subsets])
+        ids = np.concatenate([np.asarray(x, np.uint32) for x in subsets]) if n and offs[n] else np.zeros(1, np.uint32)
+        outs = (C.POINTER(ClusterSet) * max(n, 1))()
+        check(self.lib.rattle_hip_cluster_subsets(self.h, C.byref(P), _ptr(ids, C.c_uint32), _ptr(offs, C.c_uint64), n, outs, n_workers))
+        return [self._take_clusters(outs[i]) for i in range(n)]
+
     def _take_clusters(self, out) -> Clusters:
         cs = out.contents
         nc = cs.n_clusters
@@ -305,15 +317,17 @@ def cluster_command(ctx: Context, seqs: Sequence[bytes], ann: Sequence[int], *, 
     ctx.load_reads(sseqs, iso_k, not is_rna)
     out = []
     counters = gene.counters.copy()
-    for gi, (m, mem) in enumerate(gl):
+    subsets = []
+    for m, mem in gl:
         ids = [s[0] for s in mem]
         ids.sort(key=lambda x: -x)                                       # main.cpp:285-291
         ids.sort(key=lambda x: -len(sseqs[x]))
-        sub = ctx.cluster_reads(iso_t_s, iso_t_v, bv_threshold, bv_min_threshold, bv_falloff, 0, False,
-                                repr_percentile, is_rna, subset=np.array(ids, np.uint32))
+        subsets.append(np.array(ids, np.uint32))
+    subs = ctx.cluster_subsets(subsets, iso_t_s, iso_t_v, bv_threshold, bv_min_threshold, bv_falloff, repr_percentile, is_rna)
+    for gi, (ids, sub) in enumerate(zip(subsets, subs)):
         counters += sub.counters
         for im, imem in sub.as_list():
-            out.append(((sann[ids[im[0]]], im[1], gi), [(sann[ids[s[0]]], s[1], gi) for s in imem]))
+            out.append(((sann[int(ids[im[0]])], im[1], gi), [(sann[int(ids[s[0]])], s[1], gi) for s in imem]))
     return out, counters
 
 

@@ -183,6 +183,78 @@ int rattle_hip_cluster_subset(rattle_ctx *c, const rattle_cluster_params *P, con
     return cluster_driver(c, P, n_subset ? subset : &none, n_subset, out);
 }
 
+// Many independent subsets at once (the --iso second level: one subset per gene cluster).  Small
+// problems are launch- and synchronisation-bound, so worker threads run the unchanged greedy driver on
+// child contexts (own stream and scratch buffers, the parent's read index shared read-only) and the
+// device overlaps their kernels.
+int rattle_hip_cluster_subsets(rattle_ctx *c, const rattle_cluster_params *P, const uint32_t *ids, const uint64_t *sub_off,
+                               uint32_t n_subsets, rattle_cluster_set **outs, int n_workers) {
+    if (!c || !P || !outs || !sub_off || (n_subsets && sub_off[n_subsets] && !ids)) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    for (uint32_t i = 0; i < n_subsets; ++i) outs[i] = nullptr;
+    for (uint64_t i = 0; i < sub_off[n_subsets]; ++i) if (ids[i] >= c->idx.n) { set_error("subset id out of range"); return RATTLE_ERR_ARG; }
+    RT_HIP(hipSetDevice(c->device));
+    if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
+    RT_HIP(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> order(n_subsets);                       // largest subsets first
+    for (uint32_t i = 0; i < n_subsets; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const uint64_t la = sub_off[a + 1] - sub_off[a], lb = sub_off[b + 1] - sub_off[b];
+        return la != lb ? la > lb : a < b;
+    });
+    const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(n_subsets, n_workers > 0 ? (uint32_t)n_workers : 16u));
+    std::atomic<uint32_t> next(0);
+    std::atomic<int> rc_all(0);
+    std::mutex err_mu;
+    std::string err_msg;
+    auto worker = [&]() {
+        static const uint32_t none = 0;
+        int rc = 0;
+        rattle_ctx *k = new rattle_ctx();
+        k->device = c->device;
+        k->timing = false;
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&k->ev0) != hipSuccess || hipEventCreate(&k->ev1) != hipSuccess) {
+            set_error("worker stream/event creation failed");
+            rc = RATTLE_ERR_HIP;
+        }
+        if (rc == 0) {
+            read_index &X = k->idx;                              // shared, read-only view of the parent's index
+            const read_index &Y = c->idx;
+            X.n = Y.n; X.k = Y.k; X.both = Y.both; X.total_bases = Y.total_bases; X.total_kmers = Y.total_kmers;
+            X.h_len = Y.h_len;
+            X.seq = Y.seq; X.off = Y.off; X.koff = Y.koff; X.len = Y.len; X.uh = Y.uh;
+            for (int s = 0; s < 2; ++s) { X.kh[s] = Y.kh[s]; X.kp[s] = Y.kp[s]; X.bv[s] = Y.bv[s]; X.pc[s] = Y.pc[s]; }
+            for (uint32_t t = next++; t < n_subsets && rc == 0 && rc_all.load() == 0; t = next++) {
+                const uint32_t i = order[t];
+                const uint32_t n = (uint32_t)(sub_off[i + 1] - sub_off[i]);
+                rc = cluster_driver(k, P, n ? ids + sub_off[i] : &none, n, &outs[i]);
+            }
+        }
+        if (rc != 0) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (rc_all.load() == 0) { rc_all = rc; err_msg = rattle_hip_last_error(); }
+        }
+        if (k->stream) (void)hipStreamSynchronize(k->stream);
+        k->d_seed.release(); k->d_cand.release(); k->d_first.release(); k->d_lut.release(); k->d_pass.release();
+        k->d_surv.release(); k->d_counter.release(); k->d_pi.release(); k->d_pj.release(); k->d_ps.release();
+        k->d_res.release(); k->d_var.release(); k->d_scratch.release();
+        k->h_surv.release(); k->h_res.release(); k->h_var.release(); k->h_counter.release();
+        if (k->ev0) (void)hipEventDestroy(k->ev0);
+        if (k->ev1) (void)hipEventDestroy(k->ev1);
+        if (k->stream) (void)hipStreamDestroy(k->stream);
+        delete k;                                                // the index buffers belong to the parent
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; ++t) th.emplace_back(worker);
+    for (auto &x : th) x.join();
+    if (rc_all.load() != 0) {
+        for (uint32_t i = 0; i < n_subsets; ++i) { rattle_hip_cluster_set_free(outs[i]); outs[i] = nullptr; }
+        set_error(err_msg);
+        return rc_all.load();
+    }
+    return 0;
+}
+
 int rattle_hip_stage_reads(rattle_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n) {
     if (!c || !off || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
     RT_HIP(hipSetDevice(c->device));

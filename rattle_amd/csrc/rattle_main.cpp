@@ -319,17 +319,22 @@ int mode_cluster(int argc, char **argv) {
     load(ctx, reads, iso_k, !is_rna);
     P.t_s = a.d("iso_t_s", 0.3); P.t_v = a.d("iso_t_v", 25);
     cluster_set_t iso;
-    int gi = 0;
+    // all gene clusters at once: the subsets are independent (rattle_hip_cluster_subsets runs them concurrently)
+    std::vector<uint32_t> ids;
+    std::vector<uint64_t> sub_off(1, 0);
     for (auto &c : gene) {
         std::stable_sort(c.seqs.begin(), c.seqs.end(), [](const cseq_t &x, const cseq_t &y) { return x.seq_id > y.seq_id; });
         std::stable_sort(c.seqs.begin(), c.seqs.end(), [&reads](const cseq_t &x, const cseq_t &y) {
             return reads[x.seq_id].seq.size() > reads[y.seq_id].seq.size();
         });
-        std::vector<uint32_t> subset;
-        for (auto &s : c.seqs) subset.push_back((uint32_t)s.seq_id);
-        rattle_cluster_set *sub = nullptr;
-        chk(rattle_hip_cluster_subset(ctx, &P, subset.data(), (uint32_t)subset.size(), &sub));
-        for (auto &ic : to_set(sub)) {
+        for (auto &s : c.seqs) ids.push_back((uint32_t)s.seq_id);
+        sub_off.push_back(ids.size());
+    }
+    std::vector<rattle_cluster_set *> subs(gene.size() ? gene.size() : 1, nullptr);
+    chk(rattle_hip_cluster_subsets(ctx, &P, ids.data(), sub_off.data(), (uint32_t)gene.size(), subs.data(), 0));
+    int gi = 0;
+    for (auto &c : gene) {
+        for (auto &ic : to_set(subs[gi])) {
             cluster_t o;
             o.main_seq = cseq_t{std::stoi(reads[c.seqs[ic.main_seq.seq_id].seq_id].ann), ic.main_seq.rev, gi};
             for (auto &s : ic.seqs) o.seqs.push_back(cseq_t{std::stoi(reads[c.seqs[s.seq_id].seq_id].ann), s.rev, gi});
