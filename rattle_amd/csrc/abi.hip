@@ -65,7 +65,7 @@ void rattle_hip_ctx_destroy(rattle_ctx *c) {
     c->d_surv.release(); c->d_counter.release(); c->d_pi.release(); c->d_pj.release(); c->d_ps.release();
     c->d_res.release(); c->d_var.release(); c->d_scratch.release();
     if (c->poa_arena) (void)hipFree(c->poa_arena);
-    for (int i = 0; i < 6; ++i) { if (c->poa_st[i]) (void)hipStreamDestroy(c->poa_st[i]); if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]); }
+    for (int i = 0; i < 7; ++i) { if (c->poa_st[i]) (void)hipStreamDestroy(c->poa_st[i]); if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]); }
     if (c->poa_go) (void)hipEventDestroy(c->poa_go);
     c->h_poa_col.release();
     c->d_staged_seq.release(); c->d_staged_qual.release();

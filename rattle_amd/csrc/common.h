@@ -204,8 +204,8 @@ struct rattle_ctx {
     // POA arena: kept across stages and calls (allocating ~100 GB costs seconds)
     uint8_t *poa_arena = nullptr;
     size_t poa_arena_bytes = 0;
-    hipStream_t poa_st[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // one per column class: classes run concurrently
-    hipEvent_t poa_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t poa_st[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // one per column class: classes run concurrently
+    hipEvent_t poa_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t poa_go = nullptr;
     rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns
     // reads staged in HBM by rattle_hip_stage_reads (keys: the host buffers they were copied from)

@@ -603,9 +603,9 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
     multi = X.multi != 0;
 }
 
-// ---- the same row recurrence on packed int16 pairs (classes up to 2048 columns) -------------------
-// Two columns per register (v_pk_add/max/min/sub_i16): H <= 5*2048, u = Hn + g - (j+1)e <= 22526 and
-// j*e >= -12288 all fit 16 bits; F never drops below g (every row has a predecessor with H >= 0, the
+// ---- the same row recurrence on packed int16 pairs (classes up to 2560 columns) -------------------
+// Two columns per register (v_pk_add/max/min/sub_i16): H <= 5*2560, u = Hn + g - (j+1)e <= 28158 and
+// j*e >= -15360 all fit 16 bits (H < 2^14 for the ring word); F never drops below g (every row has a predecessor with H >= 0, the
 // virtual one included) so -16384 can stand for "no F".  Shifted neighbours come from v_alignbit on
 // adjacent pairs (the left thread's last pair arrives by DPP), stores and ring words need no packing.
 // Same results as dp_rows, ~15 % fewer VALU instructions and half the register window.
@@ -620,7 +620,7 @@ __device__ __forceinline__ s16x2 pk_left(uint32_t cur, uint32_t prev) { return a
 template <int CPL, int RINGN, int NW>
 __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
     constexpr int NT = 64 * NW, NP = CPL / 2;
-    static_assert(RINGN > 0 && NT * CPL <= 2048, "packed rows: ring classes only");
+    static_assert(RINGN > 0 && NT * CPL <= 2560, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
     constexpr int NEGF = -16384;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t c0 = (uint32_t)tid * CPL;
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (NT * CPL > 2048 ? CPL : CPL / 2));
+        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (PK != 1 && NT * CPL > 2048 ? CPL : CPL / 2));
         S.topo = nullptr;
     }
 
@@ -1589,13 +1589,16 @@ static int max_blocks_per_cu(size_t shm) {
 // (small inputs: fewer packs than the device has room for); one or two waves per pack need no (or a
 // cheaper) per-row rendezvous and leave room for more packs per CU (large inputs: throughput).
 struct poa_variant {
-    uint32_t cpl, ring, nw;
+    uint32_t cpl, ring, nw, pk;
     hipError_t (*launch)(const poa_args &, uint32_t, size_t, hipStream_t);
     int (*max_blocks)(size_t);
 };
-#define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
-static const poa_variant k_latency[6] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(16, 4, 4, 0), POA_VARIANT(24, 5, 4, 0),
-                                         POA_VARIANT(4, 0, 4, 2) /* longer than 6144: int32 cells, segmented rows */};
+#define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, PK, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
+#define POA_CLASSES 7
+static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144};
+static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(10, 8, 4, 1),
+                                                   POA_VARIANT(16, 4, 4, 0), POA_VARIANT(24, 5, 4, 0),
+                                                   POA_VARIANT(4, 0, 4, 2) /* longer than 6144: int32 cells, segmented rows */};
 static const poa_variant k_noring[2] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
@@ -1610,17 +1613,19 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     if (n_packs == 0 || n_seqs == 0) { for (uint32_t p = 0; p < n_packs; ++p) h_width_out[p] = 0; return 0; }
     if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
 
-    // length class of each pack: 1024 / 1536 / 2048 / 4096 / 6144 columns, or longer (segmented int32 rows)
+    // length class of each pack: 1024 / 1536 / 2048 / 2560 / 4096 / 6144 columns, or longer (segmented int32 rows)
     std::vector<uint64_t> pbases(n_packs);
     std::vector<uint32_t> pmaxL(n_packs);
-    std::vector<uint32_t> by_class[6];
+    std::vector<uint32_t> by_class[POA_CLASSES];
     for (uint32_t p = 0; p < n_packs; ++p) {
         uint32_t m = 0;
         for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) m = std::max<uint32_t>(m, (uint32_t)(off[q + 1] - off[q]));
         pbases[p] = off[pack_first[p + 1]] - off[pack_first[p]];
         pmaxL[p] = m;
         if (m > POA_MAX_LEN) { set_error("sequence longer than " + std::to_string(POA_MAX_LEN) + " nt in a POA pack"); return RATTLE_ERR_ARG; }
-        by_class[m <= 1024 ? 0 : m <= 1536 ? 1 : m <= 2048 ? 2 : m <= 4096 ? 3 : m <= 6144 ? 4 : 5].push_back(p);
+        int cls = 0;
+        while (cls < POA_CLASSES - 1 && m > k_class_cols[cls]) ++cls;
+        by_class[cls].push_back(p);
     }
 
     dbuf<uint32_t> d_pf, d_queue, d_status;
@@ -1646,7 +1651,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     int rc = 0;
     if (!ctx->poa_go) {
         RT_HIP(hipEventCreateWithFlags(&ctx->poa_go, hipEventDisableTiming));
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < POA_CLASSES; ++i) {
             RT_HIP(hipStreamCreateWithFlags(&ctx->poa_st[i], hipStreamNonBlocking));
             RT_HIP(hipEventCreateWithFlags(&ctx->poa_ev[i], hipEventDisableTiming));
         }
@@ -1663,11 +1668,11 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         uint32_t n_slots = 0;
         int bpc = 1;
         const poa_variant *V = nullptr;
-    } C[6];
+    } C[POA_CLASSES];
     // RATTLE_POA_WAVES=1 selects the one/two-wave variants (measured slower than four waves per pack even
     // with thousands of packs in flight: 353 vs 401 GCUPS at 1 kb, 395 vs 429 at 1.4 kb; kept for experiments)
     const int force_waves = getenv("RATTLE_POA_WAVES") ? atoi(getenv("RATTLE_POA_WAVES")) : 0;
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < POA_CLASSES; ++c) {
         C[c].todo = by_class[c];
         C[c].V = &k_latency[c];
         if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
@@ -1678,7 +1683,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     for (int round = 0; round < 6 && rc == 0; ++round) {
         bool any = false;
         uint64_t want_bytes = 0;
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < POA_CLASSES; ++c) {
             cls_plan &P = C[c];
             P.n_slots = 0;
             if (P.todo.empty()) continue;
@@ -1687,7 +1692,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             std::sort(P.todo.begin(), P.todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
             uint64_t tb = 0; uint32_t tl = 0;
             for (uint32_t p : P.todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
-            const bool long_rows = c == 5;     // int32 cells, sequence read in place (no LDS copy)
+            const bool long_rows = c == POA_CLASSES - 1;     // int32 cells, sequence read in place (no LDS copy)
             if (round == 0 && !getenv("RATTLE_POA_NODE_CAP")) {
                 // first-round capacity: a pack of ~200 reads at 10 % error grows to ~5 nodes per base of its
                 // longest read; packs that still outgrow it are re-run with 4x nodes
@@ -1718,10 +1723,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.
             const uint32_t lds_seq = long_rows ? 16u : qcap;
             auto lds_bytes = [&](const poa_variant *V) {
-                const size_t cell = 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
+                const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
                 return (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 16 + 64;
             };
-            if ((c == 3 || c == 4) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 3];
+            if ((c == 4 || c == 5) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 4];
             P.shm = lds_bytes(P.V);
             P.bpc = P.V->max_blocks(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
@@ -1733,7 +1738,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (want_bytes > budget) {             // scale every class down proportionally (at least one slot each)
             const double f = (double)budget / (double)want_bytes;
             want_bytes = 0;
-            for (int c = 0; c < 6; ++c) if (C[c].n_slots) {
+            for (int c = 0; c < POA_CLASSES; ++c) if (C[c].n_slots) {
                 C[c].n_slots = std::max<uint32_t>(1, (uint32_t)(C[c].n_slots * f));
                 want_bytes += C[c].per_slot * C[c].n_slots;
             }
@@ -1748,7 +1753,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         hipError_t e = hipMemsetAsync(d_heads.p, 0, 32, st);
         uint64_t aoff = 0;
         uint32_t qoff = 0;
-        for (int c = 0; c < 6 && e == hipSuccess; ++c) {
+        for (int c = 0; c < POA_CLASSES && e == hipSuccess; ++c) {
             cls_plan &P = C[c];
             if (!P.n_slots) continue;
             e = hipMemcpyAsync(d_queue.p + qoff, P.todo.data(), P.todo.size() * 4, hipMemcpyHostToDevice, st);
@@ -1760,14 +1765,14 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
                 fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, ring %u) round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        c == 5 ? "> 6144: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, round, P.todo.size(), P.n_slots,
+                        c == POA_CLASSES - 1 ? "> 6144: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, round, P.todo.size(), P.n_slots,
                         P.per_slot / 1e6, P.bpc);
         }
         if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
         {
             ktimer T(ctx, K_POA, 0);
             e = hipEventRecord(ctx->poa_go, st);
-            for (int c = 0; c < 6 && e == hipSuccess; ++c) {
+            for (int c = 0; c < POA_CLASSES && e == hipSuccess; ++c) {
                 cls_plan &P = C[c];
                 if (!P.n_slots) continue;
                 hipStream_t cs = ctx->poa_st[c];
@@ -1781,7 +1786,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
-        for (int c = 0; c < 6 && rc == 0; ++c) {
+        for (int c = 0; c < POA_CLASSES && rc == 0; ++c) {
             cls_plan &P = C[c];
             if (!P.n_slots) continue;
             std::vector<uint32_t> again;
@@ -1798,7 +1803,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     d_heads.release();
     if (rc == 0) {
         size_t left = 0;
-        for (int c = 0; c < 6; ++c) left += C[c].todo.size();
+        for (int c = 0; c < POA_CLASSES; ++c) left += C[c].todo.size();
         if (left) { set_error("poa: " + std::to_string(left) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
     if (rc == 0) {
