@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "common.h"
 
@@ -255,6 +256,10 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     std::vector<uint8_t> cons2, cons3;               // consensi of stage 2b+3a / 3b, concatenated at the stage's coff
     std::vector<std::string> cl_cons(n_clusters);
     stage S2a, S2, S3;
+    dbuf<uint8_t> d_os, d_oq;                        // corrected reads, compacted on the device
+    std::thread d2h;
+    hipError_t d2h_err = hipSuccess;
+    struct joiner { std::thread &t; ~joiner() { if (t.joinable()) t.join(); } } d2h_join{d2h};      // also on error returns
     if (n_packs) {
         // ---- reads -> HBM, oriented pack members gathered into stage 1 (:343-346)
         const uint64_t total_in = off[n_reads];
@@ -316,14 +321,22 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             C.off[nc] = tot;
             if (nc) {
                 dbuf<gather_desc> d_od;
-                dbuf<uint8_t> d_os, d_oq;
                 RT_TRY(d_od.reserve(nc)); RT_TRY(d_os.reserve(tot + 64)); RT_TRY(d_oq.reserve(tot + 64));
                 RT_HIP(hipMemcpyAsync(d_od.p, od.data(), nc * sizeof(gather_desc), hipMemcpyHostToDevice, st));
                 RT_TRY(launch_gather(ctx, d_od.p, (uint32_t)nc, S1.rowc.p, S1.rowq.p, d_os.p, d_oq.p));
-                RT_HIP(hipMemcpyAsync(C.seq, d_os.p, tot, hipMemcpyDeviceToHost, st));
-                RT_HIP(hipMemcpyAsync(C.qual, d_oq.p, tot, hipMemcpyDeviceToHost, st));
                 RT_HIP(hipStreamSynchronize(st));
-                d_od.release(); d_os.release(); d_oq.release();
+                d_od.release();
+                // the download (2 GB at 1e6 reads, pageable destination) runs on a helper thread and the
+                // copy engine while the following POA stages compute
+                char *dst_s = C.seq, *dst_q = C.qual;
+                const uint8_t *src_s = d_os.p, *src_q = d_oq.p;
+                const int dev = ctx->device;
+                d2h = std::thread([=, &d2h_err]() {
+                    hipError_t e = hipSetDevice(dev);
+                    if (e == hipSuccess) e = hipMemcpy(dst_s, src_s, tot, hipMemcpyDeviceToHost);
+                    if (e == hipSuccess) e = hipMemcpy(dst_q, src_q, tot, hipMemcpyDeviceToHost);
+                    d2h_err = e;
+                });
             }
         }
         // reads whose corrected sequence came out empty: uncorrected, as fix_msa_ends left them (:289-293)
@@ -430,6 +443,9 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     } else {
         fill_set(R->corrected, {}, {}, {});
     }
+    if (d2h.joinable()) d2h.join();
+    d_os.release(); d_oq.release();
+    if (d2h_err != hipSuccess) { set_error(std::string("corrected reads download: ") + hipGetErrorString(d2h_err)); return RATTLE_ERR_HIP; }
     std::vector<hread> consensi;
     std::vector<int32_t> con_cid, con_n;
     for (uint32_t c = 0; c < n_clusters; ++c) {
