@@ -18,11 +18,14 @@
 
 namespace rattle {
 
+#define PS_EXTRA 384            // LDS words ahead of the hash list: bit-vector + search queue
+
 struct ps_args {
     const uint32_t *uh;          // forward hashes, position order
     const uint64_t *koff;
     const uint32_t *kh[2];
     const uint32_t *kp[2];
+    const uint64_t *bv[2];       // 4096-bit vectors of the 6-mers (prefilter of the hash search)
     const uint32_t *pi, *pj;
     const uint8_t *ps;
     uint32_t n_pairs;
@@ -57,8 +60,9 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     const uint32_t *__restrict__ bh_g = A.kh[strand] + A.koff[rj];
     const uint32_t *__restrict__ bp_g = A.kp[strand] + A.koff[rj];
 
-    // LDS carve: [B hashes bcap][pos1 mcap][pos2 mcap][m mcap+1 (+pad)][tv mcap+1 (+pad)][p mcap]
-    uint32_t *s_bh = lds;
+    // LDS carve: [B bit-vector 128][queue pos 128][queue hash 128][B hashes bcap][pos1 mcap][pos2 mcap][m mcap+1 (+pad)][tv mcap+1 (+pad)][p mcap]
+    uint32_t *s_bv = lds, *s_qp = lds + 128, *s_qh = lds + 256;
+    uint32_t *s_bh = lds + PS_EXTRA;
     uint32_t cap;
     uint32_t *pos1, *pos2, *m, *tv, *pp;
     if (A.gscratch) {
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
         pos1 = g; pos2 = pos1 + cap + 2; m = pos2 + cap + 2; tv = m + cap + 2; pp = tv + cap + 2;
     } else {
         cap = A.mcap;
-        pos1 = lds + A.bcap; pos2 = pos1 + cap; m = pos2 + cap; tv = m + cap + 2; pp = tv + cap + 2;
+        pos1 = s_bh + A.bcap; pos2 = pos1 + cap; m = pos2 + cap; tv = m + cap + 2; pp = tv + cap + 2;
     }
     const bool b_lds = nB <= A.bcap;
     if (b_lds) {
@@ -77,12 +81,22 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     const uint32_t *bh = b_lds ? (const uint32_t *)s_bh : bh_g;
 
     // ---- stage 1: matches in (pos1,pos2) order --------------------------------------
+    // A k-mer of i can only occur in j if its leading 6-mer is in j's 4096-bit vector (k >= 6): the positions
+    // that pass are queued (order kept) and searched 64 at a time, so unrelated reads -- most pairs -- cost
+    // about a quarter of the searches.
+    const bool pre = A.k >= 6 && nB > 0;
+    const int sh = 2 * (A.k - 6);
+    if (pre) {
+        const uint32_t *bvj = (const uint32_t *)(A.bv[strand] + (uint64_t)rj * 64);
+        for (uint32_t t = lane; t < 128; t += 64) s_bv[t] = bvj[t];
+        __syncthreads();
+    }
     uint32_t total = 0;
-    for (uint32_t base = 0; base < nA; base += 64) {
-        uint32_t p1 = base + lane;
-        uint32_t cnt = 0, lo = 0;
-        if (p1 < nA && nB > 0) {
-            uint32_t h = ah[p1];
+    auto drain = [&](const uint32_t count) {             // search queue entries [0, count), count <= 64
+        uint32_t p1 = 0, cnt = 0, lo = 0;
+        if ((uint32_t)lane < count) {
+            p1 = s_qp[lane];
+            const uint32_t h = s_qh[lane];
             uint32_t a = 0, b = nB;                    // lower_bound
             while (a < b) {
                 uint32_t mid = (a + b) >> 1;
@@ -100,7 +114,36 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
             for (uint32_t t = 0; t < cnt; ++t) { pos1[at + t] = p1; pos2[at + t] = bp_g[lo + t]; }
         }
         total += tot;
+    };
+    uint32_t qn = 0;
+    for (uint32_t base = 0; base < nA && nB > 0; base += 64) {
+        const uint32_t p1 = base + lane;
+        bool keep = false;
+        uint32_t h = 0;
+        if (p1 < nA) {
+            h = ah[p1];
+            const uint32_t six = h >> sh;
+            keep = !pre || ((s_bv[six >> 5] >> (six & 31)) & 1u);
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const uint32_t at = qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            s_qp[at] = p1; s_qh[at] = h;
+        }
+        qn += (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (qn >= 64) {
+            drain(64);
+            const uint32_t rem = qn - 64;
+            uint32_t tp = 0, th = 0;
+            if ((uint32_t)lane < rem) { tp = s_qp[64 + lane]; th = s_qh[64 + lane]; }
+            __syncthreads();
+            if ((uint32_t)lane < rem) { s_qp[lane] = tp; s_qh[lane] = th; }
+            __syncthreads();
+            qn = rem;
+        }
     }
+    if (qn) drain(qn);
     int32_t *out = A.res + (uint64_t)pr * 4;
     if (total > cap) {                                  // oversize: host reruns with global scratch
         if (lane == 0) { out[0] = INT32_MIN; out[1] = 0; out[2] = 0; out[3] = (int32_t)total; A.var[pr] = 0.0; }
@@ -178,12 +221,13 @@ int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs) {
     ps_args A;
     A.uh = X.uh.p; A.koff = X.koff.p;
     A.kh[0] = X.kh[0].p; A.kp[0] = X.kp[0].p; A.kh[1] = X.kh[1].p; A.kp[1] = X.kp[1].p;
+    A.bv[0] = X.bv[0].p; A.bv[1] = X.bv[1].p;
     A.pi = ctx->d_pi.p; A.pj = ctx->d_pj.p; A.ps = ctx->d_ps.p;
     A.n_pairs = n_pairs; A.k = X.k;
     A.bcap = 2048; A.mcap = 512;
     A.res = ctx->d_res.p; A.var = ctx->d_var.p;
     A.gscratch = nullptr; A.gstride = 0; A.remap = nullptr;
-    size_t shm = (A.bcap + 5 * (size_t)A.mcap + 8) * 4;
+    size_t shm = (PS_EXTRA + A.bcap + 5 * (size_t)A.mcap + 8) * 4;
     // algorithmic bytes are accounted by the caller (needs the pair list on the host)
     ktimer T(ctx, K_SCORE, 0);
     hipLaunchKernelGGL(pair_score_kernel, dim3(n_pairs), dim3(64), shm, ctx->stream, A);
@@ -211,13 +255,14 @@ int launch_pair_score_oversize(rattle_ctx *ctx, const std::vector<uint32_t> &slo
         ps_args A;
         A.uh = X.uh.p; A.koff = X.koff.p;
         A.kh[0] = X.kh[0].p; A.kp[0] = X.kp[0].p; A.kh[1] = X.kh[1].p; A.kp[1] = X.kp[1].p;
+        A.bv[0] = X.bv[0].p; A.bv[1] = X.bv[1].p;
         A.pi = ctx->d_pi.p; A.pj = ctx->d_pj.p; A.ps = ctx->d_ps.p;
         A.n_pairs = m; A.k = X.k;
         A.bcap = 2048; A.mcap = 0;
         A.res = ctx->d_res.p; A.var = ctx->d_var.p;
         A.gscratch = ctx->d_scratch.p; A.gstride = stride; A.remap = d_remap.p + b;
         ktimer T(ctx, K_SCORE, 0);
-        hipLaunchKernelGGL(pair_score_kernel, dim3(m), dim3(64), (A.bcap + 8) * 4, ctx->stream, A);
+        hipLaunchKernelGGL(pair_score_kernel, dim3(m), dim3(64), (PS_EXTRA + A.bcap + 8) * 4, ctx->stream, A);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error(std::string("pair_score(oversize) launch: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
     }
