@@ -153,18 +153,33 @@ struct driver {
         // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic
         const double t_s = P->t_s, t_v = P->t_v;
         uint64_t alg_bytes = 0;
-        for (uint32_t p = 0; p < nsurv; ++p) {
-            uint32_t a = ctx->h_surv.p[2 * (size_t)p], c = ctx->h_surv.p[2 * (size_t)p + 1];
-            uint32_t s = a >> 1;
-            const int32_t *r = ctx->h_res.p + 4 * (size_t)p;
-            counters[2] += (uint64_t)r[3];
-            uint32_t li = rlen(seeds[s]), lj = rlen(cands[c]);
-            alg_bytes += 8ull * ((li > (uint32_t)ctx->idx.k ? li - ctx->idx.k : 0) + (lj > (uint32_t)ctx->idx.k ? lj - ctx->idx.k : 0));
-            double mn = (double)std::min<size_t>(li, lj);
-            double score = P->use_hc ? double(r[1]) / mn : double(r[0]) / mn;
-            if (score >= t_s) {
-                if (ctx->h_var.p[p] < t_v) hits.push_back(hit_t{s, c, (uint8_t)(a & 1u)});
+        // tens of millions of survivors per level-2 round: chunks in parallel, hits concatenated in pair order
+        const uint32_t chunk = 1u << 16;
+        const uint32_t n_chunks = (nsurv + chunk - 1) / chunk;
+        std::vector<std::vector<hit_t>> part(n_chunks);
+        std::vector<uint64_t> part_matches(n_chunks, 0), part_bytes(n_chunks, 0);
+        parallel_for(n_chunks, n_chunks > 1 ? 0 : 1, [&](size_t ch) {
+            uint64_t mt = 0, ab = 0;
+            const uint32_t p1 = std::min<uint32_t>(nsurv, (uint32_t)(ch + 1) * chunk);
+            for (uint32_t p = (uint32_t)ch * chunk; p < p1; ++p) {
+                uint32_t a = ctx->h_surv.p[2 * (size_t)p], c = ctx->h_surv.p[2 * (size_t)p + 1];
+                uint32_t s = a >> 1;
+                const int32_t *r = ctx->h_res.p + 4 * (size_t)p;
+                mt += (uint64_t)r[3];
+                uint32_t li = rlen(seeds[s]), lj = rlen(cands[c]);
+                ab += 8ull * ((li > (uint32_t)ctx->idx.k ? li - ctx->idx.k : 0) + (lj > (uint32_t)ctx->idx.k ? lj - ctx->idx.k : 0));
+                double mn = (double)std::min<size_t>(li, lj);
+                double score = P->use_hc ? double(r[1]) / mn : double(r[0]) / mn;
+                if (score >= t_s) {
+                    if (ctx->h_var.p[p] < t_v) part[ch].push_back(hit_t{s, c, (uint8_t)(a & 1u)});
+                }
             }
+            part_matches[ch] = mt; part_bytes[ch] = ab;
+        });
+        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+            hits.insert(hits.end(), part[ch].begin(), part[ch].end());
+            counters[2] += part_matches[ch];
+            alg_bytes += part_bytes[ch];
         }
         ctx->stats[K_SCORE].bytes += alg_bytes;
         return 0;
@@ -273,7 +288,7 @@ int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32
             if (owner[i] == i) { slot[i] = (int32_t)clusters.size(); clusters.push_back(cl{{(int32_t)i, 0}, {cseq{(int32_t)i, 0}}}); }
         for (uint32_t i = 0; i < n; ++i)
             if (owner[i] != i) clusters[slot[owner[i]]].seqs.push_back(cseq{(int32_t)i, rev[i]});
-        for (auto &c : clusters) c.main = D.get_main_seq(c.seqs, P->repr_percentile);
+        parallel_for(clusters.size(), 0, [&](size_t i) { clusters[i].main = D.get_main_seq(clusters[i].seqs, P->repr_percentile); });
     }
     // ---- merge passes, cluster.cpp:171-256
     double thr = P->bv_threshold - P->bv_falloff;
@@ -286,7 +301,7 @@ int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32
         std::vector<cl> merged;
         std::vector<int32_t> slot(nc, -1);
         for (uint32_t i = 0; i < nc; ++i)
-            if (owner[i] == i) { slot[i] = (int32_t)merged.size(); merged.push_back(cl{{0, 0}, {}}); merged.back().seqs = clusters[i].seqs; }
+            if (owner[i] == i) { slot[i] = (int32_t)merged.size(); merged.push_back(cl{{0, 0}, {}}); merged.back().seqs = std::move(clusters[i].seqs); }
         for (uint32_t i = 0; i < nc; ++i) {
             if (owner[i] == i) continue;
             cl &dst = merged[slot[owner[i]]];
@@ -295,7 +310,7 @@ int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32
                 dst.seqs.push_back(s);
             }
         }
-        for (auto &c : merged) c.main = D.get_main_seq(c.seqs, P->repr_percentile);
+        parallel_for(merged.size(), 0, [&](size_t i) { merged[i].main = D.get_main_seq(merged[i].seqs, P->repr_percentile); });
         clusters.swap(merged);
         if (last) break;
         thr -= P->bv_falloff;                             // :251-255
