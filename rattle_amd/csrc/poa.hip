@@ -65,7 +65,6 @@ struct poa_args {
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
-    uint32_t lds_topo;             // 1: compact node topology (first in-edge, degrees) mirrored in LDS
     uint32_t debug;                // tests: bit 0 = resolve ties with the full sort, bit 1 = traceback without the LDS fast path
     uint32_t *out_col;             // per base: node id during the run, MSA column at the end
     uint32_t *out_width;           // per pack
@@ -98,7 +97,6 @@ struct poa_ws {                    // per-block workspace: global pointers + LDS
     unsigned long long *hist;
     uint32_t *ring;                        // LDS: last RING rows of packed H|F per thread (thread-private)
     int32_t *lh_ring;                      // LDS: left-column H of the last RING rows per wave
-    uint32_t *topo;                        // LDS: in0 | min(n_in,63) << 20 | n_al << 26 per node, or nullptr
     uint8_t *sq;                           // LDS copy of the sequence, 16-byte aligned
     uint32_t n_nodes, n_edges, sp, spilled, err;
 };
@@ -108,10 +106,6 @@ __device__ __forceinline__ void bit_set(uint32_t *b, uint32_t i) { b[i >> 5] |= 
 __device__ __forceinline__ uint32_t rd_letter(uint32_t info) { return info & 0xFFu; }
 __device__ __forceinline__ uint32_t rd_nal(uint32_t info) { return (info >> 8) & 0xFFu; }
 __device__ __forceinline__ uint32_t rd_nin(uint32_t info) { return info >> 16; }
-__device__ __forceinline__ uint32_t topo_pack(const uint4 &rec) {
-    const uint32_t n_in = rd_nin(rec.x);
-    return (rec.y & 0xFFFFFu) | ((n_in < 63u ? n_in : 63u) << 20) | (rd_nal(rec.x) << 26);
-}
 __device__ __forceinline__ uint32_t u4_get(const uint4 &v, uint32_t k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 __device__ __forceinline__ void u4_set(uint4 &v, uint32_t k, uint32_t x) { if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x; }
 
@@ -195,15 +189,8 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
             if (S.sp == 0) break;
             const uint32_t v = S.stack[S.sp - 1];
             if (bit_get(S.done, v)) { --S.sp; continue; }
-            uint32_t n_in, n_al, in0, more;
-            if (S.topo) {
-                const uint32_t w = S.topo[v];
-                in0 = w & 0xFFFFFu; n_in = (w >> 20) & 63u; n_al = w >> 26; more = POA_NONE;
-                if (n_in > 1) { const uint4 rec = S.nrec[v]; n_in = rd_nin(rec.x); more = rec.z; }
-            } else {
-                const uint4 rec = S.nrec[v];
-                n_in = rd_nin(rec.x); n_al = rd_nal(rec.x); in0 = rec.y; more = rec.z;
-            }
+            const uint4 rec = S.nrec[v];
+            const uint32_t n_in = rd_nin(rec.x), n_al = rd_nal(rec.x), in0 = rec.y, more = rec.z;
             bool valid = true;
             if (n_in > 0) {
                 if (!bit_get(S.done, in0)) { st_push(S, A, in0); valid = false; }
@@ -952,7 +939,6 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
 __device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
     if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return 0; }
     S.nrec[S.n_nodes] = make_uint4(letter, 0, POA_NONE, POA_NONE);
-    if (S.topo) S.topo[S.n_nodes] = 0;
     return S.n_nodes++;
 }
 
@@ -991,7 +977,6 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
         if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return -1; }
         const uint32_t id = S.n_nodes++;
         S.nrec[id] = make_uint4((uint32_t)s[i] | (1u << 16), id - 1, POA_NONE, POA_NONE);     // its only in-edge
-        if (S.topo) S.topo[id] = (id - 1) | (1u << 20);
         path[i] = id;
     }
     return (int32_t)first;
@@ -1022,7 +1007,6 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
         S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (PK != 1 && NT * CPL > 2048 ? CPL : CPL / 2));
-        S.topo = nullptr;
     }
 
     while (true) {
@@ -1718,9 +1702,6 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
             A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
-            A.lds_topo = 0u;                   // LDS mirror of the node topology: measured no gain, costs occupancy
-            // LDS ring of the last RING rows (packed H|F, thread-private): 8 rows cost a block per CU and
-            // were slower at 1e6 reads (34.1k reads/s), none 37.7k, 4 rows keep the occupancy: 38.4k.
             const uint32_t lds_seq = long_rows ? 16u : qcap;
             auto lds_bytes = [&](const poa_variant *V) {
                 const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
