@@ -347,6 +347,13 @@ __device__ __forceinline__ void store_packed(int16_t *__restrict__ p, const uint
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
+// per thread and row: two bits of min(H - E, 3) per column (packed classes)
+template <int CPL> struct ebits_sel { typedef uint32_t type; };
+template <> struct ebits_sel<4> { typedef uint8_t type; };
+template <> struct ebits_sel<6> { typedef uint16_t type; };
+template <> struct ebits_sel<8> { typedef uint16_t type; };
+template <int CPL> using ebits_t = typename ebits_sel<CPL>::type;
+
 struct dp_xchg {                 // LDS
     int4 T[2];                   // double-buffered by row parity: per wave, inclusive max of u
     int2 Q[2][4];                // for wave w: {max of u of wave w-1 without its last column, Hn of that column}
@@ -672,30 +679,30 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 for (int u = 0; u < NP; ++u) {
                     const uint32_t a = rp[u];
                     hp[u] = a & 0x3FFF3FFFu;
-                    FD[u] = as_pk(hp[u]) - as_pk((a >> 14) & 0x00030003u);       // H - min(H-F, 2)
+                    FD[u] = as_pk(hp[u]) - pk_min(as_pk((a >> 14) & 0x00030003u), pk_splat(2));       // H - min(H-F, 2)
                 }
                 const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], S.lh_ring[slot * 4 + wave]);
 #pragma unroll
                 for (int u = 0; u < NP; ++u) HD[u] = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
             } else {
-                uint32_t hp[NP], fp[NP];
+                uint32_t hp[NP];
                 uint32_t hl = 0;
                 if (act) {
-                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
-                    const uint32_t *fq = (const uint32_t *)(S.F + (uint64_t)prow * Lp + c0);
+                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);      // same word format as the ring
 #pragma unroll
-                    for (int u = 0; u < NP; ++u) { hp[u] = hq[u]; fp[u] = fq[u]; }
+                    for (int u = 0; u < NP; ++u) {
+                        const uint32_t a = hq[u];
+                        hp[u] = a & 0x3FFF3FFFu;
+                        FD[u] = as_pk(hp[u]) - pk_min(as_pk((a >> 14) & 0x00030003u), pk_splat(2));
+                    }
                     if (lane == 0 && wave > 0) hl = (uint32_t)S.lh[prow * 4 + wave] << 16;
                 } else {
 #pragma unroll
-                    for (int u = 0; u < NP; ++u) { hp[u] = 0; fp[u] = as_u(pk_splat(NEGF)); }
+                    for (int u = 0; u < NP; ++u) { hp[u] = 0; FD[u] = pk_splat(POA_G - POA_E); }
                 }
                 const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)hl);
 #pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    HD[u] = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
-                    FD[u] = pk_max(as_pk(hp[u]) + pk_splat(POA_G - POA_E), as_pk(fp[u]));
-                }
+                for (int u = 0; u < NP; ++u) HD[u] = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
             }
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
@@ -780,23 +787,29 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             lbest = gt ? lm : lbest;
         }
         {
+            // One word per pair serves the ring, later rows and the traceback: H (14 bits) and min(H - F, 3).
+            // The traceback's tests on F and E can only hold where H - F (H - E) <= 2, and a clipped value
+            // H - 3 can never satisfy them (H of the cell above / left is at most 8 higher), so two bits
+            // per cell are an exact record; E's two bits go to a separate array (a byte per four cells).
+            uint32_t W[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14);
             const uint32_t slot = row % (uint32_t)RINGN;
             uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * NP;
 #pragma unroll
-            for (int u = 0; u < NP; ++u) rp[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(2))) << 14);
+            for (int u = 0; u < NP; ++u) rp[u] = W[u];
             if (lane == 0) S.lh_ring[slot * 4 + wave] = (int32_t)((uint32_t)hl_new << 16);
-        }
-        if (act) {
-            uint32_t pk[NP];
+            if (act) {
+                store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, W);
+                uint32_t eb = 0;
 #pragma unroll
-            for (int u = 0; u < NP; ++u) pk[u] = as_u(HN[u]);
-            store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, pk);
-#pragma unroll
-            for (int u = 0; u < NP; ++u) pk[u] = as_u(FN[u]);
-            store_packed<CPL>(S.F + (uint64_t)row * Lp + c0, pk);
-#pragma unroll
-            for (int u = 0; u < NP; ++u) pk[u] = as_u(EV[u]);
-            store_packed<CPL>(S.E + (uint64_t)row * Lp + c0, pk);
+                for (int u = 0; u < NP; ++u) {
+                    const uint32_t d = as_u(pk_min(HN[u] - EV[u], pk_splat(3)));
+                    eb |= ((d | (d >> 14)) & 0xFu) << (4 * u);
+                }
+                ebits_t<CPL> *ep = (ebits_t<CPL> *)S.E + (uint64_t)row * NT + tid;
+                *ep = (ebits_t<CPL>)eb;
+            }
         }
     };
 
@@ -1079,14 +1092,14 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                                 load_block<CPL>(S.H + (uint64_t)r * Lp + t * CPL, v);
                                 bool hit = false;
 #pragma unroll
-                                for (int u = 0; u < CPL; ++u) hit |= v[u] == best;
+                                for (int u = 0; u < CPL; ++u) hit |= (PK == 1 ? (v[u] & 0x3FFF) : v[u]) == best;
                                 if (hit) S.rowmax[r] = 1;
                             }
                         } else {
                             for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NW) {
                                 const cell_t *Hr = (const cell_t *)S.H + (uint64_t)r * Lp;
                                 bool hit = false;
-                                for (uint32_t c = tid & 63; c < Lp; c += 64) hit |= (int32_t)Hr[c] == best;
+                                for (uint32_t c = tid & 63; c < Lp; c += 64) hit |= (PK == 1 ? (int32_t)(Hr[c] & 0x3FFF) : (int32_t)Hr[c]) == best;
                                 if (hit) S.rowmax[r] = 1;
                             }
                         }
@@ -1202,7 +1215,7 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                     const cell_t *Hb = (const cell_t *)S.H + (uint64_t)best_row * Lp;
                     if (tid == 0) s_bc[5] = 0xFFFFFFFFu;
                     __syncthreads();
-                    for (uint32_t c = tid; c < L; c += NT) if ((int32_t)Hb[c] == best) { atomicMin(&s_bc[5], c + 1); break; }
+                    for (uint32_t c = tid; c < L; c += NT) if ((PK == 1 ? (int32_t)(Hb[c] & 0x3FFF) : (int32_t)Hb[c]) == best) { atomicMin(&s_bc[5], c + 1); break; }
                     __syncthreads();
                     const uint32_t bj = s_bc[5];
                     // Traceback by wave 0, in spoa's order of tests: diagonal (predecessors in in-edge order),
@@ -1229,9 +1242,27 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                         const uint32_t lane = (uint32_t)tid;
                         uint32_t i = best_row, j = bj, cnt = 0, err = 0;
                         const cell_t *H = (const cell_t *)S.H, *F = (const cell_t *)S.F, *E = (const cell_t *)S.E;
-                        auto Hat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? 0 : (int32_t)H[(uint64_t)r * Lp + c - 1]; };
-                        auto Fat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? POA_NEG : (int32_t)F[(uint64_t)r * Lp + c - 1]; };
-                        auto Eat = [&](uint32_t r, uint32_t c) -> int32_t { return (r == 0 || c == 0) ? POA_NEG : (int32_t)E[(uint64_t)r * Lp + c - 1]; };
+                        // packed classes (PK == 1): the H word carries min(H - F, 3) in its two top bits and min(H - E, 3)
+                        // sits in the per-thread bit array behind S.E -- exact for every test below (dp_rows_pk)
+                        auto Hat = [&](uint32_t r, uint32_t c) -> int32_t {
+                            if (r == 0 || c == 0) return 0;
+                            const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1];
+                            return PK == 1 ? (w & 0x3FFF) : w;
+                        };
+                        auto Fat = [&](uint32_t r, uint32_t c) -> int32_t {
+                            if (r == 0 || c == 0) return POA_NEG;
+                            if (PK == 1) { const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1]; return (w & 0x3FFF) - ((w >> 14) & 3); }
+                            return (int32_t)F[(uint64_t)r * Lp + c - 1];
+                        };
+                        auto Eat = [&](uint32_t r, uint32_t c) -> int32_t {
+                            if (r == 0 || c == 0) return POA_NEG;
+                            if (PK == 1) {
+                                const uint32_t t = (c - 1) / CPL, k = (c - 1) % CPL;
+                                const uint32_t bits = ((const ebits_t<CPL> *)S.E)[(uint64_t)r * NT + t];
+                                return ((int32_t)H[(uint64_t)r * Lp + c - 1] & 0x3FFF) - (int32_t)((bits >> (2 * k)) & 3u);
+                            }
+                            return (int32_t)E[(uint64_t)r * Lp + c - 1];
+                        };
                         auto put = [&](int32_t row, int32_t pos) {
                             if (cnt >= A.aln_cap) { err = POA_ERR_ALN; return; }
                             if (lane == 0) { S.aln[2 * cnt] = row; S.aln[2 * cnt + 1] = pos; }
@@ -1251,7 +1282,7 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                                 const bool in = lane < K && j > lane;       // column of my step: j - lane >= 1
                                 const uint32_t my_j = in ? j - lane : 1u;
                                 int32_t c = 0;
-                                if (in && my_next != 0 && my_j > 1) c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2];
+                                if (in && my_next != 0 && my_j > 1) { c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2]; if (PK == 1) c &= 0x3FFF; }
                                 const int32_t hcur = wave_shr1(c, Hij);     // H of my step's own cell = the cell lane-1 fetched
                                 const int32_t mc = tlet[my_i] == (PK == 2 ? s[my_j - 1] : S.sq[my_j - 1]) ? POA_M : POA_N;
                                 const bool ok = in && my_i != 0 && hcur != 0 && hcur == c + mc;
@@ -1698,7 +1729,12 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
             A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
             const uint64_t cell_bytes = long_rows ? 4 : 2;
-            A.o_H = take(ccap * cell_bytes); A.o_F = take(ccap * cell_bytes); A.o_E = take(ccap * cell_bytes);
+            if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
+                const uint64_t eb = cpl == 4 ? 1 : cpl <= 8 ? 2 : 4;
+                A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * eb);
+            } else {
+                A.o_H = take(ccap * cell_bytes); A.o_F = take(ccap * cell_bytes); A.o_E = take(ccap * cell_bytes);
+            }
             A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
             A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
