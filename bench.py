@@ -149,7 +149,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "poa_align", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "alg_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
-                         "launches": launches, "gcups": cells * a.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0},
+                         "launches": launches, "gcups": cells * a.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                         "note": "achieved = SURVEY 8(d)'s 6 B per DP cell x exact cells / kernel time; the packed column classes "
+                                 "store 2.25 B per cell (PMC traffic: profiles/round1i_pmc_hbm_traffic_300k.json)"},
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
         }
         if not a.no_cpu_baseline:
