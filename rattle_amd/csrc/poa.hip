@@ -369,6 +369,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
     constexpr int NT = 64 * NW;
     constexpr bool WIDE = NT * CPL > 2048;       // H may need 15 bits: the ring takes a dword per cell (H | min(H-F,2) << 16)
     constexpr int RW = WIDE ? CPL : CPL / 2;     // ring dwords per thread and row
+    constexpr int NWD = (CPL + 7) / 8;           // dwords of F/E nibbles per thread and row (traceback record)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t c0 = (uint32_t)tid * CPL;
     const bool act = c0 < Lp;
@@ -440,22 +441,21 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) hd[t] = t == 0 ? hleft : hp[t - 1];
             } else {
-                int32_t hp[CPL], fp[CPL];
+                int32_t hp[CPL];
                 int32_t hl = 0;
                 if (act) {
                     load_block<CPL>(S.H + (uint64_t)prow * Lp + c0, hp);
-                    load_block<CPL>(S.F + (uint64_t)prow * Lp + c0, fp);
+                    const uint32_t *np = (const uint32_t *)S.E + ((uint64_t)prow * NT + tid) * NWD;
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) fd[t] = hp[t] - min((int32_t)((np[t / 8] >> (4 * (t % 8))) & 3u), 2);   // H - min(H-F, 2)
                     if (lane == 0 && wave > 0) hl = S.lh[prow * 4 + wave];
                 } else {
 #pragma unroll
-                    for (int t = 0; t < CPL; ++t) { hp[t] = 0; fp[t] = POA_NEG; }
+                    for (int t = 0; t < CPL; ++t) { hp[t] = 0; fd[t] = POA_G - POA_E; }
                 }
                 const int32_t hleft = wave_shr1(hp[CPL - 1], hl);
 #pragma unroll
-                for (int t = 0; t < CPL; ++t) {
-                    hd[t] = t == 0 ? hleft : hp[t - 1];
-                    fd[t] = max(hp[t] + (POA_G - POA_E), fp[t]);
-                }
+                for (int t = 0; t < CPL; ++t) hd[t] = t == 0 ? hleft : hp[t - 1];
             }
 #pragma unroll
             for (int t = 0; t < CPL; ++t) {
@@ -533,12 +533,11 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             lrow = gt ? row : lrow;
             lbest = gt ? lm : lbest;
         }
-        uint32_t pkH[CPL / 2], pkF[CPL / 2], pkE[CPL / 2];
+        uint32_t pkH[CPL / 2], pkF[CPL / 2];
 #pragma unroll
         for (int u = 0; u < CPL / 2; ++u) {
             pkH[u] = pack16(hN[2 * u], hN[2 * u + 1]);
             pkF[u] = pack16(fr[2 * u], fr[2 * u + 1]);       // F >= g: every row has a (possibly virtual) predecessor with H >= 0
-            pkE[u] = pack16(ev[2 * u], ev[2 * u + 1]);
         }
         if (RINGN > 0) {
             const uint32_t slot = row % (uint32_t)(RINGN > 0 ? RINGN : 1);
@@ -561,9 +560,17 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             if (lane == 0) S.lh_ring[slot * 4 + wave] = hl_new;
         }
         if (act) {
+            // the traceback record: H as int16 plus a nibble per column, min(H-F,3) | min(H-E,3) << 2 (exact: see dp_rows_pk)
             store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, pkH);
-            store_packed<CPL>(S.F + (uint64_t)row * Lp + c0, pkF);
-            store_packed<CPL>(S.E + (uint64_t)row * Lp + c0, pkE);
+            uint32_t *np = (uint32_t *)S.E + ((uint64_t)row * NT + tid) * NWD;
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int t = 8 * w; t < 8 * w + 8 && t < CPL; ++t)
+                    v |= ((uint32_t)min(hN[t] - fr[t], 3) | ((uint32_t)min(hN[t] - ev[t], 3) << 2)) << (4 * (t - 8 * w));
+                np[w] = v;
+            }
         }
     };
 
@@ -856,7 +863,8 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
                              bool &multi) {
     constexpr int CPL = 4, NT = 64 * NW;
     constexpr uint32_t SEG = (uint32_t)NT * CPL;
-    int32_t *H = (int32_t *)S.H, *F = (int32_t *)S.F, *E = (int32_t *)S.E;
+    int32_t *H = (int32_t *)S.H;
+    uint16_t *NB = (uint16_t *)S.E;                  // per four columns: nibbles min(H-F,3) | min(H-E,3) << 2 (exact traceback record, see dp_rows_pk)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t lbest = 0;
     uint32_t lrow = 0, lcnt = 0, stepc = 0;
@@ -885,12 +893,13 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
                     if (k < 4) prow = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
                     else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
                     if (!act) continue;
-                    const int32_t *hp = H + (uint64_t)prow * Lp + c0, *fp = F + (uint64_t)prow * Lp + c0;
-                    const int4 h = *(const int4 *)hp, f = *(const int4 *)fp;
+                    const int32_t *hp = H + (uint64_t)prow * Lp + c0;
+                    const int4 h = *(const int4 *)hp;
+                    const uint32_t nb = NB[((uint64_t)prow * Lp + c0) >> 2];
                     const int32_t hleft = c0 ? hp[-1] : 0;
                     hm[0] = max(hm[0], hleft); hm[1] = max(hm[1], h.x); hm[2] = max(hm[2], h.y); hm[3] = max(hm[3], h.z);
-                    fm[0] = max(fm[0], max(h.x + (POA_G - POA_E), f.x)); fm[1] = max(fm[1], max(h.y + (POA_G - POA_E), f.y));
-                    fm[2] = max(fm[2], max(h.z + (POA_G - POA_E), f.z)); fm[3] = max(fm[3], max(h.w + (POA_G - POA_E), f.w));
+                    fm[0] = max(fm[0], h.x - min((int32_t)(nb & 3u), 2)); fm[1] = max(fm[1], h.y - min((int32_t)((nb >> 4) & 3u), 2));
+                    fm[2] = max(fm[2], h.z - min((int32_t)((nb >> 8) & 3u), 2)); fm[3] = max(fm[3], h.w - min((int32_t)((nb >> 12) & 3u), 2));
                 }
                 int32_t hn[CPL], fr[CPL], ex[CPL];
                 int32_t run = POA_NEG;
@@ -916,8 +925,11 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
                 hv.x = max(hn[0], ev.x); hv.y = max(hn[1], ev.y); hv.z = max(hn[2], ev.z); hv.w = max(hn[3], ev.w);
                 if (act) {
                     *(int4 *)(H + (uint64_t)row * Lp + c0) = hv;
-                    *(int4 *)(F + (uint64_t)row * Lp + c0) = make_int4(fr[0], fr[1], fr[2], fr[3]);
-                    *(int4 *)(E + (uint64_t)row * Lp + c0) = ev;
+                    const uint32_t n0 = (uint32_t)min(hv.x - fr[0], 3) | ((uint32_t)min(hv.x - ev.x, 3) << 2);
+                    const uint32_t n1 = (uint32_t)min(hv.y - fr[1], 3) | ((uint32_t)min(hv.y - ev.y, 3) << 2);
+                    const uint32_t n2 = (uint32_t)min(hv.z - fr[2], 3) | ((uint32_t)min(hv.z - ev.z, 3) << 2);
+                    const uint32_t n3 = (uint32_t)min(hv.w - fr[3], 3) | ((uint32_t)min(hv.w - ev.w, 3) << 2);
+                    NB[((uint64_t)row * Lp + c0) >> 2] = (uint16_t)(n0 | (n1 << 4) | (n2 << 8) | (n3 << 12));
                     rowmax = max(rowmax, max(max(hv.x, hv.y), max(hv.z, hv.w)));
                 }
                 carry = max(max(carry, T.x), max(max(T.y, T.z), NW > 3 ? T.w : POA_NEG));
@@ -1241,9 +1253,16 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                     if (w0) {
                         const uint32_t lane = (uint32_t)tid;
                         uint32_t i = best_row, j = bj, cnt = 0, err = 0;
-                        const cell_t *H = (const cell_t *)S.H, *F = (const cell_t *)S.F, *E = (const cell_t *)S.E;
+                        const cell_t *H = (const cell_t *)S.H;
                         // packed classes (PK == 1): the H word carries min(H - F, 3) in its two top bits and min(H - E, 3)
                         // sits in the per-thread bit array behind S.E -- exact for every test below (dp_rows_pk)
+                        // 32-bit register classes (PK == 0): H int16 plus a nibble per column behind S.E (dp_rows)
+                        auto nib = [&](uint32_t r, uint32_t c) -> uint32_t {
+                            if (PK == 2) return ((uint32_t)((const uint16_t *)S.E)[((uint64_t)r * Lp + c - 1) >> 2] >> (4 * ((c - 1) & 3u))) & 0xFu;   // segmented rows: per column
+                            constexpr uint32_t NWD = (CPL + 7) / 8;
+                            const uint32_t t = (c - 1) / CPL, k = (c - 1) % CPL;
+                            return (((const uint32_t *)S.E)[((uint64_t)r * NT + t) * NWD + k / 8] >> (4 * (k % 8))) & 0xFu;
+                        };
                         auto Hat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return 0;
                             const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1];
@@ -1252,7 +1271,7 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                         auto Fat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return POA_NEG;
                             if (PK == 1) { const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1]; return (w & 0x3FFF) - ((w >> 14) & 3); }
-                            return (int32_t)F[(uint64_t)r * Lp + c - 1];
+                            return (int32_t)H[(uint64_t)r * Lp + c - 1] - (int32_t)(nib(r, c) & 3u);
                         };
                         auto Eat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return POA_NEG;
@@ -1261,7 +1280,7 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                                 const uint32_t bits = ((const ebits_t<CPL> *)S.E)[(uint64_t)r * NT + t];
                                 return ((int32_t)H[(uint64_t)r * Lp + c - 1] & 0x3FFF) - (int32_t)((bits >> (2 * k)) & 3u);
                             }
-                            return (int32_t)E[(uint64_t)r * Lp + c - 1];
+                            return (int32_t)H[(uint64_t)r * Lp + c - 1] - (int32_t)((nib(r, c) >> 2) & 3u);
                         };
                         auto put = [&](int32_t row, int32_t pos) {
                             if (cnt >= A.aln_cap) { err = POA_ERR_ALN; return; }
@@ -1732,8 +1751,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
                 const uint64_t eb = cpl == 4 ? 1 : cpl <= 8 ? 2 : 4;
                 A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * eb);
-            } else {
-                A.o_H = take(ccap * cell_bytes); A.o_F = take(ccap * cell_bytes); A.o_E = take(ccap * cell_bytes);
+            } else if (P.V->pk == 0) {         // H int16 plus a nibble per column (min(H-F,3), min(H-E,3))
+                A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * ((cpl + 7) / 8) * 4);
+            } else {                           // segmented int32 rows: H int32 plus a nibble per column
+                A.o_H = take(ccap * cell_bytes); A.o_F = take(0); A.o_E = take(ccap / 2 + 64);
             }
             A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
             P.per_slot = o;
