@@ -30,11 +30,19 @@ def make_workload(n_reads, genes, seed):
     return synth.reads_packed(n_reads, genes, 1, True, seed=seed, exon=(50, 210))
 
 
+PHASES = {"cluster": 0.0, "correct": 0.0}      # host wall time of the two calls, summed over the timed steps
+
+
 def run_step(ctx, cat, qcat, off, k=10):
     """`rattle cluster` (sort + index + gene-level cluster_reads + id translation, main.cpp:254-277)
     then `rattle correct` (correct_reads, main.cpp:405) on the same reads."""
+    t0 = time.time()
     cl = ctx.cluster_unsorted_packed(cat, off, k=k)
+    t1 = time.time()
     res = ctx.correct_packed(cat, qcat, off, cl)
+    t2 = time.time()
+    PHASES["cluster"] += t1 - t0
+    PHASES["correct"] += t2 - t1
     assign = np.full(len(off) - 1, -1, np.int32)
     assign[cl.member_id] = np.repeat(np.arange(len(cl.main_id), dtype=np.int32), np.diff(cl.offsets.astype(np.int64)))
     return cl, res, assign
@@ -67,6 +75,37 @@ def cpu_baseline(cat, qcat, off, tid, target_reads=600):
     return {"value": len(s) / dt, "unit": "reads/s", "cores": 1, "kind": "port",
             "sample": f"{len(s)} reads = every read of {len(set(int(tid[i]) for i in ids))} transcripts of the same workload, "
                       f"oracle cluster+correct, {dt:.1f} s"}
+
+
+def cpu_baseline_all_cores(cat, qcat, off, tid):
+    """The same oracle on every host core: one task per whole transcript on a process pool
+    (oracle/par_baseline.py, run as a separate process so the pool forks without a HIP runtime).
+    Transcripts are clustered separately, which spares the CPU the cross-transcript filter tests."""
+    import subprocess
+    import tempfile
+    cores = os.cpu_count() or 1
+    counts = np.bincount(tid)
+    rng = np.random.default_rng(2)
+    keep = [int(g) for g in rng.permutation(len(counts)) if 6 <= counts[g] <= 100][:max(8, cores)]      # bounded: ~20-30 s of wall time
+    sel = np.nonzero(np.isin(tid, keep))[0]
+    lens = (off[sel + 1] - off[sel]).astype(np.int64)
+    o2 = np.zeros(len(sel) + 1, np.uint64)
+    o2[1:] = np.cumsum(lens)
+    idx = np.concatenate([np.arange(int(off[i]), int(off[i + 1])) for i in sel]) if len(sel) else np.zeros(0, np.int64)
+    model = ""
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "sample.npz")
+        np.savez(path, cat=cat[idx], qcat=qcat[idx], off=o2, grp=tid[sel])
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "par_baseline.py"), path, str(cores)], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": r.stderr[-300:]}
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": j["reads"] / j["seconds"], "unit": "reads/s", "cores": int(min(cores, j["tasks"])), "nproc": cores, "cpu": model, "kind": "port",
+            "sample": f"{j['reads']} reads = every read of {j['tasks']} transcripts (6..100 reads each), one oracle task per transcript, {j['seconds']:.1f} s"}
 
 
 def main():
@@ -116,6 +155,7 @@ def main():
     for _ in range(a.warmup):
         step()
     ctx.reset_stats()
+    PHASES["cluster"] = PHASES["correct"] = 0.0
     barrier()
     t0 = time.time()
     for _ in range(a.steps):
@@ -134,6 +174,16 @@ def main():
         names = {K_KMER: "kmer_extract", K_FILTER: "bv_filter", K_SCORE: "pair_score", K_POA: "poa_align", K_POST: "post_msa"}
         kst = {names[k]: ctx.kernel_stats(k) for k in names}
         ms, launches, alg = kst["poa_align"]
+        # what this GPU sustains on a plain device-to-device copy (read + write bytes), SURVEY 8(d)
+        buf = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(buf)
+        dst.copy_(buf); torch.cuda.synchronize()
+        tc = time.time()
+        for _ in range(10):
+            dst.copy_(buf)
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * buf.numel() / (time.time() - tc) / 1e9
+        del buf, dst
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         cells = int(res[3][0])
         out = {
@@ -147,15 +197,18 @@ def main():
                        "reads_per_gpu": a.reads, "clusters": int(len(cl.main_id)), "poa_dp_cells_per_step": cells,
                        "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "kernel": "poa_align", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": None, "measured_copy_gbs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "alg_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
                          "launches": launches, "gcups": cells * a.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                          "note": "achieved = SURVEY 8(d)'s 6 B per DP cell x exact cells / kernel time; the packed column classes "
                                  "store 2.25 B per cell (PMC traffic: profiles/round1i_pmc_hbm_traffic_300k.json)"},
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
+            "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items()},
+            "phase_reads_per_s": {k: total_reads / world / (v / a.steps) for k, v in PHASES.items() if v > 0},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cat, qcat, off, tid)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
