@@ -26,3 +26,23 @@ def test_reads_packed_model():
     i = int(np.nonzero(flip == 0)[0][0])
     r = difflib.SequenceMatcher(None, cat[int(off[i]):int(off[i + 1])].tobytes(), tx[tid[i]].tobytes(), autojunk=False).ratio()
     assert r > 0.85
+
+
+def test_par_baseline_helper_runs(tmp_path):
+    """oracle/par_baseline.py (bench.py's all-cores CPU leg): one oracle task per transcript on a process pool."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    from rattle_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cat, qcat, off, tid, _ = synth.reads_packed(120, 4, 1, True, seed=9, exon=(20, 60))
+    path = str(tmp_path / "s.npz")
+    np.savez(path, cat=cat, qcat=qcat, off=off, grp=tid)
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "par_baseline.py"), path, "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["reads"] == 120 and j["workers"] == 2 and j["tasks"] == len(set(tid.tolist()))
