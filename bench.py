@@ -129,8 +129,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("RATTLE_BENCH_FORCE_DIST"))      # the flag exercises the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     genes = a.genes or max(5, a.reads // 200)
     cat, qcat, off, tid, _ = make_workload(a.reads, genes, seed=20260929 + rank)
@@ -138,13 +141,13 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
         cl, res, assign = run_step(ctx, cat, qcat, off)
-        if world > 1:     # reassemble cluster assignments on every rank (RCCL all-gather over xGMI)
+        if use_dist:      # reassemble cluster assignments on every rank (RCCL all-gather over xGMI)
             mine = torch.from_numpy(assign).cuda()
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)
@@ -162,7 +165,7 @@ def main():
         cl, res = step()
     barrier()
     dt = time.time() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -210,7 +213,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cat, qcat, off, tid)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
