@@ -196,6 +196,11 @@ int rattle_hip_correct_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const u
                              const rattle_correct_params *params, rattle_correction **out);
 void rattle_hip_correction_free(rattle_correction *c);
 
+/* Test hook, needs no device: phred_symbol's value `-10*log10(p)+33` (utils.cpp:6-8, before the narrowing to
+ * char) through the threshold table the post-MSA kernel bisects and through the host libm.  Returns the number
+ * of explicit exceptions the table carries. */
+int rattle_hip_debug_phred_symbol(double p, int *table_value, int *libm_value);
+
 /* ------------------------------------------------------------------------------------
  * Per-kernel timing measured with HIP events on the stream the kernels run on.
  * kernel: 0 kmer_extract, 1 bv_filter, 2 pair_score, 3 poa_align, 4 post_msa.  Accumulated since

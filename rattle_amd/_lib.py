@@ -62,6 +62,7 @@ SIGNATURES = {
     "rattle_hip_cluster_reads": (C.c_int, [C.c_void_p, _P(ClusterParams), _P(_P(ClusterSet))]),
     "rattle_hip_cluster_subset": (C.c_int, [C.c_void_p, _P(ClusterParams), _u32p, C.c_uint32, _P(_P(ClusterSet))]),
     "rattle_hip_cluster_subsets": (C.c_int, [C.c_void_p, _P(ClusterParams), _u32p, _u64p, C.c_uint32, _P(_P(ClusterSet)), C.c_int]),
+    "rattle_hip_debug_phred_symbol": (C.c_int, [C.c_double, _P(C.c_int), _P(C.c_int)]),
     "rattle_hip_stage_reads": (C.c_int, [C.c_void_p, _u8p, _u8p, _u64p, C.c_uint32]),
     "rattle_hip_unstage_reads": (C.c_int, [C.c_void_p]),
     "rattle_hip_cluster_unsorted": (C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint32, C.c_int, _P(ClusterParams),

@@ -1,5 +1,6 @@
 // extern "C" surface of librattle_hip.so (include/rattle_hip.h).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -383,6 +384,21 @@ void rattle_hip_correction_free(rattle_correction *r) {
     if (!r) return;
     free_set(r->corrected); free_set(r->uncorrected); free_set(r->consensi);
     free(r);
+}
+
+// Test hook (no device needed): the value of `-10*log10(p)+33` before the narrowing to char, once through the
+// threshold table kernel D uses and once through the host libm (utils.cpp:6-8).  They must agree for every p.
+int rattle_hip_debug_phred_symbol(double p, int *table_value, int *libm_value) {
+    static std::mutex mu;
+    static phred_table T;
+    static bool ready = false;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!ready) { build_phred_table(T); ready = true; }
+    }
+    if (table_value) *table_value = phred_lookup_host(T, p);
+    if (libm_value) *libm_value = (int)(-10 * log10(p) + 33);
+    return (int)T.exc_bits.size();
 }
 
 int rattle_hip_kernel_stats(rattle_ctx *c, int kernel, double *ms, uint64_t *launches, uint64_t *bytes) {

@@ -144,6 +144,7 @@ struct phred_table {
     std::vector<int32_t> exc_val;
 };
 void build_phred_table(phred_table &T);
+int phred_lookup_host(const phred_table &T, double p);
 
 // copy descriptor of the gather kernel: flags bit 0 = reverse complement (qualities reversed)
 struct gather_desc {

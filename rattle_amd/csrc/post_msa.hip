@@ -284,4 +284,15 @@ void build_phred_table(phred_table &T) {
     for (auto &e : exc) { T.exc_bits.push_back(e.first); T.exc_val.push_back(e.second); }
 }
 
+// Host mirror of the device lookup (phred_value), for the CPU-side test of the table construction.
+int phred_lookup_host(const phred_table &T, double p) {
+    uint64_t bits;
+    memcpy(&bits, &p, 8);
+    const auto it = std::lower_bound(T.exc_bits.begin(), T.exc_bits.end(), bits);
+    if (it != T.exc_bits.end() && *it == bits) return T.exc_val[it - T.exc_bits.begin()];
+    int lo = 0, hi = (int)T.lo.size() - 1;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (p >= T.lo[m]) hi = m; else lo = m + 1; }
+    return T.n0 + lo;
+}
+
 }  // namespace rattle

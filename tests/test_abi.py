@@ -51,3 +51,33 @@ def test_no_device_fails_loudly(lib):
     with pytest.raises(_lib.RattleError):
         from rattle_amd.api import Context
         Context(0)
+
+
+def test_phred_symbol_table_matches_libm():
+    """Kernel D never evaluates log10: it bisects a table of thresholds built with the host libm
+    (post_msa.hip).  Same lookup on the host against `(int)(-10*log10(p)+33)` itself: exact powers
+    10^(-q/10) (where the expression sits on an integer), their neighbours by a few ulps, means of
+    a few of them (what a column's mean error looks like) and random magnitudes."""
+    import ctypes as C
+
+    import numpy as np
+
+    from rattle_amd import _lib
+    lib = _lib.load()
+    t, m = C.c_int(), C.c_int()
+    rng = np.random.default_rng(0)
+    base = np.array([10.0 ** (-(c - 33) / 10.0) for c in range(0, 128)])
+    cases = list(base)
+    for b in base:
+        bits = int(np.array([b]).view(np.uint64)[0])
+        cases += list(np.array([bits + d for d in range(-6, 7)], np.uint64).view(np.float64))
+    for _ in range(20000):
+        k = int(rng.integers(1, 6))
+        cases.append(float(np.sum(rng.choice(base[33:100], k)) / k))
+    cases += list(10.0 ** rng.uniform(-12, 18, 20000))
+    bad = []
+    for p in cases:
+        lib.rattle_hip_debug_phred_symbol(float(p), C.byref(t), C.byref(m))
+        if t.value != m.value:
+            bad.append((p, t.value, m.value))
+    assert not bad, bad[:5]
