@@ -1785,8 +1785,14 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (ctx->poa_arena_bytes < want_bytes) {
             if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
             ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
-            if (hipMalloc((void **)&ctx->poa_arena, want_bytes) != hipSuccess) { set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break; }
-            ctx->poa_arena_bytes = want_bytes;
+            // allocating (and freeing) tens of GB costs seconds: take half as much again so that the next stage,
+            // whose packs differ a little, does not trigger another round of it
+            uint64_t take_bytes = std::min<uint64_t>(budget, want_bytes + want_bytes / 2);
+            if (hipMalloc((void **)&ctx->poa_arena, take_bytes) != hipSuccess) {
+                take_bytes = want_bytes;
+                if (hipMalloc((void **)&ctx->poa_arena, take_bytes) != hipSuccess) { set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break; }
+            }
+            ctx->poa_arena_bytes = take_bytes;
         }
         hipError_t e = hipMemsetAsync(d_heads.p, 0, 32, st);
         uint64_t aoff = 0;
