@@ -400,19 +400,23 @@ int mode_correct(int argc, char **argv) {
         if (gid == -1) return ",gene_cluster_" + std::to_string(cid);
         return ",gene_cluster_" + std::to_string(gid) + ",transcript_cluster_" + std::to_string(cid);
     };
-    auto to_reads = [&](const rattle_read_set &S, bool corrected) {
-        read_set_t out;
+    // corrected.fq / uncorrected.fq (fasta.cpp:436-445 record layout) straight from the library's buffers
+    auto write_set = [&](const rattle_read_set &S, bool corrected, const std::string &path) {
+        FILE *f = fopen(path.c_str(), "wb");
+        if (!f) die("Error: cannot write " + path);
+        std::string buf;
+        buf.reserve(64u << 20);
         for (uint32_t i = 0; i < S.n; ++i) {
-            read_t r;
-            r.header = reads[S.read_id[i]].header + tag(S.cluster_id[i]);
-            r.seq.assign(S.seq + S.off[i], S.seq + S.off[i + 1]);
-            r.quality.assign(S.qual + S.off[i], S.qual + S.off[i + 1]);
-            r.ann = corrected ? "+" : reads[S.read_id[i]].ann;
-            out.push_back(r);
+            buf += reads[S.read_id[i]].header; buf += tag(S.cluster_id[i]); buf += '\n';
+            buf.append(S.seq + S.off[i], S.seq + S.off[i + 1]); buf += '\n';
+            buf += corrected ? std::string("+") : reads[S.read_id[i]].ann; buf += '\n';
+            buf.append(S.qual + S.off[i], S.qual + S.off[i + 1]); buf += '\n';
+            if (buf.size() > (60u << 20)) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
         }
-        return out;
+        fwrite(buf.data(), 1, buf.size(), f);
+        fclose(f);
     };
-    read_set_t corrected = to_reads(R->corrected, true), uncorrected = to_reads(R->uncorrected, false), consensi;
+    read_set_t consensi;
     // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's packs
     std::vector<std::vector<int>> label_counts(clusters.size(), std::vector<int>(labels.size(), 0));
     if (!labels.empty()) {
@@ -449,8 +453,8 @@ int mode_correct(int argc, char **argv) {
     }
     std::cerr << std::endl << "Generating consensi..." << std::endl;
     std::string outdir = a.str("output", ".");
-    write_fastq_file(corrected, outdir + "/corrected.fq");
-    write_fastq_file(uncorrected, outdir + "/uncorrected.fq");
+    write_set(R->corrected, true, outdir + "/corrected.fq");
+    write_set(R->uncorrected, false, outdir + "/uncorrected.fq");
     write_fastq_file(consensi, outdir + "/consensi.fq");
     rattle_hip_correction_free(R);
     rattle_hip_ctx_destroy(ctx);
