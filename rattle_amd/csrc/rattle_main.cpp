@@ -101,18 +101,41 @@ struct line_reader {
 // Records of a FASTQ (4 lines each) or FASTA (header + joined, upper-cased sequence lines; quality '~').
 void for_each_record(const std::string &file, bool fastq,
                      const std::function<void(const std::string &, const std::string &, const std::string &, const std::string &)> &f) {
+    if (fastq) {
+        // whole file in memory, lines by memchr (std::getline was the slowest part of a run once the kernels were fast);
+        // same line semantics: '\n' separated, a final line without one counts, DOS endings detected on line 1
+        FILE *fp = fopen(file.c_str(), "rb");
+        if (!fp) return;
+        std::string buf;
+        {
+            fseek(fp, 0, SEEK_END);
+            const long sz = ftell(fp);
+            fseek(fp, 0, SEEK_SET);
+            buf.resize(sz > 0 ? (size_t)sz : 0);
+            size_t got = 0;
+            while (got < buf.size()) { const size_t n = fread(&buf[got], 1, buf.size() - got, fp); if (n == 0) break; got += n; }
+            buf.resize(got);
+            fclose(fp);
+        }
+        std::string fld[4];
+        bool dos = false, first = true;
+        int id = 0;
+        size_t pos = 0;
+        while (pos < buf.size()) {
+            const char *nl = (const char *)memchr(buf.data() + pos, '\n', buf.size() - pos);
+            size_t end = nl ? (size_t)(nl - buf.data()) : buf.size();
+            size_t len = end - pos;
+            if (first) { dos = len > 0 && buf[end - 1] == '\r'; first = false; }
+            if (dos && len > 0) --len;
+            fld[id].assign(buf.data() + pos, len);
+            pos = end + 1;
+            if (++id == 4) { f(fld[0], fld[1], fld[2], fld[3]); id = 0; }
+        }
+        return;
+    }
     line_reader R(file);
     std::string l;
-    if (fastq) {
-        std::string h, s, a;
-        int id = 0;
-        while (R.next(l)) {
-            if (id == 0) { h = l; id = 1; }
-            else if (id == 1) { s = l; id = 2; }
-            else if (id == 2) { a = l; id = 3; }
-            else { f(h, s, a, l); id = 0; }
-        }
-    } else {
+    {
         std::string h, s;
         bool have = false;
         while (R.next(l)) {
