@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""Headline benchmark: reads/sec for `cluster` + `correct` on synthetic ONT cDNA reads.
+"""Headline benchmark: reads/sec for `cluster` + `correct` on 1e6 synthetic ONT cDNA reads, 1 -> 8 GPUs.
 
-One step = one full pass of the hot path over one batch of reads per GPU:
-  k-mer index (kernel K) -> greedy clustering (kernels A+B) -> correct (kernel C x3 + host vote).
-N GPUs = N ranks (torch.distributed / RCCL), each clustering+correcting its own shard of the
-sample (weak scaling: reads per GPU fixed); the only collective is the all-gather of the
-per-read cluster assignment that reassembles the result on every rank.
+One step = one full pass of the hot path over the SAME 1e6-read batch:
+  sort + k-mer index (kernel K) -> greedy clustering (kernels A + B) -> correct (kernel C x3, kernel D).
+N GPUs = N ranks (launched by torch.distributed.run) working on ONE job (strong scaling): every rank holds
+the reads in HBM, the candidates of a seed batch / the `correct` packs are sharded over the ranks inside
+librattle_hip.so, the exchange is RCCL all-gather(v) of small byte strings (hit lists, pack consensi), and
+the corrected reads are gathered on rank 0, whose result must carry the same digest as the 1-GPU run.
+`--weak` keeps the reads per GPU fixed instead (each rank its own data set, no exchange).
+`--iso` benchmarks config 3 instead: the two-level `cluster --iso` flow (k=10 then k=11).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (poa_align) and `cpu_baseline` (the oracle timed on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the dominant kernel
+(poa_align) and `cpu_baseline` (the oracle timed on a bounded sample).
 """
 import argparse
 import json
@@ -24,57 +27,89 @@ sys.path.insert(0, ROOT)
 from rattle_amd import synth  # noqa: E402
 from rattle_amd.api import K_FILTER, K_KMER, K_POA, K_POST, K_SCORE, Context  # noqa: E402
 
+METRIC = "reads/sec for `cluster`+`correct` on 1e6×1kb synthetic ONT reads, 1→8 GPU"
+VALU_PEAK_TINSTR = 256 * 4 * 2.4e9 / 2 / 1e12      # wave64 VALU instructions per second: 256 CUs x 4 SIMDs, 2 cycles each at 2.4 GHz
 
-def make_workload(n_reads, genes, seed):
+
+def make_workload(n_reads, genes, seed, isoforms=1):
     # mean ~1 kb transcripts (8 exons of U[50,210]), 10 % error, both strands (cDNA); packed arrays
-    return synth.reads_packed(n_reads, genes, 1, True, seed=seed, exon=(50, 210))
+    return synth.reads_packed(n_reads, genes, isoforms, True, seed=seed, exon=(50, 210))
 
 
 PHASES = {"cluster": 0.0, "correct": 0.0}      # host wall time of the two calls, summed over the timed steps
 
 
-def run_step(ctx, cat, qcat, off, k=10):
+def run_step(ctx, cat, qcat, off, root, k=10):
     """`rattle cluster` (sort + index + gene-level cluster_reads + id translation, main.cpp:254-277)
-    then `rattle correct` (correct_reads, main.cpp:405) on the same reads."""
+    then `rattle correct` (correct_reads, main.cpp:405) on the same reads; several ranks: the sharded result
+    is reassembled on `root`."""
     t0 = time.time()
     cl = ctx.cluster_unsorted_packed(cat, off, k=k)
     t1 = time.time()
-    res = ctx.correct_packed(cat, qcat, off, cl)
+    res = ctx.correct_packed(cat, qcat, off, cl, gather_root=root, keep=True)
     t2 = time.time()
     PHASES["cluster"] += t1 - t0
     PHASES["correct"] += t2 - t1
-    assign = np.full(len(off) - 1, -1, np.int32)
-    assign[cl.member_id] = np.repeat(np.arange(len(cl.main_id), dtype=np.int32), np.diff(cl.offsets.astype(np.int64)))
-    return cl, res, assign
+    return cl, res
 
 
-def cpu_baseline(cat, qcat, off, tid, target_reads=600):
-    """Oracle (CPU restatement, 1 thread) on a bounded sample: all reads of randomly chosen
-    transcripts until ~target_reads, so per-cluster depth matches the full workload."""
+def expected_consensi(cl, split=200, min_reads=5):
+    """clusters owning at least one pack of more than min_reads reads (correct.cpp:331-360)"""
+    sizes = np.diff(cl.offsets.astype(np.int64))
+    nf = (sizes - 1) // split + 1
+    return int(((sizes - 1) // np.maximum(nf, 1) + 1 > min_reads).sum())
+
+
+def cluster_digest(cl):
+    import zlib
+    crc = 0
+    for a in (cl.main_id, cl.main_rev, cl.offsets, cl.member_id, cl.member_rev):
+        crc = zlib.crc32(np.ascontiguousarray(a).tobytes(), crc)
+    return crc
+
+
+def cpu_baseline(cat, qcat, off, tid, correct_reads=600, cluster_reads=5000):
+    """Oracle (CPU restatement, 1 thread), timed per phase on bounded samples of the same workload: `cluster` on
+    every read of randomly chosen transcripts up to ~cluster_reads, `correct` on a ~correct_reads subset of whole
+    transcripts (so per-cluster depth matches the full workload).  The combined rate is the harmonic sum."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc_mod
     from rattle_amd import hps
     orc = orc_mod.Oracle()
     rng = np.random.default_rng(1)
-    ids = []
     counts = np.bincount(tid)
-    for g in rng.permutation(int(tid.max()) + 1):
-        if counts[g] > target_reads // 2 or counts[g] < 6:      # keep the sample bounded (~10-30 s of CPU)
-            continue
-        ids += [i for i in np.nonzero(tid == g)[0]]
-        if len(ids) >= target_reads:
-            break
-    s = [cat[int(off[i]):int(off[i + 1])].tobytes() for i in ids]
-    q = [qcat[int(off[i]):int(off[i + 1])].tobytes() for i in ids]
+    perm = rng.permutation(int(tid.max()) + 1)
+
+    def sample(target, lo, hi):
+        ids = []
+        for g in perm:
+            if counts[g] > hi or counts[g] < lo:
+                continue
+            ids += [int(i) for i in np.nonzero(tid == g)[0]]
+            if len(ids) >= target:
+                break
+        return ids
+
+    ids_c = sample(cluster_reads, 6, cluster_reads // 4)
+    s = [cat[int(off[i]):int(off[i + 1])].tobytes() for i in ids_c]
     t0 = time.time()
     order = sorted(range(len(s)), key=lambda i: -len(s[i]))
-    cl, _ = orc.cluster_reads([s[i] for i in order], k=10)
-    clusters = [((order[m[0]], m[1], -1), [(order[x[0]], x[1], -1) for x in mem]) for m, mem in cl]
-    orc.correct([b"@r%d" % i for i in range(len(s))], s, q, hps.encode(clusters))
-    dt = time.time() - t0
-    return {"value": len(s) / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"{len(s)} reads = every read of {len(set(int(tid[i]) for i in ids))} transcripts of the same workload, "
-                      f"oracle cluster+correct, {dt:.1f} s"}
+    cl, cnt = orc.cluster_reads([s[i] for i in order], k=10)
+    dt_cluster = time.time() - t0
+    ids_k = sample(correct_reads, 6, correct_reads // 2)
+    s2 = [cat[int(off[i]):int(off[i + 1])].tobytes() for i in ids_k]
+    q2 = [qcat[int(off[i]):int(off[i + 1])].tobytes() for i in ids_k]
+    order2 = sorted(range(len(s2)), key=lambda i: -len(s2[i]))
+    cl2, _ = orc.cluster_reads([s2[i] for i in order2], k=10)
+    clusters = [((order2[m[0]], m[1], -1), [(order2[x[0]], x[1], -1) for x in mem]) for m, mem in cl2]
+    t1 = time.time()
+    orc.correct([b"@r%d" % i for i in range(len(s2))], s2, q2, hps.encode(clusters))
+    dt_correct = time.time() - t1
+    r_cluster, r_correct = len(s) / dt_cluster, len(s2) / dt_correct
+    return {"value": 1.0 / (1.0 / r_cluster + 1.0 / r_correct), "unit": "reads/s", "cores": 1, "kind": "port",
+            "cluster_reads_per_s": r_cluster, "correct_reads_per_s": r_correct,
+            "sample": f"oracle, one thread, per phase on whole transcripts of the same workload: cluster {len(s)} reads in {dt_cluster:.1f} s "
+                      f"({int(cnt[0])} pair tests, {int(cnt[1])} full comparisons), correct {len(s2)} reads in {dt_correct:.1f} s; value = harmonic sum"}
 
 
 def cpu_baseline_all_cores(cat, qcat, off, tid):
@@ -108,36 +143,61 @@ def cpu_baseline_all_cores(cat, qcat, off, tid):
             "sample": f"{j['reads']} reads = every read of {j['tasks']} transcripts (6..100 reads each), one oracle task per transcript, {j['seconds']:.1f} s"}
 
 
+def pmc_reference():
+    """Counter-derived constants of kernel C for THIS tree, measured in separate rocprofv3 --pmc passes and
+    committed under profiles/ (the counters cannot be read from inside the benchmark process)."""
+    path = os.path.join(ROOT, "profiles", "round2_pmc_poa.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("RATTLE_BENCH_READS", 1000000)), help="reads per GPU")
-    ap.add_argument("--genes", type=int, default=0, help="transcripts per GPU shard (default reads/200)")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("RATTLE_BENCH_READS", 1000000)), help="reads of the job (per GPU with --weak)")
+    ap.add_argument("--genes", type=int, default=0, help="transcripts (default reads/200; --iso: genes = reads/600 x 3 isoforms)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: every rank its own data set of --reads reads, no exchange")
+    ap.add_argument("--iso", action="store_true", help="config 3: two-level `cluster --iso` (k=10, then k=11 per gene cluster) instead of cluster+correct")
+    ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl", help="exchange of the sharded job: RCCL on device buffers, or host buffers through gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-digest", action="store_true", help="several ranks: skip the unsharded reference run the result is checked against")
     ap.add_argument("--no-stage", action="store_true", help="hand the reads over as host buffers every step (PCIe-inclusive rate)")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # ranks of one node share the host cores for the post-MSA logic
+    # ranks of one node share the host cores for pack planning / result assembly
     os.environ.setdefault("RATTLE_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    same_device = bool(os.environ.get("RATTLE_BENCH_ONE_DEVICE"))      # tests: several ranks on one GPU (gloo transport only)
+    if same_device:
+        local = 0
     torch.cuda.set_device(local)
     use_dist = world > 1 or bool(os.environ.get("RATTLE_BENCH_FORCE_DIST"))      # the flag exercises the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    genes = a.genes or max(5, a.reads // 200)
-    cat, qcat, off, tid, _ = make_workload(a.reads, genes, seed=20260929 + rank)
-    ctx = Context(local)
+        if a.transport == "gloo" or same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sharded = use_dist and not a.weak
+    if a.iso:
+        genes = a.genes or max(5, a.reads // 600)
+        cat, qcat, off, tid, _ = make_workload(a.reads, genes, seed=20260929 + (rank if a.weak else 0), isoforms=3)
+    else:
+        genes = a.genes or max(5, a.reads // 200)
+        cat, qcat, off, tid, _ = make_workload(a.reads, genes, seed=20260929 + (rank if a.weak else 0))
+    n_reads = len(off) - 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,38 +205,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # several ranks on one job: the result must equal the unsharded one -> rank 0 runs it once, untimed, first
+    ref_digest = None
+    if sharded and world > 1 and not a.no_reference_digest and not a.iso:
+        if rank == 0:
+            ref = Context(local)
+            cl0 = ref.cluster_unsorted_packed(cat, off)
+            h0 = ref.correct_packed(cat, qcat, off, cl0, keep=True)
+            ref_digest = (cluster_digest(cl0), h0.digest())
+            h0.free()
+            ref.close()
+        barrier()
+
+    ctx = Context(local)
+    if sharded:
+        if a.transport == "gloo" or same_device:
+            ctx.set_exchange_gloo()
+        else:
+            ctx.comm_init_rccl()
+    root = 0 if sharded else None
+
     def step():
-        cl, res, assign = run_step(ctx, cat, qcat, off)
-        if use_dist:      # reassemble cluster assignments on every rank (RCCL all-gather over xGMI)
-            mine = torch.from_numpy(assign).cuda()
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-        return cl, res
+        if a.iso:
+            t0 = time.time()
+            cl, gid, ng = ctx.cluster_iso_unsorted_packed(cat, off)
+            PHASES["cluster"] += time.time() - t0
+            return cl, (gid, ng)
+        return run_step(ctx, cat, qcat, off, root)
 
     if not a.no_stage:     # inputs resident in HBM before the timed region (BASELINE metric definition)
         ctx.stage_reads(cat, qcat, off)
+    warm = None
     for _ in range(a.warmup):
-        step()
+        if warm is not None and not a.iso:
+            warm[1].free()
+        warm = step()
     ctx.reset_stats()
     PHASES["cluster"] = PHASES["correct"] = 0.0
     barrier()
     t0 = time.time()
+    last = None
     for _ in range(a.steps):
-        cl, res = step()
+        if last is not None and not a.iso:
+            last[1].free()
+        last = step()
     barrier()
     dt = time.time() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
-    total_reads = a.reads * world
+    total_reads = n_reads * (world if a.weak else 1)
     value = total_reads / (dt / a.steps)
+    cl, res = last
+
+    # ---- correctness of what was timed (outside the timed region) ----
+    checks = {}
+    if a.iso:
+        gid, ng = res
+        assert len(cl.member_id) == n_reads and np.array_equal(np.sort(cl.member_id), np.arange(n_reads)), "--iso: not a partition of the reads"
+        assert np.all(np.diff(gid) >= 0) and (len(gid) == 0 or gid[-1] == ng - 1), "--iso: gene ids not in gene order"
+        checks = {"partition": True, "gene_clusters": int(ng), "transcript_clusters": int(len(cl.main_id)), "cluster_digest": cluster_digest(cl)}
+        if warm is not None:
+            assert cluster_digest(warm[0]) == checks["cluster_digest"], "--iso: result differs between steps"
+            checks["digest_equal_across_steps"] = True
+    else:
+        if rank == 0 or not sharded:
+            n_cor, n_unc, n_cons, counters = res.counts()
+            assert n_cor + n_unc == n_reads, f"accounting: {n_cor} corrected + {n_unc} uncorrected != {n_reads} reads"
+            assert n_cons == expected_consensi(cl), f"consensus count {n_cons} != {expected_consensi(cl)}"
+            assert len(cl.member_id) == n_reads, "cluster: not a partition of the reads"
+            dg = (cluster_digest(cl), res.digest())
+            checks = {"n_corrected": int(n_cor), "n_uncorrected": int(n_unc), "n_consensi": int(n_cons), "packs_skipped": int(counters[3]),
+                      "cluster_digest": dg[0], "correct_digest": dg[1]}
+            if warm is not None:
+                assert (cluster_digest(warm[0]), warm[1].digest()) == dg, "result differs between steps"
+                checks["digest_equal_across_steps"] = True
+            if ref_digest is not None:
+                assert ref_digest == dg, f"sharded result {dg} != single-GPU result {ref_digest}"
+                checks["digest_equal_to_single_gpu"] = True
 
     if rank == 0:
         names = {K_KMER: "kmer_extract", K_FILTER: "bv_filter", K_SCORE: "pair_score", K_POA: "poa_align", K_POST: "post_msa"}
         kst = {names[k]: ctx.kernel_stats(k) for k in names}
-        ms, launches, alg = kst["poa_align"]
         # what this GPU sustains on a plain device-to-device copy (read + write bytes), SURVEY 8(d)
         buf = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(buf)
@@ -187,32 +299,71 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 10 * 2 * buf.numel() / (time.time() - tc) / 1e9
         del buf, dst
-        achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        cells = int(res[3][0])
+        par = ("replicas%d" % world) if a.weak else ("shard%d" % world)
         out = {
-            "metric": "reads/sec for `cluster`+`correct` on 1e6\u00d71kb synthetic ONT reads, 1\u21928 GPU",
+            "metric": METRIC if not a.iso else "reads/sec for `cluster --iso` (two-level, k=10 then k=11) on 1e6x1kb synthetic ONT cDNA reads",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if a.weak else "strong", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic", "inputs": "host buffers per step (PCIe inclusive)" if a.no_stage else "resident in HBM (rattle_hip_stage_reads)",
-            "config": {"workload": f"{a.reads} synthetic cDNA reads per GPU (mean 1 kb, 10% err, both strands, {genes} transcripts, "
-                                   "Zipf abundance), `rattle cluster` k=10 gene level + `rattle correct` "
-                                   "(BASELINE metric size; configs[1]/[3] shape on one GPU)",
-                       "reads_per_gpu": a.reads, "clusters": int(len(cl.main_id)), "poa_dp_cells_per_step": cells,
-                       "parallelism": f"shard{world}"},
-            "roofline": {"bound": "hbm", "kernel": "poa_align", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "measured_copy_gbs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                         "alg_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
-                         "launches": launches, "gcups": cells * a.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                         "note": "achieved = SURVEY 8(d)'s 6 B per DP cell x exact cells / kernel time; the packed column classes "
-                                 "store 2.25 B per cell (PMC traffic: profiles/round1i_pmc_hbm_traffic_300k.json)"},
+            "checks": checks,
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
-            "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items()},
-            "phase_reads_per_s": {k: total_reads / world / (v / a.steps) for k, v in PHASES.items() if v > 0},
+            "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items() if v > 0},
+            "phase_reads_per_s": {k: n_reads / (v / a.steps) for k, v in PHASES.items() if v > 0},
+            "cluster_counters": {"bv_pair_tests": int(cl.counters[0]), "full_comparisons": int(cl.counters[1]), "kmer_matches": int(cl.counters[2]),
+                                 "seed_rounds": int(cl.counters[3]), "kernel_launches": int(cl.counters[4])},
         }
-        if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cat, qcat, off, tid)
+        if sharded:
+            calls, xbytes = ctx.comm_stats()
+            out["exchange"] = {"transport": "gloo(host)" if (a.transport == "gloo" or same_device) else "rccl", "collectives": calls, "bytes_received": xbytes}
+        if a.iso:
+            out["config"] = {"workload": f"{n_reads} synthetic cDNA reads (mean 1 kb, 10% err, both strands, {genes} genes x 3 isoforms, Zipf abundance), "
+                                         "`rattle cluster --iso` k=10 / iso k=11 (BASELINE configs[2])",
+                             "reads": n_reads, "gene_clusters": checks["gene_clusters"], "transcript_clusters": checks["transcript_clusters"], "parallelism": par}
+            ms, launches, alg = kst["pair_score"]
+            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": "pair_score", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "alg_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                               "note": "8 B x (nK_i + nK_j) per full comparison (SURVEY 8d) / kernel time from HIP events"}
+        else:
+            n_cor, n_unc, n_cons, counters = res.counts()
+            cells = int(counters[0])
+            ms, launches, alg = kst["poa_align"]
+            # several ranks on one job: `cells` is the job's total, `ms` this GPU's kernel time -> per-GPU rate
+            per_gpu = world if sharded else 1
+            gcups = cells / per_gpu / (ms / a.steps * 1e-3) / 1e9 if ms > 0 else 0.0
+            hbm6 = 6.0 * gcups
+            pmc = pmc_reference()
+            ipc = pmc.get("valu_wave_instr_per_cell") if pmc else None
+            ach = gcups * 1e9 * ipc / 1e12 if ipc else None
+            out["config"] = {"workload": f"{n_reads} synthetic cDNA reads (mean 1 kb, 10% err, both strands, {genes} transcripts, Zipf abundance), "
+                                         "`rattle cluster` k=10 gene level + `rattle correct` (BASELINE metric size; configs[1]/[3] shape)"
+                                         + (" per GPU" if a.weak else ", ONE job over all GPUs"),
+                             "reads": n_reads, "clusters": int(len(cl.main_id)), "poa_dp_cells_per_step": cells, "poa_alignments_per_step": int(counters[1]),
+                             "packs": int(counters[2]), "parallelism": par}
+            out["roofline"] = {
+                # kernel C is bound by VALU issue / per-row latency, not by HBM (profiles/round2_*): priced in wave64 VALU
+                # instructions per second against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
+                "bound": "valu_issue", "kernel": "poa_align", "achieved": ach, "peak": VALU_PEAK_TINSTR, "unit": "Tinstr/s",
+                "frac": ach / VALU_PEAK_TINSTR if ach else None,
+                "valu_wave_instr_per_cell": ipc, "gcups": gcups, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+                "cells_per_launch": cells * a.steps / max(launches, 1),
+                # HBM view: SURVEY 8(d)'s 6 B per DP cell (three int16 matrices) and what the kernel really stores
+                "hbm": {"achieved_6B_per_cell_gbs": hbm6, "peak_gbs": 8000.0, "frac_6B_per_cell": hbm6 / 8000.0, "measured_copy_gbs": copy_gbs,
+                        "stored_bytes_per_cell": pmc.get("hbm_bytes_per_cell") if pmc else None,
+                        "achieved_stored_gbs": gcups * pmc["hbm_bytes_per_cell"] if pmc and pmc.get("hbm_bytes_per_cell") else None},
+                "traffic": (pmc["hbm_bytes_per_cell"] * cells * a.steps / max(launches, 1)) if pmc and pmc.get("hbm_bytes_per_cell") else None,
+                "pmc_source": "profiles/round2_pmc_poa.json" if pmc else None,
+                "note": "achieved = exact DP cells / kernel time (HIP events on the library's streams) x VALU wave-instructions per cell from the "
+                        "committed SQ_INSTS_VALU pass of this tree; traffic = FETCH_SIZE(x2) + WRITE_SIZE per cell from the committed PMC passes x cells per launch"}
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cat, qcat, off, tid)
         print(json.dumps(out))
+    if not a.iso:
+        res.free()
+        if warm is not None:
+            warm[1].free()
+    ctx.close()
     if use_dist:
         dist.destroy_process_group()
 

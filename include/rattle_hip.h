@@ -35,6 +35,10 @@ int rattle_hip_abi_version(void);
 
 /* Context = one HIP device + its streams and device-resident read index. */
 int rattle_hip_ctx_create(int device, rattle_ctx **out);
+/* A context WITHOUT a device, for a coordinating process and for CPU tests of the sharding: only
+ * rattle_hip_set_exchange and rattle_hip_correction_gather work on it; every compute entry point returns
+ * RATTLE_ERR_STATE (there is still no CPU path for the kernels). */
+int rattle_hip_ctx_create_host(rattle_ctx **out);
 void rattle_hip_ctx_destroy(rattle_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------
@@ -104,6 +108,7 @@ typedef struct {
     /* exact work counters: bit-vector pair tests, full comparisons, k-mer matches,
        seed rounds, kernel launches */
     uint64_t counters[8];
+    int32_t *gene_id;       /* [n_clusters] cseq_t::gene_id of the --iso flow (index of the gene cluster), else NULL */
 } rattle_cluster_set;
 
 /* Keep a copy of the reads (and, if not NULL, their qualities) in HBM.  Later calls of
@@ -132,6 +137,12 @@ int rattle_hip_cluster_subsets(rattle_ctx *ctx, const rattle_cluster_params *par
  * cluster_reads, then ids translated back to positions in the caller's order. */
 int rattle_hip_cluster_unsorted(rattle_ctx *ctx, const uint8_t *seq_concat, const uint64_t *offsets, uint32_t n_reads,
                                 int kmer_size, const rattle_cluster_params *params, rattle_cluster_set **out);
+/* `rattle cluster --iso` (main.cpp:254-323) for reads in FILE order: gene level with (kmer_size, params), every
+ * gene cluster sub-clustered with (iso_kmer_size, iso_params); result = the transcript clusters in gene order
+ * with gene_id set, ids = positions in the caller's order.  n_gene_clusters (optional) receives the first level's count. */
+int rattle_hip_cluster_iso_unsorted(rattle_ctx *ctx, const uint8_t *seq_concat, const uint64_t *offsets, uint32_t n_reads,
+                                    int kmer_size, int iso_kmer_size, const rattle_cluster_params *params,
+                                    const rattle_cluster_params *iso_params, rattle_cluster_set **out, uint32_t *n_gene_clusters);
 void rattle_hip_cluster_set_free(rattle_cluster_set *cs);
 
 /* ------------------------------------------------------------------------------------
@@ -159,8 +170,9 @@ void rattle_hip_msa_set_free(rattle_msa_set *ms);
  * Pack building (strided split, in-place reverse complement of `rev` members), POA #1 over
  * the raw reads of every pack, fix_msa_ends, column vote + per-read correction, POA #2 over
  * the corrected reads, pack consensus, POA #3 over the pack consensi of multi-pack clusters.
- * All POAs of one stage run in a single device launch; the post-MSA logic (correct.cpp:32-309)
- * runs on host threads, one pack per task, in the reference's double arithmetic.
+ * All POAs of one stage run in a single device pass (kernel C); the post-MSA logic
+ * (correct.cpp:32-309) is kernel D on the device, in the reference's double arithmetic and
+ * accumulation order.
  * Reads are given in FILE order with qualities (main.cpp:386); clusters index them by seq_id.
  * Outputs follow the reference's single-thread order: packs in queue order, pack consensi
  * collected in pack order (the reference's multi-thread run uses completion order).
@@ -169,10 +181,27 @@ void rattle_hip_msa_set_free(rattle_msa_set *ms);
 typedef struct {
     double min_occ, gap_occ, err_ratio;   /* 0.3, 0.3, 30.0 */
     int split, min_reads;                 /* 200, 5 */
-    int n_threads;                        /* host threads for the post-MSA logic; 0 = all cores */
+    int n_threads;                        /* host threads for pack planning / output assembly; 0 = all cores */
     char vote_order[8];                   /* column-vote tie order, 6 symbols; "" = "U-GTCA", the
                                              iteration order of the reference's unordered_map
                                              (correct.cpp:105-110,174) under libstdc++ */
+    /* Order in which a multi-pack cluster's pack consensi enter POA #3 (correct.cpp:469,520-526).  The
+     * reference collects them in worker COMPLETION order when n_threads > 1; the default here is pack
+     * order (the reference's single-thread order).  Optional override for n_pack_orders clusters:
+     * cluster pack_order_cluster[i] takes its packs in the order
+     * pack_order_perm[pack_order_offsets[i] .. pack_order_offsets[i+1]) -- a permutation of 0..np-1 over
+     * the cluster's packs that passed the min_reads test, in queue order. */
+    uint32_t n_pack_orders;
+    const uint32_t *pack_order_cluster;
+    const uint32_t *pack_order_offsets;
+    const uint32_t *pack_order_perm;
+    /* A pack whose POA does not fit the device (the DP record of one alignment outgrows the HBM left for
+     * the arena; 100 kb reads need > 10^10 cells per alignment in the reference as well) is SKIPPED, not
+     * fatal: its reads go to `uncorrected` untouched, it contributes no consensus, and it is listed in
+     * rattle_correction::skipped.  max_pack_cells > 0 additionally skips, before any device work, every
+     * pack whose largest alignment would need more than that many DP cells by the bound
+     * (6 * longest read + 64) * longest read; 0 = no such limit. */
+    uint64_t max_pack_cells;
 } rattle_correct_params;
 
 typedef struct {
@@ -185,9 +214,24 @@ typedef struct {
     char *qual;
 } rattle_read_set;
 
+/* Packs (stage 1, 2: POA #1 / #2 of a pack) or clusters (stage 3: POA #3) that were not processed. */
+typedef struct {
+    uint32_t n;
+    int32_t *cluster_id;    /* [n] */
+    uint32_t *pack;         /* [n] index of the pack among the cluster's queued packs (stage 3: 0) */
+    uint32_t *stage;        /* [n] 1: POA #1 did not fit (reads -> uncorrected), 2: POA #2 (no pack consensus),
+                                   3: POA #3 (no cluster consensus), 0: max_pack_cells rule */
+    uint64_t *read_off;     /* [n+1] range of the entry's reads in read_id */
+    int32_t *read_id;       /* original read indices */
+} rattle_skip_list;
+
 typedef struct {
     rattle_read_set corrected, uncorrected, consensi;
-    uint64_t counters[8];   /* DP cells, alignments, packs, ... */
+    uint64_t counters[8];   /* [0] DP cells, [1] alignments, [2] packs queued, [3] packs skipped, [4] reads in skipped packs */
+    rattle_skip_list skipped;
+    /* global pack index of every corrected / uncorrected record (0xFFFFFFFF: member of a pack that never
+     * entered the queue); what rattle_hip_correction_gather orders the merged result by */
+    uint32_t *corrected_pack, *uncorrected_pack;
 } rattle_correction;
 
 int rattle_hip_correct_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const uint8_t *qual_concat,
@@ -195,6 +239,60 @@ int rattle_hip_correct_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const u
                              const uint32_t *cluster_offsets, const int32_t *member_id, const uint8_t *member_rev,
                              const rattle_correct_params *params, rattle_correction **out);
 void rattle_hip_correction_free(rattle_correction *c);
+
+/* ------------------------------------------------------------------------------------
+ * One job over the GPUs of a node.  The reference parallelises the same axes with host
+ * threads: the strided candidate loop of a seed (cluster.cpp:138-158,189-209), the gene clusters of the
+ * --iso level (main.cpp:281-318) and the pack queue of `correct` (correct.cpp:377-392).  Here a context
+ * can be one RANK of nranks (one process or thread per GPU, every rank holding the same reads and making
+ * the same calls):
+ *   cluster_reads / cluster_unsorted : each rank scores its share of the candidates of a seed batch
+ *                                      (cyclic by candidate position), hit lists are all-gathered, every
+ *                                      rank resolves them identically -> identical results on all ranks;
+ *   cluster_subsets                  : gene clusters LPT-assigned to ranks by size, results all-gathered;
+ *   correct_reads                    : packs LPT-assigned by the cost proxy L_0 * sum L_j; both POAs of a
+ *                                      pack on one GPU; pack consensi all-gathered; POA #3 groups
+ *                                      LPT-assigned; every rank returns ITS packs' corrected / uncorrected
+ *                                      reads and ALL consensi; rattle_hip_correction_gather reassembles
+ *                                      the single-GPU result (same order, same bytes) on the root.
+ * Transports: RCCL over xGMI (rattle_hip_comm_init; device buffers, the library's own stream) or a
+ * caller-supplied all-gather on host buffers (rattle_hip_set_exchange; MPI / gloo / tests).
+ */
+/* all ranks call with their `send` (send_bytes == recv_bytes[rank]); recv receives the nranks pieces
+ * back to back in rank order.  Returns 0 on success. */
+typedef int (*rattle_allgatherv_fn)(void *user, const void *send, uint64_t send_bytes, void *recv, const uint64_t *recv_bytes);
+int rattle_hip_set_exchange(rattle_ctx *ctx, int rank, int nranks, rattle_allgatherv_fn fn, void *user);
+#define RATTLE_COMM_ID_BYTES 128
+int rattle_hip_comm_unique_id(uint8_t *id_out /* RATTLE_COMM_ID_BYTES, from rank 0, to be handed to every rank */);
+int rattle_hip_comm_init(rattle_ctx *ctx, int rank, int nranks, const uint8_t *id);
+int rattle_hip_comm_destroy(rattle_ctx *ctx);
+/* statistics of the exchange since context creation: collective calls, payload bytes received */
+int rattle_hip_comm_stats(rattle_ctx *ctx, uint64_t *calls, uint64_t *bytes);
+/* Collective: merges the per-rank results of rattle_hip_correct_reads on `root` (*merged is NULL on the
+ * other ranks).  With nranks == 1 it returns a copy. */
+int rattle_hip_correction_gather(rattle_ctx *ctx, const rattle_correction *local, int root, rattle_correction **merged);
+
+/* The work list of correct_reads without a device (pack building correct.cpp:328-370 and the static
+ * assignment to ranks), for callers that schedule themselves and for the CPU tests of the sharding. */
+typedef struct {
+    uint32_t n_packs;
+    uint32_t *pack_first;   /* [n_packs+1] member range */
+    int32_t *member_id;     /* read ids, pack after pack */
+    uint8_t *member_rev;
+    int32_t *pack_cluster;  /* [n_packs] */
+    uint32_t *pack_local;   /* [n_packs] index among the cluster's queued packs */
+    uint64_t *pack_cost;    /* [n_packs] L_0 * sum L_j */
+    uint32_t *pack_owner;   /* [n_packs] rank */
+    uint32_t n_unqueued;    /* members of packs that never enter the queue (<= min_reads, or max_pack_cells) */
+    int32_t *unqueued_id;
+    int32_t *unqueued_cluster;
+} rattle_pack_plan;
+int rattle_hip_plan_packs(const uint64_t *offsets, uint32_t n_reads, uint32_t n_clusters, const uint32_t *cluster_offsets,
+                          const int32_t *member_id, const uint8_t *member_rev, const rattle_correct_params *params, int nranks,
+                          rattle_pack_plan **out);
+void rattle_hip_pack_plan_free(rattle_pack_plan *p);
+/* longest-processing-time-first: items by cost descending (ties: lower index) to the least loaded rank (ties: lower rank) */
+int rattle_hip_lpt_assign(const uint64_t *cost, uint32_t n, int nranks, uint32_t *owner_out);
 
 /* Test hook, needs no device: phred_symbol's value `-10*log10(p)+33` (utils.cpp:6-8, before the narrowing to
  * char) through the threshold table the post-MSA kernel bisects and through the host libm.  Returns the number

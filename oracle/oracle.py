@@ -103,8 +103,9 @@ class Oracle(_Lib):
         assert len(order) == 6
         self.lib.orc_set_cv_order(C.c_char_p(order))
 
-    def correct(self, headers, seqs, quals, clusters_hps: bytes, min_occ=0.3, gap_occ=0.3, split=200, min_reads=5):
-        """Whole `correct`; returns (corrected, uncorrected, consensi) FASTQ texts + counters."""
+    def correct(self, headers, seqs, quals, clusters_hps: bytes, min_occ=0.3, gap_occ=0.3, split=200, min_reads=5, pack_order=None):
+        """Whole `correct`; returns (corrected, uncorrected, consensi) FASTQ texts + counters.
+        pack_order = {cluster: [pack indices]}: the order a cluster's pack consensi enter POA #3 in."""
         n = len(seqs)
         off = np.zeros(n + 1, np.uint64)
         off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
@@ -112,9 +113,15 @@ class Oracle(_Lib):
         H = (C.c_char_p * n)(*headers)
         a = C.c_void_p(); b = C.c_void_p(); c = C.c_void_p(); cnt = np.zeros(3, np.uint64)
         buf = (C.c_uint8 * len(clusters_hps)).from_buffer_copy(clusters_hps)
+        po = pack_order or {}
+        pcl = np.array(sorted(po), np.uint32)
+        poff = np.zeros(len(pcl) + 1, np.uint32)
+        poff[1:] = np.cumsum([len(po[int(x)]) for x in pcl])
+        pperm = np.array([y for x in pcl for y in po[int(x)]] + [0], np.uint32)
         rc = self.lib.orc_correct(C.c_char_p(cat), C.c_char_p(qcat), _ptr(off, C.c_uint64), C.c_uint32(n), H, buf,
                                   C.c_uint64(len(clusters_hps)), C.c_double(min_occ), C.c_double(gap_occ), C.c_int(split),
-                                  C.c_int(min_reads), C.byref(a), C.byref(b), C.byref(c), _ptr(cnt, C.c_uint64))
+                                  C.c_int(min_reads), C.byref(a), C.byref(b), C.byref(c), _ptr(cnt, C.c_uint64),
+                                  C.c_uint32(len(pcl)), _ptr(pcl, C.c_uint32), _ptr(poff, C.c_uint32), _ptr(pperm, C.c_uint32))
         if rc != 0:
             raise RuntimeError("orc_correct failed")
         out = tuple(C.string_at(x) for x in (a, b, c))

@@ -95,14 +95,17 @@ int64_t orc_poa_msa(const char *seqs, const uint64_t *off, uint32_t n, char *msa
 // byte encoding.  Writes the three FASTQ texts into malloc'd buffers (caller frees with orc_free).
 int32_t orc_correct(const char *seqs, const char *quals, const uint64_t *off, uint32_t n, const char *const *headers,
                     const uint8_t *clusters_hps, uint64_t clusters_len, double min_occ, double gap_occ, int split,
-                    int min_reads, char **corrected, char **uncorrected, char **consensi, uint64_t *counters) {
+                    int min_reads, char **corrected, char **uncorrected, char **consensi, uint64_t *counters,
+                    uint32_t n_pack_orders, const uint32_t *po_cluster, const uint32_t *po_offsets, const uint32_t *po_perm) {
     read_set_t rs = make_reads(seqs, off, n, quals);
     for (uint32_t i = 0; i < n; ++i) { rs[i].ann = "+"; if (headers) rs[i].header = headers[i]; }
     cluster_set_t cs;
     std::string b((const char *)clusters_hps, clusters_len);
     if (!hps_decode(b, 3, cs) && !hps_decode(b, 2, cs)) return -1;
     correct_counters_t cc;
-    correction_results_t R = correct_reads(cs, rs, min_occ, gap_occ, 30.0, split, min_reads, {}, &cc);
+    std::map<int, std::vector<int>> po;
+    for (uint32_t i = 0; i < n_pack_orders; ++i) po[(int)po_cluster[i]] = std::vector<int>(po_perm + po_offsets[i], po_perm + po_offsets[i + 1]);
+    correction_results_t R = correct_reads(cs, rs, min_occ, gap_occ, 30.0, split, min_reads, {}, &cc, n_pack_orders ? &po : nullptr);
     auto dump = [](const read_set_t &v) {
         std::string s;
         for (auto &r : v) s += r.header + "\n" + r.seq + "\n" + r.ann + "\n" + r.quality + "\n";

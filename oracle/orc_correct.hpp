@@ -11,6 +11,7 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <map>
 #include <queue>
 #include <string>
 #include <vector>
@@ -199,7 +200,8 @@ inline std::string strip_gaps(const std::vector<char> &v) {
 // correct.cpp:311-563, n_threads = 1.
 inline correction_results_t correct_reads(const cluster_set_t &clusters, read_set_t &reads, double min_occ, double gap_occ,
                                           double err_ratio, int split, int min_reads, const std::vector<std::string> &labels,
-                                          correct_counters_t *cc = nullptr) {
+                                          correct_counters_t *cc = nullptr,
+                                          const std::map<int, std::vector<int>> *pack_order = nullptr) {
     struct pack_t { int cid; read_set_t reads; };
     std::queue<pack_t> pending;
     correction_results_t R;
@@ -263,6 +265,16 @@ inline correction_results_t correct_reads(const cluster_set_t &clusters, read_se
         consensi[pack.cid].push_back(read_t{gid + "," + std::to_string(creads.size()) + "," + label_result, consensus, "+",
                                             std::string(consensus.size(), 'K')});
     }
+    // The reference's workers push pack consensi in COMPLETION order (:469); a given order (a permutation of
+    // the cluster's queued packs) reproduces one such run.  Default: pack order (n_threads == 1).
+    if (pack_order)
+        for (auto &po : *pack_order) {
+            read_set_t &it = consensi[po.first];
+            if (po.second.size() != it.size()) { fprintf(stderr, "oracle: pack order of cluster %d has %zu entries for %zu packs\n", po.first, po.second.size(), it.size()); abort(); }
+            read_set_t re;
+            for (int k : po.second) re.push_back(it[k]);
+            it.swap(re);
+        }
     cid = 0;
     for (auto &it : consensi) {                                // :489-556
         int total_reads = 0, gid = 0;

@@ -52,13 +52,97 @@ class Clusters:
         return out
 
 
+def correct_params(min_occ=0.3, gap_occ=0.3, err_ratio=30.0, split=200, min_reads=5, n_threads=0, vote_order: bytes = b"",
+                   pack_order=None, max_pack_cells=0):
+    """rattle_correct_params; pack_order = {cluster: [pack indices in the order their consensi enter POA #3]}.
+    Returns (struct, keep-alive list)."""
+    P = CorrectParams(min_occ, gap_occ, err_ratio, split, min_reads, n_threads, vote_order)
+    keep = []
+    if pack_order:
+        cl = np.array(sorted(pack_order), np.uint32)
+        offs = np.zeros(len(cl) + 1, np.uint32)
+        offs[1:] = np.cumsum([len(pack_order[int(c)]) for c in cl])
+        perm = np.array([x for c in cl for x in pack_order[int(c)]], np.uint32)
+        P.n_pack_orders = len(cl)
+        P.pack_order_cluster = _ptr(cl, C.c_uint32); P.pack_order_offsets = _ptr(offs, C.c_uint32); P.pack_order_perm = _ptr(perm, C.c_uint32)
+        keep = [cl, offs, perm]
+    P.max_pack_cells = int(max_pack_cells)
+    return P, keep
+
+
+def unpack_correction(R) -> dict:
+    """rattle_correction -> dict of record lists (read_id, cluster_id, n_reads, seq, qual), counters, skip list."""
+    def unpack(S):
+        n = S.n
+        o = np.ctypeslib.as_array(S.off, (n + 1,)).copy()
+        tot = int(o[n])
+        sq = C.string_at(S.seq, tot); ql = C.string_at(S.qual, tot)
+        rid = np.ctypeslib.as_array(S.read_id, (max(n, 1),))[:n]
+        cid = np.ctypeslib.as_array(S.cluster_id, (max(n, 1),))[:n]
+        nr = np.ctypeslib.as_array(S.n_reads, (max(n, 1),))[:n]
+        return [(int(rid[i]), int(cid[i]), int(nr[i]), sq[int(o[i]):int(o[i + 1])], ql[int(o[i]):int(o[i + 1])])
+                for i in range(n)]
+
+    K = R.skipped
+    skipped = []
+    if K.n:
+        ro = np.ctypeslib.as_array(K.read_off, (K.n + 1,))
+        rid = np.ctypeslib.as_array(K.read_id, (max(int(ro[K.n]), 1),))
+        for i in range(K.n):
+            skipped.append({"cluster": int(K.cluster_id[i]), "pack": int(K.pack[i]), "stage": int(K.stage[i]),
+                            "reads": [int(x) for x in rid[int(ro[i]):int(ro[i + 1])]]})
+    return {"corrected": unpack(R.corrected), "uncorrected": unpack(R.uncorrected), "consensi": unpack(R.consensi),
+            "counters": np.array(list(R.counters), dtype=np.uint64), "skipped": skipped}
+
+
+def correction_digest(R) -> int:
+    """CRC over every output array of a rattle_correction (ids, offsets, bases, qualities)."""
+    import zlib
+    crc = 0
+    for S in (R.corrected, R.uncorrected, R.consensi):
+        n = S.n
+        o = np.ctypeslib.as_array(S.off, (n + 1,))
+        tot = int(o[n])
+        crc = zlib.crc32(o.tobytes(), crc)
+        for arr in (S.read_id, S.cluster_id, S.n_reads):
+            crc = zlib.crc32(np.ctypeslib.as_array(arr, (max(n, 1),))[:n].tobytes(), crc)
+        crc = zlib.crc32(C.string_at(S.seq, tot), crc)
+        crc = zlib.crc32(C.string_at(S.qual, tot), crc)
+    return crc
+
+
+class CorrectionHandle:
+    """A library-owned rattle_correction kept alive by the caller (bench.py digests it outside the timed region)."""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def counts(self):
+        if self.ptr is None:
+            return (0, 0, 0, np.zeros(8, np.uint64))
+        R = self.ptr.contents
+        return (R.corrected.n, R.uncorrected.n, R.consensi.n, np.array(list(R.counters), dtype=np.uint64))
+
+    def digest(self):
+        return None if self.ptr is None else correction_digest(self.ptr.contents)
+
+    def free(self):
+        if self.ptr is not None:
+            self.lib.rattle_hip_correction_free(self.ptr)
+            self.ptr = None
+
+
 class Context:
     """One HIP device + the device-resident read index (rattle_ctx)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: Optional[int] = 0):
+        """device=None: a host-only context (exchange entry points only, rattle_hip_ctx_create_host)."""
         self.lib = _lib.load()
         h = C.c_void_p()
-        check(self.lib.rattle_hip_ctx_create(device, C.byref(h)))
+        if device is None:
+            check(self.lib.rattle_hip_ctx_create_host(C.byref(h)))
+        else:
+            check(self.lib.rattle_hip_ctx_create(device, C.byref(h)))
         self.h = h
         self.n = 0
         self.both = False
@@ -187,34 +271,50 @@ class Context:
                                                    C.byref(P), C.byref(out)))
         return self._take_clusters(out)
 
+    def cluster_iso_unsorted_packed(self, cat: np.ndarray, off: np.ndarray, k=10, iso_k=11, t_s=0.2, t_v=1000000.0, iso_t_s=0.3,
+                                    iso_t_v=25.0, bv_threshold=0.4, min_bv_threshold=0.2, bv_falloff=0.05, repr_percentile=0.15,
+                                    is_rna=False):
+        """`rattle cluster --iso` (main.cpp:254-323) on packed arrays in file order.  Returns (Clusters, gene_id per
+        cluster, number of gene clusters)."""
+        P = ClusterParams(t_s, t_v, bv_threshold, min_bv_threshold, bv_falloff, 0, 0, repr_percentile, int(is_rna))
+        Q = ClusterParams(iso_t_s, iso_t_v, bv_threshold, min_bv_threshold, bv_falloff, 0, 0, repr_percentile, int(is_rna))
+        out = C.POINTER(ClusterSet)()
+        ng = C.c_uint32()
+        check(self.lib.rattle_hip_cluster_iso_unsorted(self.h, _ptr(cat, C.c_uint8), _ptr(off, C.c_uint64), len(off) - 1, k, iso_k,
+                                                       C.byref(P), C.byref(Q), C.byref(out), C.byref(ng)))
+        nc = out.contents.n_clusters
+        gid = np.ctypeslib.as_array(out.contents.gene_id, (max(nc, 1),))[:nc].copy()
+        return self._take_clusters(out), gid, ng.value
+
     def correct_packed(self, cat: np.ndarray, qcat: np.ndarray, off: np.ndarray, cl: Clusters, min_occ=0.3, gap_occ=0.3,
-                       split=200, min_reads=5, n_threads=0, vote_order: bytes = b"", digest: bool = False):
+                       split=200, min_reads=5, n_threads=0, vote_order: bytes = b"", digest: bool = False, max_pack_cells=0,
+                       gather_root: Optional[int] = None, keep: bool = False):
         """correct_reads on packed arrays; returns (n_corrected, n_uncorrected, n_consensi, counters)
         without materialising Python objects (the library still builds every output record).
-        digest=True appends a CRC over every output array (ids, offsets, bases, qualities)."""
-        P = CorrectParams(min_occ, gap_occ, 30.0, split, min_reads, n_threads, vote_order)
+        digest=True appends a CRC over every output array (ids, offsets, bases, qualities).
+        gather_root: with several ranks, reassemble the sharded result on that rank
+        (rattle_hip_correction_gather); the other ranks get zero counts and digest None.
+        keep=True returns a CorrectionHandle instead (counts now, digest / free later)."""
+        P, keep_alive = correct_params(min_occ, gap_occ, 30.0, split, min_reads, n_threads, vote_order, None, max_pack_cells)
         out = C.POINTER(Correction)()
         mid = cl.member_id if len(cl.member_id) else np.zeros(1, np.int32)
         mrev = cl.member_rev if len(cl.member_rev) else np.zeros(1, np.uint8)
         check(self.lib.rattle_hip_correct_reads(self.h, _ptr(cat, C.c_uint8), _ptr(qcat, C.c_uint8), _ptr(off, C.c_uint64),
                                                 len(off) - 1, len(cl.main_id), _ptr(cl.offsets, C.c_uint32),
                                                 _ptr(mid, C.c_int32), _ptr(mrev, C.c_uint8), C.byref(P), C.byref(out)))
-        R = out.contents
-        res = (R.corrected.n, R.uncorrected.n, R.consensi.n, np.array(list(R.counters), dtype=np.uint64))
+        final = out
+        if gather_root is not None:
+            merged = C.POINTER(Correction)()
+            check(self.lib.rattle_hip_correction_gather(self.h, out, gather_root, C.byref(merged)))
+            self.lib.rattle_hip_correction_free(out)
+            final = merged
+        h = CorrectionHandle(self.lib, final if final else None)
+        if keep:
+            return h
+        res = h.counts()
         if digest:
-            import zlib
-            crc = 0
-            for S in (R.corrected, R.uncorrected, R.consensi):
-                n = S.n
-                o = np.ctypeslib.as_array(S.off, (n + 1,))
-                tot = int(o[n])
-                crc = zlib.crc32(o.tobytes(), crc)
-                for arr in (S.read_id, S.cluster_id, S.n_reads):
-                    crc = zlib.crc32(np.ctypeslib.as_array(arr, (max(n, 1),))[:n].tobytes(), crc)
-                crc = zlib.crc32(C.string_at(S.seq, tot), crc)
-                crc = zlib.crc32(C.string_at(S.qual, tot), crc)
-            res = res + (crc,)
-        self.lib.rattle_hip_correction_free(out)
+            res = res + (h.digest(),)
+        h.free()
         return res
 
     # a15
@@ -246,9 +346,12 @@ class Context:
 
     # a14-a20
     def correct_reads(self, seqs: Sequence[bytes], quals: Sequence[bytes], clusters, min_occ=0.3, gap_occ=0.3,
-                      err_ratio=30.0, split=200, min_reads=5, n_threads=0, vote_order: bytes = b""):
+                      err_ratio=30.0, split=200, min_reads=5, n_threads=0, vote_order: bytes = b"", pack_order=None,
+                      max_pack_cells=0, gather_root: Optional[int] = None):
         """correct_reads (correct.hpp:44).  `clusters` in rattle_amd.hps list form (ids index `seqs`).
-        Returns dict of three record lists: (read_id, cluster_id, n_reads, seq, qual)."""
+        Returns dict of three record lists: (read_id, cluster_id, n_reads, seq, qual), the counters and
+        the list of skipped packs.  With several ranks and gather_root set, the root gets the merged
+        result and the others None."""
         cat, off = pack_reads(seqs)
         qcat, qoff = pack_reads(quals)
         assert np.array_equal(off, qoff), "sequence and quality lengths differ"
@@ -258,28 +361,74 @@ class Context:
         mrev = np.array([s[1] for _, m in clusters for s in m], np.uint8)
         if len(mid) == 0:
             mid = np.zeros(1, np.int32); mrev = np.zeros(1, np.uint8)
-        P = CorrectParams(min_occ, gap_occ, err_ratio, split, min_reads, n_threads, vote_order)
+        P, keep = correct_params(min_occ, gap_occ, err_ratio, split, min_reads, n_threads, vote_order, pack_order, max_pack_cells)
         out = C.POINTER(Correction)()
         check(self.lib.rattle_hip_correct_reads(self.h, _ptr(cat, C.c_uint8), _ptr(qcat, C.c_uint8), _ptr(off, C.c_uint64),
                                                 len(seqs), len(clusters), _ptr(coff, C.c_uint32), _ptr(mid, C.c_int32),
                                                 _ptr(mrev, C.c_uint8), C.byref(P), C.byref(out)))
-        R = out.contents
-
-        def unpack(S):
-            n = S.n
-            o = np.ctypeslib.as_array(S.off, (n + 1,)).copy()
-            tot = int(o[n])
-            sq = C.string_at(S.seq, tot); ql = C.string_at(S.qual, tot)
-            rid = np.ctypeslib.as_array(S.read_id, (max(n, 1),))[:n]
-            cid = np.ctypeslib.as_array(S.cluster_id, (max(n, 1),))[:n]
-            nr = np.ctypeslib.as_array(S.n_reads, (max(n, 1),))[:n]
-            return [(int(rid[i]), int(cid[i]), int(nr[i]), sq[int(o[i]):int(o[i + 1])], ql[int(o[i]):int(o[i + 1])])
-                    for i in range(n)]
-
-        res = {"corrected": unpack(R.corrected), "uncorrected": unpack(R.uncorrected), "consensi": unpack(R.consensi),
-               "counters": np.array(list(R.counters), dtype=np.uint64)}
-        self.lib.rattle_hip_correction_free(out)
+        final = out
+        if gather_root is not None:
+            merged = C.POINTER(Correction)()
+            check(self.lib.rattle_hip_correction_gather(self.h, out, gather_root, C.byref(merged)))
+            self.lib.rattle_hip_correction_free(out)
+            final = merged
+        if not final:
+            return None
+        res = unpack_correction(final.contents)
+        self.lib.rattle_hip_correction_free(final)
         return res
+
+    # ---- one job over several GPUs (include/rattle_hip.h, "One job over the GPUs of a node")
+    def set_exchange_gloo(self, group=None):
+        """Host-buffer all-gather through torch.distributed (any backend that takes CPU tensors, e.g. gloo)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def fn(user, send, send_bytes, recv, recv_bytes):
+            try:
+                sizes = [int(recv_bytes[r]) for r in range(world)]
+                mine = torch.frombuffer(C.string_at(send, send_bytes) if send_bytes else b"\0", dtype=torch.uint8)[:send_bytes].clone()
+                pad = max(sizes + [1])
+                buf = torch.zeros(pad, dtype=torch.uint8)
+                buf[:send_bytes] = mine
+                parts = [torch.zeros(pad, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, buf, group=group)
+                at = 0
+                for r in range(world):
+                    if sizes[r]:
+                        C.memmove(recv + at, parts[r].numpy().ctypes.data, sizes[r])
+                    at += sizes[r]
+                return 0
+            except Exception as e:  # never unwind through the C frame
+                import sys
+                print(f"exchange callback failed: {e}", file=sys.stderr)
+                return 1
+
+        self._xchg_fn = _lib.ALLGATHERV_FN(fn)       # keep the thunk alive
+        check(self.lib.rattle_hip_set_exchange(self.h, rank, world, self._xchg_fn, None))
+
+    def comm_init_rccl(self, group=None):
+        """RCCL communicator for this context; the unique id travels through torch.distributed."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            check(self.lib.rattle_hip_comm_unique_id(_ptr(uid, C.c_uint8)))
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.from_numpy(uid).to(dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        uid = t.cpu().numpy().copy()
+        check(self.lib.rattle_hip_comm_init(self.h, rank, world, _ptr(uid, C.c_uint8)))
+
+    def comm_destroy(self):
+        check(self.lib.rattle_hip_comm_destroy(self.h))
+
+    def comm_stats(self):
+        a = C.c_uint64(); b = C.c_uint64()
+        check(self.lib.rattle_hip_comm_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def kernel_stats(self, kernel: int):
         ms = C.c_double(); n = C.c_uint64(); b = C.c_uint64()
@@ -332,11 +481,18 @@ def cluster_command(ctx: Context, seqs: Sequence[bytes], ann: Sequence[int], *, 
 
 
 def correct_command(ctx: Context, headers: Sequence[bytes], seqs: Sequence[bytes], quals: Sequence[bytes], clusters, *,
-                    min_occ=0.3, gap_occ=0.3, split=200, min_reads=5, n_threads=0, vote_order=b""):
+                    min_occ=0.3, gap_occ=0.3, split=200, min_reads=5, n_threads=0, vote_order=b"", pack_order=None,
+                    ann: Optional[Sequence[bytes]] = None, max_pack_cells=0, gather_root: Optional[int] = None,
+                    with_skipped=False):
     """`rattle correct` after input parsing (main.cpp:396-408): returns the three FASTQ texts
     (corrected, uncorrected, consensi) with the headers correct.cpp:348-353,540-549 builds
-    (no -l labels: `labels=` is empty)."""
-    res = ctx.correct_reads(seqs, quals, clusters, min_occ, gap_occ, 30.0, split, min_reads, n_threads, vote_order)
+    (no -l labels: `labels=` is empty).  `ann` = the third line of each input record: uncorrected reads
+    keep theirs (the reference pushes the original read_t, correct.cpp:362-366,289-293); corrected reads
+    and consensi get "+" (:286, :469)."""
+    res = ctx.correct_reads(seqs, quals, clusters, min_occ, gap_occ, 30.0, split, min_reads, n_threads, vote_order, pack_order,
+                            max_pack_cells, gather_root)
+    if res is None:
+        return None
     gene_mode = len(clusters) == 0 or clusters[0][0][2] == -1
 
     def tag(cid):
@@ -345,8 +501,9 @@ def correct_command(ctx: Context, headers: Sequence[bytes], seqs: Sequence[bytes
             return b",gene_cluster_%d" % cid
         return b",gene_cluster_%d,transcript_cluster_%d" % (gid, cid)
 
-    def fq(recs):
-        return b"".join(b"%s%s\n%s\n+\n%s\n" % (headers[r[0]], tag(r[1]), r[3], r[4]) for r in recs)
+    def fq(recs, keep_ann):
+        return b"".join(b"%s%s\n%s\n%s\n%s\n" % (headers[r[0]], tag(r[1]), r[3], ann[r[0]] if keep_ann and ann is not None else b"+", r[4])
+                        for r in recs)
 
     cons = []
     for rid, cid, nr, s, q in res["consensi"]:
@@ -355,4 +512,5 @@ def correct_command(ctx: Context, headers: Sequence[bytes], seqs: Sequence[bytes
         else:
             h = b"@transcript_cluster_%d gene_cluster_%d reads=%d labels=" % (cid, clusters[cid][0][2], nr)
         cons.append(b"%s\n%s\n+\n%s\n" % (h, s, q))
-    return fq(res["corrected"]), fq(res["uncorrected"]), b"".join(cons), res["counters"]
+    out = (fq(res["corrected"], False), fq(res["uncorrected"], True), b"".join(cons), res["counters"])
+    return out + (res["skipped"],) if with_skipped else out

@@ -26,10 +26,17 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
 
 using namespace rattle;
 
+// compute entry points need the context's device; a host-only context (rattle_hip_ctx_create_host) has none
+static int use_device(rattle_ctx *c) {
+    if (c->device < 0) { set_error("this context has no device (rattle_hip_ctx_create_host): only the exchange entry points work"); return RATTLE_ERR_STATE; }
+    RT_HIP(hipSetDevice(c->device));
+    return 0;
+}
+
 extern "C" {
 
 const char *rattle_hip_last_error(void) { return g_err.c_str(); }
-int rattle_hip_abi_version(void) { return 1; }
+int rattle_hip_abi_version(void) { return 2; }
 
 int rattle_hip_ctx_create(int device, rattle_ctx **out) {
     if (!out) { set_error("out is null"); return RATTLE_ERR_ARG; }
@@ -55,32 +62,24 @@ int rattle_hip_ctx_create(int device, rattle_ctx **out) {
     return 0;
 }
 
+int rattle_hip_ctx_create_host(rattle_ctx **out) {
+    if (!out) { set_error("out is null"); return RATTLE_ERR_ARG; }
+    rattle_ctx *c = new rattle_ctx();
+    c->device = -1;
+    c->timing = false;
+    *out = c;
+    return 0;
+}
+
 void rattle_hip_ctx_destroy(rattle_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    read_index &X = c->idx;
-    X.seq.release(); X.off.release(); X.koff.release(); X.len.release(); X.uh.release();
-    for (int s = 0; s < 2; ++s) { X.kh[s].release(); X.kp[s].release(); X.bv[s].release(); X.pc[s].release(); }
-    c->d_seed.release(); c->d_cand.release(); c->d_first.release(); c->d_lut.release(); c->d_pass.release();
-    c->d_surv.release(); c->d_counter.release(); c->d_pi.release(); c->d_pj.release(); c->d_ps.release();
-    c->d_res.release(); c->d_var.release(); c->d_scratch.release();
-    if (c->poa_arena) (void)hipFree(c->poa_arena);
-    for (int i = 0; i < 7; ++i) { if (c->poa_st[i]) (void)hipStreamDestroy(c->poa_st[i]); if (c->poa_ev[i]) (void)hipEventDestroy(c->poa_ev[i]); }
-    if (c->poa_go) (void)hipEventDestroy(c->poa_go);
-    c->h_poa_col.release();
-    c->d_staged_seq.release(); c->d_staged_qual.release();
-    c->d_phred_lo.release(); c->d_perr.release(); c->d_exc_bits.release(); c->d_exc_val.release();
-    c->h_surv.release(); c->h_res.release(); c->h_var.release(); c->h_counter.release();
-    (void)hipEventDestroy(c->ev0);
-    (void)hipEventDestroy(c->ev1);
-    (void)hipStreamDestroy(c->stream);
-    delete c;
+    (void)rattle_hip_comm_destroy(c);
+    delete c;            // ~rattle_ctx: streams, events, arena; the buffers release themselves
 }
 
 int rattle_hip_load_reads(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k, int both) {
     if (!c || !off || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     return build_index(c, seq, off, n, k, both);
 }
 
@@ -90,7 +89,7 @@ int rattle_hip_get_read_index(rattle_ctx *c, uint32_t r, int strand, uint32_t *h
     read_index &X = c->idx;
     if (r >= X.n) { set_error("read out of range"); return RATTLE_ERR_ARG; }
     if (strand < 0 || strand > 1 || (strand == 1 && !X.both)) { set_error("strand not indexed"); return RATTLE_ERR_ARG; }
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     uint64_t ko = X.h_koff[r], nk = X.h_koff[r + 1] - ko;
     if (nk && hash_out) RT_HIP(hipMemcpy(hash_out, X.kh[strand].p + ko, nk * 4, hipMemcpyDeviceToHost));
     if (nk && pos_out) RT_HIP(hipMemcpy(pos_out, X.kp[strand].p + ko, nk * 4, hipMemcpyDeviceToHost));
@@ -106,7 +105,7 @@ int rattle_hip_bv_filter(rattle_ctx *c, const uint32_t *seed_ids, uint32_t n_see
     for (uint32_t i = 0; i < n_seeds; ++i) if (seed_ids[i] >= c->idx.n) { set_error("seed id out of range"); return RATTLE_ERR_ARG; }
     for (uint32_t i = 0; i < n_cands; ++i) if (cand_ids[i] >= c->idx.n) { set_error("cand id out of range"); return RATTLE_ERR_ARG; }
     if (n_seeds == 0 || n_cands == 0) return 0;
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     hipStream_t st = c->stream;
     RT_TRY(c->d_seed.reserve(n_seeds)); RT_TRY(c->d_first.reserve(n_seeds)); RT_TRY(c->d_cand.reserve(n_cands));
     RT_TRY(c->d_lut.reserve(4097)); RT_TRY(c->d_pass.reserve((size_t)n_seeds * n_cands)); RT_TRY(c->d_counter.reserve(4));
@@ -130,7 +129,7 @@ int rattle_hip_pair_score(rattle_ctx *c, const uint32_t *i_ids, const uint32_t *
         if (strand[p] > 1 || (strand[p] == 1 && !X.both)) { set_error("strand not indexed"); return RATTLE_ERR_ARG; }
     }
     if (n == 0) return 0;
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     hipStream_t st = c->stream;
     RT_TRY(c->d_pi.reserve(n)); RT_TRY(c->d_pj.reserve(n)); RT_TRY(c->d_ps.reserve(n));
     RT_TRY(c->d_res.reserve((size_t)n * 4)); RT_TRY(c->d_var.reserve(n));
@@ -168,8 +167,10 @@ int rattle_hip_pair_score(rattle_ctx *c, const uint32_t *i_ids, const uint32_t *
 int rattle_hip_cluster_reads(rattle_ctx *c, const rattle_cluster_params *P, rattle_cluster_set **out) {
     if (!c || !P || !out) { set_error("null argument"); return RATTLE_ERR_ARG; }
     *out = nullptr;
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
+    // cluster.cpp:42: `if (is_rna) return {-1,false}` comes before the reverse test, so a both-strand index would over-cluster
+    if (P->is_rna && c->idx.both) { set_error("--rna mode needs the reads loaded with both_strands=0"); return RATTLE_ERR_STATE; }
     return cluster_driver(c, P, nullptr, 0, out);
 }
 
@@ -178,8 +179,10 @@ int rattle_hip_cluster_subset(rattle_ctx *c, const rattle_cluster_params *P, con
     if (!c || !P || !out || (n_subset && !subset)) { set_error("null argument"); return RATTLE_ERR_ARG; }
     *out = nullptr;
     for (uint32_t i = 0; i < n_subset; ++i) if (subset[i] >= c->idx.n) { set_error("subset id out of range"); return RATTLE_ERR_ARG; }
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
+    // cluster.cpp:42: `if (is_rna) return {-1,false}` comes before the reverse test, so a both-strand index would over-cluster
+    if (P->is_rna && c->idx.both) { set_error("--rna mode needs the reads loaded with both_strands=0"); return RATTLE_ERR_STATE; }
     static const uint32_t none = 0;
     return cluster_driver(c, P, n_subset ? subset : &none, n_subset, out);
 }
@@ -193,16 +196,28 @@ int rattle_hip_cluster_subsets(rattle_ctx *c, const rattle_cluster_params *P, co
     if (!c || !P || !outs || !sub_off || (n_subsets && sub_off[n_subsets] && !ids)) { set_error("null argument"); return RATTLE_ERR_ARG; }
     for (uint32_t i = 0; i < n_subsets; ++i) outs[i] = nullptr;
     for (uint64_t i = 0; i < sub_off[n_subsets]; ++i) if (ids[i] >= c->idx.n) { set_error("subset id out of range"); return RATTLE_ERR_ARG; }
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
+    // cluster.cpp:42: `if (is_rna) return {-1,false}` comes before the reverse test, so a both-strand index would over-cluster
+    if (P->is_rna && c->idx.both) { set_error("--rna mode needs the reads loaded with both_strands=0"); return RATTLE_ERR_STATE; }
     RT_HIP(hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> order(n_subsets);                       // largest subsets first
-    for (uint32_t i = 0; i < n_subsets; ++i) order[i] = i;
+    // several ranks: the subsets (gene clusters, main.cpp:281-318) are independent -> LPT over ranks by the
+    // pair count proxy n^2, every rank clusters its own and the results are all-gathered at the end
+    const int R = c->xchg.nranks, rk = c->xchg.rank;
+    std::vector<uint32_t> owner(n_subsets, 0);
+    if (R > 1) {
+        std::vector<uint64_t> cost(n_subsets);
+        for (uint32_t i = 0; i < n_subsets; ++i) { const uint64_t n = sub_off[i + 1] - sub_off[i]; cost[i] = n * n; }
+        lpt_assign(cost, R, owner);
+    }
+    std::vector<uint32_t> order;                                  // my subsets, largest first
+    for (uint32_t i = 0; i < n_subsets; ++i) if ((int)owner[i] == rk) order.push_back(i);
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         const uint64_t la = sub_off[a + 1] - sub_off[a], lb = sub_off[b + 1] - sub_off[b];
         return la != lb ? la > lb : a < b;
     });
-    const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(n_subsets, n_workers > 0 ? (uint32_t)n_workers : 16u));
+    const uint32_t n_mine = (uint32_t)order.size();
+    const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(n_mine, n_workers > 0 ? (uint32_t)n_workers : 16u));
     std::atomic<uint32_t> next(0);
     std::atomic<int> rc_all(0);
     std::mutex err_mu;
@@ -223,9 +238,9 @@ int rattle_hip_cluster_subsets(rattle_ctx *c, const rattle_cluster_params *P, co
             const read_index &Y = c->idx;
             X.n = Y.n; X.k = Y.k; X.both = Y.both; X.total_bases = Y.total_bases; X.total_kmers = Y.total_kmers;
             X.h_len = Y.h_len;
-            X.seq = Y.seq; X.off = Y.off; X.koff = Y.koff; X.len = Y.len; X.uh = Y.uh;
-            for (int s = 0; s < 2; ++s) { X.kh[s] = Y.kh[s]; X.kp[s] = Y.kp[s]; X.bv[s] = Y.bv[s]; X.pc[s] = Y.pc[s]; }
-            for (uint32_t t = next++; t < n_subsets && rc == 0 && rc_all.load() == 0; t = next++) {
+            X.seq.borrow(Y.seq); X.off.borrow(Y.off); X.koff.borrow(Y.koff); X.len.borrow(Y.len); X.uh.borrow(Y.uh);
+            for (int s = 0; s < 2; ++s) { X.kh[s].borrow(Y.kh[s]); X.kp[s].borrow(Y.kp[s]); X.bv[s].borrow(Y.bv[s]); X.pc[s].borrow(Y.pc[s]); }
+            for (uint32_t t = next++; t < n_mine && rc == 0 && rc_all.load() == 0; t = next++) {
                 const uint32_t i = order[t];
                 const uint32_t n = (uint32_t)(sub_off[i + 1] - sub_off[i]);
                 rc = cluster_driver(k, P, n ? ids + sub_off[i] : &none, n, &outs[i]);
@@ -235,30 +250,66 @@ int rattle_hip_cluster_subsets(rattle_ctx *c, const rattle_cluster_params *P, co
             std::lock_guard<std::mutex> g(err_mu);
             if (rc_all.load() == 0) { rc_all = rc; err_msg = rattle_hip_last_error(); }
         }
-        if (k->stream) (void)hipStreamSynchronize(k->stream);
-        k->d_seed.release(); k->d_cand.release(); k->d_first.release(); k->d_lut.release(); k->d_pass.release();
-        k->d_surv.release(); k->d_counter.release(); k->d_pi.release(); k->d_pj.release(); k->d_ps.release();
-        k->d_res.release(); k->d_var.release(); k->d_scratch.release();
-        k->h_surv.release(); k->h_res.release(); k->h_var.release(); k->h_counter.release();
-        if (k->ev0) (void)hipEventDestroy(k->ev0);
-        if (k->ev1) (void)hipEventDestroy(k->ev1);
-        if (k->stream) (void)hipStreamDestroy(k->stream);
-        delete k;                                                // the index buffers belong to the parent
+        delete k;                                                // borrowed index buffers stay with the parent
     };
     std::vector<std::thread> th;
     for (uint32_t t = 0; t < T; ++t) th.emplace_back(worker);
     for (auto &x : th) x.join();
-    if (rc_all.load() != 0) {
+    int rc = rc_all.load();
+    if (rc != 0) set_error(err_msg);
+    if (R > 1) {
+        // all ranks take part in the exchange even after a local failure (an empty payload marks it)
+        std::vector<uint8_t> mine;
+        auto put = [&mine](const void *p, size_t n) { const size_t at = mine.size(); mine.resize(at + n); if (n) memcpy(mine.data() + at, p, n); };
+        if (rc == 0)
+            for (uint32_t i : order) {
+                const rattle_cluster_set *cs = outs[i];
+                const uint32_t hdr[3] = {i, cs->n_clusters, cs->offsets[cs->n_clusters]};
+                put(hdr, 12); put(cs->counters, 64);
+                put(cs->main_id, (size_t)hdr[1] * 4); put(cs->offsets, ((size_t)hdr[1] + 1) * 4); put(cs->member_id, (size_t)hdr[2] * 4);
+                put(cs->main_rev, hdr[1]); put(cs->member_rev, hdr[2]);
+                const uint8_t z[4] = {0, 0, 0, 0};
+                put(z, (4 - (hdr[1] + hdr[2]) % 4) % 4);
+            }
+        else { const uint32_t bad = 0xFFFFFFFFu; put(&bad, 4); }
+        std::vector<std::vector<uint8_t>> all;
+        int xrc = xchg_allgatherv(c, mine, all);
+        if (rc == 0) rc = xrc;
+        for (int r = 0; r < R && rc == 0; ++r) {
+            if (r == rk) continue;
+            const std::vector<uint8_t> &b = all[r];
+            if (b.size() == 4) { set_error("cluster_subsets failed on rank " + std::to_string(r)); rc = RATTLE_ERR_HIP; break; }
+            size_t at = 0;
+            while (at + 12 <= b.size()) {
+                uint32_t hdr[3];
+                memcpy(hdr, b.data() + at, 12); at += 12;
+                if (hdr[0] >= n_subsets || outs[hdr[0]]) { set_error("cluster_subsets exchange: malformed record"); rc = RATTLE_ERR_HIP; break; }
+                rattle_cluster_set *cs = (rattle_cluster_set *)calloc(1, sizeof(rattle_cluster_set));
+                cs->n_clusters = hdr[1];
+                memcpy(cs->counters, b.data() + at, 64); at += 64;
+                cs->main_id = (int32_t *)malloc(std::max<size_t>(1, hdr[1]) * 4); cs->offsets = (uint32_t *)malloc(((size_t)hdr[1] + 1) * 4);
+                cs->member_id = (int32_t *)malloc(std::max<size_t>(1, hdr[2]) * 4);
+                cs->main_rev = (uint8_t *)malloc(std::max<size_t>(1, hdr[1])); cs->member_rev = (uint8_t *)malloc(std::max<size_t>(1, hdr[2]));
+                memcpy(cs->main_id, b.data() + at, (size_t)hdr[1] * 4); at += (size_t)hdr[1] * 4;
+                memcpy(cs->offsets, b.data() + at, ((size_t)hdr[1] + 1) * 4); at += ((size_t)hdr[1] + 1) * 4;
+                memcpy(cs->member_id, b.data() + at, (size_t)hdr[2] * 4); at += (size_t)hdr[2] * 4;
+                memcpy(cs->main_rev, b.data() + at, hdr[1]); at += hdr[1];
+                memcpy(cs->member_rev, b.data() + at, hdr[2]); at += hdr[2];
+                at += (4 - (hdr[1] + hdr[2]) % 4) % 4;
+                outs[hdr[0]] = cs;
+            }
+        }
+    }
+    if (rc != 0) {
         for (uint32_t i = 0; i < n_subsets; ++i) { rattle_hip_cluster_set_free(outs[i]); outs[i] = nullptr; }
-        set_error(err_msg);
-        return rc_all.load();
+        return rc;
     }
     return 0;
 }
 
 int rattle_hip_stage_reads(rattle_ctx *c, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n) {
     if (!c || !off || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     const uint64_t total = off[n] - off[0];
     c->staged_seq_key = nullptr; c->staged_qual_key = nullptr;
     RT_TRY(c->d_staged_seq.reserve(total + 64));
@@ -279,14 +330,10 @@ int rattle_hip_unstage_reads(rattle_ctx *c) {
     return 0;
 }
 
-int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k,
-                                const rattle_cluster_params *P, rattle_cluster_set **out) {
-    if (!c || !off || !P || !out || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
-    *out = nullptr;
-    RT_HIP(hipSetDevice(c->device));
-    phase_timer T_all("cluster_unsorted: total");
-    // main.cpp:254-262: stable sort by length, longest first (counting sort; lengths are small integers)
-    std::vector<uint32_t> order(n);
+// main.cpp:254-262: stable sort by length, longest first (counting sort; lengths are small integers), the reads
+// gathered into processing order (on the device when they are staged there) and indexed with k-mer size k
+static int sort_and_index(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k, int both, std::vector<uint32_t> &order) {
+    order.resize(n);
     {
         phase_timer T("cluster: sort + gather");
         uint64_t max_len = 0;
@@ -317,23 +364,31 @@ int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_
         RT_TRY(d_desc.reserve(n)); RT_TRY(d_cat.reserve(soff[n] + 64));
         RT_HIP(hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n * sizeof(gather_desc), hipMemcpyHostToDevice, c->stream));
         RT_TRY(launch_gather(c, d_desc.p, n, c->d_staged_seq.p, nullptr, d_cat.p, nullptr));
-        int rc = build_index(c, d_cat.p, soff.data(), n, k, P->is_rna ? 0 : 1);
+        int rc = build_index(c, d_cat.p, soff.data(), n, k, both);
         RT_HIP(hipStreamSynchronize(c->stream));
-        d_desc.release(); d_cat.release();
-        if (rc) return rc;
-    } else {
-        std::unique_ptr<uint8_t[]> cat(new uint8_t[off[n] - off[0] + 1]);
-        {
-            phase_timer T("cluster: host gather");
-            const size_t chunk = 2048;
-            parallel_for((n + chunk - 1) / chunk, 0, [&](size_t ch) {
-                for (size_t i = ch * chunk; i < std::min<size_t>(n, (ch + 1) * chunk); ++i)
-                    memcpy(cat.get() + soff[i], seq + off[order[i]], soff[i + 1] - soff[i]);
-            });
-        }
-        phase_timer T("cluster: build_index");
-        RT_TRY(build_index(c, cat.get(), soff.data(), n, k, P->is_rna ? 0 : 1));
+        return rc;
     }
+    std::unique_ptr<uint8_t[]> cat(new uint8_t[off[n] - off[0] + 1]);
+    {
+        phase_timer T("cluster: host gather");
+        const size_t chunk = 2048;
+        parallel_for((n + chunk - 1) / chunk, 0, [&](size_t ch) {
+            for (size_t i = ch * chunk; i < std::min<size_t>(n, (ch + 1) * chunk); ++i)
+                memcpy(cat.get() + soff[i], seq + off[order[i]], soff[i + 1] - soff[i]);
+        });
+    }
+    phase_timer T("cluster: build_index");
+    return build_index(c, cat.get(), soff.data(), n, k, both);
+}
+
+int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k,
+                                const rattle_cluster_params *P, rattle_cluster_set **out) {
+    if (!c || !off || !P || !out || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    RT_TRY(use_device(c));
+    phase_timer T_all("cluster_unsorted: total");
+    std::vector<uint32_t> order;
+    RT_TRY(sort_and_index(c, seq, off, n, k, P->is_rna ? 0 : 1, order));
     { phase_timer T("cluster: greedy driver"); RT_TRY(cluster_driver(c, P, nullptr, 0, out)); }
     rattle_cluster_set *cs = *out;
     const uint32_t nm = cs->offsets[cs->n_clusters];
@@ -342,9 +397,66 @@ int rattle_hip_cluster_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_
     return 0;
 }
 
+// `rattle cluster --iso`, main.cpp:254-323, for reads in FILE order: gene level with (k, gene params), then every
+// gene cluster's members -- re-sorted by length desc, ties larger id first (:285-291; the order cluster_reads
+// already leaves them in) -- clustered again with (iso_k, iso params); transcript clusters appended in gene
+// order, each carrying its gene's index.
+int rattle_hip_cluster_iso_unsorted(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, uint32_t n, int k, int iso_k,
+                                    const rattle_cluster_params *P, const rattle_cluster_params *iso_P, rattle_cluster_set **out,
+                                    uint32_t *n_gene_clusters) {
+    if (!c || !off || !P || !iso_P || !out || (n && !seq)) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    RT_TRY(use_device(c));
+    phase_timer T_all("cluster_iso_unsorted: total");
+    std::vector<uint32_t> order;
+    RT_TRY(sort_and_index(c, seq, off, n, k, P->is_rna ? 0 : 1, order));
+    rattle_cluster_set *gene = nullptr;
+    { phase_timer T("cluster: gene level"); RT_TRY(cluster_driver(c, P, nullptr, 0, &gene)); }
+    struct freer { rattle_cluster_set *p; ~freer() { rattle_hip_cluster_set_free(p); } } gene_free{gene};
+    if (n_gene_clusters) *n_gene_clusters = gene->n_clusters;
+    // second index with the iso k-mer size over the same (already sorted, device-resident) reads
+    {
+        phase_timer T("cluster: iso index");
+        std::vector<uint64_t> soff = c->idx.h_off;
+        RT_TRY(build_index(c, c->idx.seq.p, soff.data(), n, iso_k, iso_P->is_rna ? 0 : 1));
+    }
+    const uint32_t G = gene->n_clusters;
+    std::vector<uint32_t> ids(gene->offsets[G] ? gene->offsets[G] : 1);
+    std::vector<uint64_t> sub_off(G + 1, 0);
+    for (uint32_t g = 0; g <= G; ++g) sub_off[g] = gene->offsets[g];
+    for (uint32_t i = 0; i < gene->offsets[G]; ++i) ids[i] = (uint32_t)gene->member_id[i];
+    std::vector<rattle_cluster_set *> subs(G ? G : 1, nullptr);
+    { phase_timer T("cluster: iso level"); RT_TRY(rattle_hip_cluster_subsets(c, iso_P, ids.data(), sub_off.data(), G, subs.data(), 0)); }
+    size_t nc = 0, nm = 0;
+    for (uint32_t g = 0; g < G; ++g) { nc += subs[g]->n_clusters; nm += subs[g]->offsets[subs[g]->n_clusters]; }
+    rattle_cluster_set *R = (rattle_cluster_set *)calloc(1, sizeof(rattle_cluster_set));
+    R->n_clusters = (uint32_t)nc;
+    R->main_id = (int32_t *)malloc(std::max<size_t>(1, nc) * 4); R->main_rev = (uint8_t *)malloc(std::max<size_t>(1, nc));
+    R->gene_id = (int32_t *)malloc(std::max<size_t>(1, nc) * 4);
+    R->offsets = (uint32_t *)malloc((nc + 1) * 4);
+    R->member_id = (int32_t *)malloc(std::max<size_t>(1, nm) * 4); R->member_rev = (uint8_t *)malloc(std::max<size_t>(1, nm));
+    uint32_t ci = 0, mi = 0;
+    for (int i = 0; i < 8; ++i) R->counters[i] = gene->counters[i];
+    for (uint32_t g = 0; g < G; ++g) {
+        const rattle_cluster_set *S = subs[g];
+        const uint32_t *gids = ids.data() + sub_off[g];
+        for (uint32_t k2 = 0; k2 < S->n_clusters; ++k2) {
+            R->main_id[ci] = (int32_t)order[gids[S->main_id[k2]]]; R->main_rev[ci] = S->main_rev[k2]; R->gene_id[ci] = (int32_t)g;
+            R->offsets[ci] = mi;
+            for (uint32_t t = S->offsets[k2]; t < S->offsets[k2 + 1]; ++t) { R->member_id[mi] = (int32_t)order[gids[S->member_id[t]]]; R->member_rev[mi] = S->member_rev[t]; ++mi; }
+            ++ci;
+        }
+        for (int i = 0; i < 8; ++i) R->counters[i] += S->counters[i];
+        rattle_hip_cluster_set_free(subs[g]);
+    }
+    R->offsets[nc] = mi;
+    *out = R;
+    return 0;
+}
+
 void rattle_hip_cluster_set_free(rattle_cluster_set *cs) {
     if (!cs) return;
-    free(cs->main_id); free(cs->main_rev); free(cs->offsets); free(cs->member_id); free(cs->member_rev);
+    free(cs->main_id); free(cs->main_rev); free(cs->offsets); free(cs->member_id); free(cs->member_rev); free(cs->gene_id);
     free(cs);
 }
 
@@ -352,7 +464,7 @@ int rattle_hip_poa_msa(rattle_ctx *c, const uint8_t *seq, const uint64_t *off, u
                        uint32_t n_packs, rattle_msa_set **out) {
     if (!c || !off || !pack_first || !out) { set_error("null argument"); return RATTLE_ERR_ARG; }
     *out = nullptr;
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     return poa_msa_run(c, seq, off, n_seqs, pack_first, n_packs, out);
 }
 
@@ -370,7 +482,7 @@ int rattle_hip_correct_reads(rattle_ctx *c, const uint8_t *seq, const uint8_t *q
         return RATTLE_ERR_ARG;
     }
     *out = nullptr;
-    RT_HIP(hipSetDevice(c->device));
+    RT_TRY(use_device(c));
     int rc = correct_driver(c, seq, qual, off, n_reads, n_clusters, coff, mid, mrev, P, out);
     if (rc != 0 && *out) { rattle_hip_correction_free(*out); *out = nullptr; }
     return rc;
@@ -383,6 +495,8 @@ static void free_set(rattle_read_set &s) {
 void rattle_hip_correction_free(rattle_correction *r) {
     if (!r) return;
     free_set(r->corrected); free_set(r->uncorrected); free_set(r->consensi);
+    free(r->skipped.cluster_id); free(r->skipped.pack); free(r->skipped.stage); free(r->skipped.read_off); free(r->skipped.read_id);
+    free(r->corrected_pack); free(r->uncorrected_pack);
     free(r);
 }
 

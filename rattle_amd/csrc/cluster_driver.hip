@@ -9,6 +9,11 @@
 //   level 1: seeds x seeds  -> which seeds are absorbed by an earlier seed (exact founders)
 //   level 2: founders x all remaining items -> each item joins the FIRST founder that accepts it
 // The merge passes (cluster.cpp:171-256) are the same procedure over cluster representatives.
+//
+// One job over several GPUs: the reference cuts the candidate loop of a seed over its threads
+// (cluster.cpp:138-158: thread t takes candidates t, t+T, ...).  Here rank r of R scores the candidates at
+// positions r, r+R, ... of every level-2 evaluation (level 1, 256 x 256, is replicated), the accepted
+// (seed, candidate, strand) triples are all-gathered and every rank resolves them identically.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -73,8 +78,43 @@ struct driver {
     }
 
     // Evaluate cluster_together for every (seed s, cand c >= first[s]); seeds/cands are LOCAL ids.
+    // shard: this rank scores the candidates at positions rank, rank + nranks, ... and the hits of all ranks
+    // are all-gathered (every rank ends up with the same list; the callers sort it).
+    std::vector<uint32_t> sh_cands, sh_first;
     int eval(const std::vector<uint32_t> &seeds, const uint32_t *cands, uint32_t n_cands, const std::vector<uint32_t> &first,
-             double thr, std::vector<hit_t> &hits) {
+             double thr, std::vector<hit_t> &hits, bool shard = false) {
+        const int R = ctx->xchg.nranks, r = ctx->xchg.rank;
+        if (!shard || R <= 1) return eval_local(seeds, cands, n_cands, first, thr, hits);
+        sh_cands.clear();
+        for (uint32_t c = (uint32_t)r; c < n_cands; c += (uint32_t)R) sh_cands.push_back(cands[c]);
+        sh_first.resize(first.size());
+        for (size_t i = 0; i < first.size(); ++i) sh_first[i] = first[i] <= (uint32_t)r ? 0u : (first[i] - (uint32_t)r + (uint32_t)R - 1u) / (uint32_t)R;
+        uint64_t before[3] = {counters[0], counters[1], counters[2]};
+        RT_TRY(eval_local(seeds, sh_cands.data(), (uint32_t)sh_cands.size(), sh_first, thr, hits));
+        // payload: three counter deltas, then (seed, global candidate position, strand) triples
+        std::vector<uint8_t> mine(24 + hits.size() * 12);
+        for (int i = 0; i < 3; ++i) { const uint64_t d = counters[i] - before[i]; memcpy(mine.data() + 8 * i, &d, 8); counters[i] = before[i]; }
+        for (size_t i = 0; i < hits.size(); ++i) {
+            const uint32_t t[3] = {hits[i].seed, hits[i].cand * (uint32_t)R + (uint32_t)r, hits[i].rev};
+            memcpy(mine.data() + 24 + 12 * i, t, 12);
+        }
+        std::vector<std::vector<uint8_t>> all;
+        RT_TRY(xchg_allgatherv(ctx, mine, all));
+        hits.clear();
+        for (const std::vector<uint8_t> &b : all) {
+            if (b.size() < 24 || (b.size() - 24) % 12) { set_error("cluster exchange: malformed hit list"); return RATTLE_ERR_HIP; }
+            for (int i = 0; i < 3; ++i) { uint64_t d; memcpy(&d, b.data() + 8 * i, 8); counters[i] += d; }
+            for (size_t at = 24; at < b.size(); at += 12) {
+                uint32_t t[3];
+                memcpy(t, b.data() + at, 12);
+                hits.push_back(hit_t{t[0], t[1], (uint8_t)t[2]});
+            }
+        }
+        return 0;
+    }
+
+    int eval_local(const std::vector<uint32_t> &seeds, const uint32_t *cands, uint32_t n_cands, const std::vector<uint32_t> &first,
+                   double thr, std::vector<hit_t> &hits) {
         hits.clear();
         uint32_t ns = (uint32_t)seeds.size();
         if (ns == 0 || n_cands == 0) return 0;
@@ -111,6 +151,7 @@ struct driver {
             RT_HIP(hipMemcpyAsync(ctx->h_counter.p, ctx->d_counter.p, 4, hipMemcpyDeviceToHost, st));
             RT_HIP(hipStreamSynchronize(st));
             nsurv = ctx->h_counter.p[0];
+            if ((uint64_t)nsurv > npairs * 2) { set_error("bv_filter: survivor counter overflow"); return RATTLE_ERR_HIP; }
             if (nsurv <= cap) break;
             cap = (size_t)nsurv + nsurv / 8;
         }
@@ -213,6 +254,13 @@ struct driver {
         while (!remaining.empty()) {
             counters[3]++;
             uint32_t B = (uint32_t)std::min<size_t>(batch, remaining.size());
+            {
+                // every pair can survive the filter (the thr == 0 pass lets all of them through, cluster.cpp:19,43): keep
+                // seeds x candidates x strands below the 32-bit survivor counter, and below 64 M where all of them DO survive
+                const uint64_t per_seed = (uint64_t)remaining.size() * (ctx->idx.both ? 2u : 1u);
+                const uint64_t cap = thr == 0.0 ? (64ull << 20) : (1ull << 31);
+                B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, cap / std::max<uint64_t>(per_seed, 1)));
+            }
             // ---- level 1: seeds x seeds
             seeds_local.resize(B);
             first.resize(B);
@@ -248,7 +296,7 @@ struct driver {
                 std::vector<uint32_t> fl(founders.size());
                 ffirst.assign(founders.size(), 0);
                 for (size_t f = 0; f < founders.size(); ++f) fl[f] = seeds_local[founders[f]];
-                RT_TRY(eval(fl, cands_local.data(), nrest, ffirst, thr, hits));
+                RT_TRY(eval(fl, cands_local.data(), nrest, ffirst, thr, hits, true));
                 std::sort(hits.begin(), hits.end(), [](const hit_t &a, const hit_t &b) {
                     return a.seed != b.seed ? a.seed < b.seed : (a.cand != b.cand ? a.cand < b.cand : a.rev < b.rev);
                 });

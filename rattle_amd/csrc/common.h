@@ -66,25 +66,35 @@ void parallel_for(size_t n, int n_threads, F f) {
         if (r__ != 0) return r__; \
     } while (0)
 
-// Growable device buffer (never shrinks; contents are not preserved across grow()).
+// Growable device buffer (never shrinks; contents are not preserved across grow()).  Owns its
+// allocation and frees it on destruction, so early error returns do not leak HBM; borrow() makes a
+// non-owning view of another buffer (the child contexts of cluster_subsets share the parent's index).
 template <typename T>
 struct dbuf {
     T *p = nullptr;
     size_t cap = 0;
+    bool owned = true;
+    dbuf() = default;
+    dbuf(const dbuf &) = delete;
+    dbuf &operator=(const dbuf &) = delete;
+    ~dbuf() { release(); }
     int reserve(size_t n) {
         if (n <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
+        release();
         size_t want = n + n / 4 + 64;
         RT_HIP(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
         return 0;
     }
+    void borrow(const dbuf &o) {
+        release();
+        p = o.p; cap = o.cap; owned = false;
+    }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        owned = true;
     }
 };
 
@@ -93,11 +103,13 @@ template <typename T>
 struct hbuf {
     T *p = nullptr;
     size_t cap = 0;
+    hbuf() = default;
+    hbuf(const hbuf &) = delete;
+    hbuf &operator=(const hbuf &) = delete;
+    ~hbuf() { release(); }
     int reserve(size_t n) {
         if (n <= cap) return 0;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
+        release();
         size_t want = n + n / 4 + 64;
         RT_HIP(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
         cap = want;
@@ -145,6 +157,44 @@ struct phred_table {
 };
 void build_phred_table(phred_table &T);
 int phred_lookup_host(const phred_table &T, double p);
+
+// ---- one job over several GPUs (exchange.hip) ----------------------------------------------------------
+// The path shards by independent objects: candidate reads of a seed batch, --iso gene clusters,
+// `correct` packs.  A context may be one rank of nranks; the only data-path communication is an
+// all-gather(v) of small byte strings (hit lists, cluster sets, pack consensi) plus the final gather of
+// the corrected reads.  Two transports: RCCL on device buffers (rattle_hip_comm_init) or a caller-supplied
+// host-buffer all-gather (rattle_hip_set_exchange: MPI, gloo, tests).
+struct exchange {
+    int rank = 0, nranks = 1;
+    rattle_allgatherv_fn fn = nullptr;
+    void *user = nullptr;
+    void *comm = nullptr;               // ncclComm_t
+    void *rccl = nullptr;               // dlopen handle of librccl.so
+    uint64_t calls = 0, bytes = 0;      // statistics
+};
+
+// `correct` work list: the packs of correct.cpp:328-370 from ids and lengths only, plus the static
+// assignment of packs to ranks (LPT by the DP cost proxy L_0 * sum L_j).  Pure host code.
+struct sref { int32_t rid; uint8_t rev; };
+struct pack_plan {
+    std::vector<sref> members;          // members of all queued packs, pack after pack
+    std::vector<uint32_t> first;        // [n_packs+1] into members
+    std::vector<int32_t> pk_cid;        // cluster of each pack
+    std::vector<uint32_t> pk_local;     // index among its cluster's queued packs
+    std::vector<uint64_t> pk_cost;
+    std::vector<uint32_t> pk_owner;     // rank
+    std::vector<uint32_t> cl_p0, cl_np; // per cluster: first pack, number of packs
+    std::vector<sref> small;            // members of packs that are never queued, in the reference's order
+    std::vector<int32_t> small_cid;
+    std::vector<uint8_t> small_why;     // 0: <= min_reads (correct.cpp:360), 1: max_pack_cells rule
+    std::vector<uint32_t> small_pack;   // local pack index within the cluster
+};
+int plan_packs(const uint64_t *off, uint32_t n_reads, uint32_t n_clusters, const uint32_t *coff, const int32_t *mid, const uint8_t *mrev,
+               const rattle_correct_params *P, int nranks, pack_plan &out);
+// longest-processing-time-first assignment of weighted items to nranks bins (ties: lower index / lower rank)
+void lpt_assign(const std::vector<uint64_t> &cost, int nranks, std::vector<uint32_t> &owner);
+// all-gather of one byte string per rank (sizes first, then the payload)
+int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all);
 
 // copy descriptor of the gather kernel: flags bit 0 = reverse complement (qualities reversed)
 struct gather_desc {
@@ -220,6 +270,22 @@ struct rattle_ctx {
     rattle::dbuf<unsigned long long> d_exc_bits;
     rattle::dbuf<int32_t> d_exc_val;
     bool phred_ready = false;
+    rattle::exchange xchg;
+    rattle_ctx() = default;
+    rattle_ctx(const rattle_ctx &) = delete;
+    rattle_ctx &operator=(const rattle_ctx &) = delete;
+    // streams, events and the arena; the dbuf / hbuf members release themselves
+    ~rattle_ctx() {
+        if (device < 0) return;                 // host-only context: nothing on a device
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (poa_arena) (void)hipFree(poa_arena);
+        for (int i = 0; i < 7; ++i) { if (poa_st[i]) (void)hipStreamDestroy(poa_st[i]); if (poa_ev[i]) (void)hipEventDestroy(poa_ev[i]); }
+        if (poa_go) (void)hipEventDestroy(poa_go);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace rattle {
@@ -256,7 +322,7 @@ int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs);
 // poa.hip : device-resident POA over packs (sequences, offsets, column output in HBM)
 int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n_seqs,
                    const uint32_t *h_pack_first, uint32_t n_packs, uint32_t *d_col, uint32_t *d_width, uint32_t *h_width,
-                   unsigned long long *h_cnt);
+                   unsigned long long *h_cnt, std::vector<uint8_t> *skipped);
 // post_msa.hip
 int launch_gather(rattle_ctx *ctx, const gather_desc *d_desc, uint32_t n, const uint8_t *sseq, const uint8_t *squal, uint8_t *dseq,
                   uint8_t *dqual);

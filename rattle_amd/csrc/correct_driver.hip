@@ -5,9 +5,17 @@
 // independent, so here each POA stage is ONE device pass over all packs, and the post-MSA logic
 // (fix_msa_ends :32-92, column vote :94-193, per-read correction :196-309) is kernel D
 // (post_msa.hip), one workgroup per pack.  Sequences, qualities, MSA columns and row matrices stay
-// in HBM from the upload of the reads to the download of the corrected reads and consensi; between
-// stages the host only sees lengths (pack widths, corrected read lengths, trim counts), from which it
-// plans the next stage (pack order, length-sorted order for POA #2, gather descriptors).
+// in HBM from the upload of the reads to the download of the corrected reads; between stages the
+// host only sees lengths (pack widths, corrected read lengths, trim counts) and the pack consensi
+// (a few MB), from which it plans the next stage (pack order, length-sorted order for POA #2,
+// gather descriptors).
+//
+// One job over several GPUs: the pack list is the same on every rank (plan_packs); packs
+// are LPT-assigned to ranks, both POAs of a pack stay on one GPU, pack consensi are all-gathered (the
+// only data-path exchange, a few MB), POA #3 groups are LPT-assigned again.  A rank returns its own
+// packs' reads and all consensi; correction_gather reassembles the single-GPU result on the root.
+//
+// Packs that do not fit the device are skipped and reported, never fatal (rattle_skip_list).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -18,14 +26,72 @@
 
 namespace rattle {
 
+// ---- pure host planning (also behind rattle_hip_plan_packs / rattle_hip_lpt_assign) ---------------------
+void lpt_assign(const std::vector<uint64_t> &cost, int nranks, std::vector<uint32_t> &owner) {
+    const size_t n = cost.size();
+    owner.assign(n, 0);
+    if (nranks <= 1 || n == 0) return;
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    std::vector<uint64_t> load((size_t)nranks, 0);
+    for (uint32_t i : order) {
+        int best = 0;
+        for (int r = 1; r < nranks; ++r) if (load[r] < load[best]) best = r;
+        owner[i] = (uint32_t)best;
+        load[best] += std::max<uint64_t>(cost[i], 1);
+    }
+}
+
+int plan_packs(const uint64_t *off, uint32_t n_reads, uint32_t n_clusters, const uint32_t *coff, const int32_t *mid, const uint8_t *mrev,
+               const rattle_correct_params *P, int nranks, pack_plan &out) {
+    const int split = P->split > 0 ? P->split : 200;
+    out = pack_plan();
+    out.first.assign(1, 0);
+    out.cl_p0.assign(n_clusters, 0); out.cl_np.assign(n_clusters, 0);
+    for (uint32_t c = 0; c < n_clusters; ++c) {
+        const uint32_t a = coff[c], b = coff[c + 1];
+        const int n = (int)(b - a);
+        out.cl_p0[c] = (uint32_t)out.pk_cid.size();
+        if (n <= 0) continue;
+        const int n_files = (n - 1) / split + 1;                                  // correct.cpp:331
+        for (int nf = 0; nf < n_files; ++nf) {
+            const size_t start = out.members.size();
+            uint64_t sum = 0, longest = 0;
+            for (int j = nf; j < n; j += n_files) {                               // :335 strided sub-packs
+                const int32_t rid = mid[a + j];
+                if (rid < 0 || (uint32_t)rid >= n_reads) { set_error("cluster member id out of range"); return RATTLE_ERR_ARG; }
+                out.members.push_back(sref{rid, (uint8_t)(mrev[a + j] ? 1 : 0)});
+                const uint64_t L = off[rid + 1] - off[rid];
+                sum += L; longest = std::max(longest, L);
+            }
+            const bool queued = (int)(out.members.size() - start) > P->min_reads;  // :360 strict
+            const bool too_big = queued && P->max_pack_cells && (6 * longest + 64) * longest > P->max_pack_cells;
+            if (queued && !too_big) {
+                out.pk_cid.push_back((int32_t)c);
+                out.pk_local.push_back(out.cl_np[c]);
+                out.pk_cost.push_back(longest * sum);
+                out.first.push_back((uint32_t)out.members.size());
+                ++out.cl_np[c];
+            } else {
+                for (size_t t = start; t < out.members.size(); ++t) {
+                    out.small.push_back(out.members[t]); out.small_cid.push_back((int32_t)c);
+                    out.small_why.push_back(too_big ? 1 : 0); out.small_pack.push_back((uint32_t)nf);
+                }
+                out.members.resize(start);
+            }
+        }
+    }
+    lpt_assign(out.pk_cost, nranks, out.pk_owner);
+    return 0;
+}
+
 namespace {
 
 struct hread {
     std::string seq, qual;
     int32_t rid;
 };
-
-struct sref { int32_t rid; uint8_t rev; };
 
 inline char comp_base(char c) {                                                  // utils.hpp:8-14
     switch (c) {
@@ -103,6 +169,7 @@ struct stage {
     std::vector<uint64_t> off;          // [n+1] host copy of the sequence offsets
     std::vector<uint32_t> first;        // [n_packs+1]
     std::vector<uint32_t> width;        // [n_packs] MSA width (after the POA)
+    std::vector<uint8_t> skipped;       // [n_packs] the pack did not fit the device
     std::vector<uint64_t> moff, coff;   // per pack: matrix byte offset / column-array offset
     uint64_t cells = 0, cols = 0;
     dbuf<uint8_t> seq, qual, rowc, rowq, ccons, cflag, csym, cons_out;
@@ -130,6 +197,7 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     const uint32_t n = S.n(), np = S.n_packs();
     const uint64_t total = S.off[n];
     S.width.assign(np, 0);
+    S.skipped.assign(np, 0);
     if (np == 0) return 0;
     dbuf<gather_desc> d_desc;
     RT_TRY(d_desc.reserve(n + 1));
@@ -144,7 +212,7 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     unsigned long long h_cnt[16];
     {
         phase_timer T("  stage: POA");
-        RT_TRY(poa_device_run(ctx, S.seq.p, S.d_off.p, S.off.data(), n, S.first.data(), np, S.col.p, S.d_width.p, S.width.data(), h_cnt));
+        RT_TRY(poa_device_run(ctx, S.seq.p, S.d_off.p, S.off.data(), n, S.first.data(), np, S.col.p, S.d_width.p, S.width.data(), h_cnt, &S.skipped));
     }
     d_desc.release();
     counters[0] += h_cnt[0];
@@ -183,6 +251,34 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     return 0;
 }
 
+// Consensus stage (POA #2 of packs, POA #3 of clusters) whose input sequences come from the host: the pack
+// consensi are a few MB and, with several ranks, arrive through the exchange.
+struct cons_stage {
+    stage S;
+    std::vector<uint8_t> h_in;                 // concatenated input sequences (host-sourced groups)
+    std::vector<uint32_t> len;                 // [n_packs] consensus length
+    std::vector<uint8_t> cons;                 // consensi at S.coff
+};
+
+int fetch_consensi(rattle_ctx *ctx, cons_stage &C) {
+    const uint32_t np = C.S.n_packs();
+    C.len.assign(np + 1, 0);
+    C.cons.assign(C.S.cols + 1, 0);
+    if (!np) return 0;
+    RT_HIP(hipMemcpyAsync(C.len.data(), C.S.cons_len.p, (size_t)np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (C.S.cols) RT_HIP(hipMemcpyAsync(C.cons.data(), C.S.cons_out.p, C.S.cols, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// byte-string records of the exchange: [u32 id][u32 flag][u32 len][bytes]
+void put_rec(std::vector<uint8_t> &b, uint32_t id, uint32_t flag, const char *s, uint32_t len) {
+    const size_t at = b.size();
+    b.resize(at + 12 + len);
+    memcpy(b.data() + at, &id, 4); memcpy(b.data() + at + 4, &flag, 4); memcpy(b.data() + at + 8, &len, 4);
+    if (len) memcpy(b.data() + at + 12, s, len);
+}
+
 }  // namespace
 
 int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n_reads,
@@ -192,46 +288,47 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     memcpy(order, P->vote_order[0] ? P->vote_order : "U-GTCA", 6);
     for (int i = 0; i < 6; ++i)
         if (!order[i] || !strchr("ACGTU-", order[i])) { set_error("vote_order must be a permutation of ACGTU-"); return RATTLE_ERR_ARG; }
-    const int split = P->split > 0 ? P->split : 200;
     rattle_correction *R = (rattle_correction *)calloc(1, sizeof(rattle_correction));
     *out = R;
     hipStream_t st = ctx->stream;
     phase_timer T_all("correct: total");
     RT_TRY(ensure_post_constants(ctx));
+    const int rank = ctx->xchg.rank, nranks = ctx->xchg.nranks;
 
     // ---- correct.cpp:328-370 pack building: ids and strands only, the bases stay where they are
-    std::vector<int32_t> pk_cid;
-    std::vector<sref> S1r, small;
-    std::vector<int32_t> small_cid;
-    std::vector<uint32_t> cl_p0(n_clusters, 0), cl_np(n_clusters, 0);
-    stage S1;
-    S1.first.assign(1, 0);
-    for (uint32_t c = 0; c < n_clusters; ++c) {
-        const uint32_t a = coff[c], b = coff[c + 1];
-        const int n = (int)(b - a);
-        cl_p0[c] = (uint32_t)pk_cid.size();
-        if (n <= 0) continue;
-        const int n_files = (n - 1) / split + 1;
-        for (int nf = 0; nf < n_files; ++nf) {
-            const size_t start = S1r.size();
-            for (int j = nf; j < n; j += n_files) {
-                const int32_t rid = mid[a + j];
-                if (rid < 0 || (uint32_t)rid >= n_reads) { set_error("cluster member id out of range"); return RATTLE_ERR_ARG; }
-                S1r.push_back(sref{rid, (uint8_t)(mrev[a + j] ? 1 : 0)});
-            }
-            if ((int)(S1r.size() - start) > P->min_reads) {                      // :360 strict
-                pk_cid.push_back((int32_t)c);
-                S1.first.push_back((uint32_t)S1r.size());
-                ++cl_np[c];
-            } else {
-                for (size_t t = start; t < S1r.size(); ++t) { small.push_back(S1r[t]); small_cid.push_back((int32_t)c); }
-                S1r.resize(start);
-            }
-        }
-    }
-    const uint32_t n_packs = (uint32_t)pk_cid.size(), n1 = (uint32_t)S1r.size();
+    pack_plan PL;
+    RT_TRY(plan_packs(off, n_reads, n_clusters, coff, mid, mrev, P, nranks, PL));
+    const uint32_t n_packs = (uint32_t)PL.pk_cid.size();
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     counters[2] = n_packs;
+
+    // the order a cluster's pack consensi enter POA #3 in (default: pack order)
+    std::vector<std::vector<uint32_t>> cl_perm(P->n_pack_orders ? n_clusters : 0);
+    for (uint32_t i = 0; i < P->n_pack_orders; ++i) {
+        if (!P->pack_order_cluster || !P->pack_order_offsets || !P->pack_order_perm) { set_error("pack order arrays missing"); return RATTLE_ERR_ARG; }
+        const uint32_t c = P->pack_order_cluster[i];
+        if (c >= n_clusters) { set_error("pack order: cluster out of range"); return RATTLE_ERR_ARG; }
+        const uint32_t a = P->pack_order_offsets[i], b = P->pack_order_offsets[i + 1];
+        std::vector<uint32_t> perm(P->pack_order_perm + a, P->pack_order_perm + b), chk(perm);
+        std::sort(chk.begin(), chk.end());
+        bool ok = b - a == PL.cl_np[c];
+        for (uint32_t t = 0; ok && t < chk.size(); ++t) ok = chk[t] == t;
+        if (!ok) { set_error("pack order of cluster " + std::to_string(c) + " is not a permutation of its " + std::to_string(PL.cl_np[c]) + " packs"); return RATTLE_ERR_ARG; }
+        cl_perm[c] = perm;
+    }
+
+    // my packs, in pack order (all of them on one rank)
+    std::vector<uint32_t> mine;
+    for (uint32_t p = 0; p < n_packs; ++p) if ((int)PL.pk_owner[p] == rank) mine.push_back(p);
+    const uint32_t nm = (uint32_t)mine.size();
+    stage S1;
+    S1.first.assign(1, 0);
+    std::vector<sref> S1r;
+    for (uint32_t p : mine) {
+        for (uint32_t q = PL.first[p]; q < PL.first[p + 1]; ++q) S1r.push_back(PL.members[q]);
+        S1.first.push_back((uint32_t)S1r.size());
+    }
+    const uint32_t n1 = (uint32_t)S1r.size();
 
     // only A, C, G, T, U are defined for the vote (an unordered_map key set in the reference)
     {
@@ -247,20 +344,38 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         if (bad) { set_error("correct: read contains a base other than A, C, G, T, U"); return RATTLE_ERR_ARG; }
     }
 
+    // skip list (this rank's share; unqueued entries on rank 0)
+    struct skip_t { int32_t cid; uint32_t pack, stage; std::vector<int32_t> rids; };
+    std::vector<skip_t> skips;
+
     std::vector<hread> uncorrected;
     std::vector<int32_t> unc_cid;
-    for (size_t i = 0; i < small.size(); ++i) { uncorrected.push_back(oriented_read(seq, qual, off, small[i], 0, 0)); unc_cid.push_back(small_cid[i]); }
+    std::vector<uint32_t> unc_pack;
+    if (rank == 0) {
+        for (size_t i = 0; i < PL.small.size(); ++i) {
+            uncorrected.push_back(oriented_read(seq, qual, off, PL.small[i], 0, 0));
+            unc_cid.push_back(PL.small_cid[i]); unc_pack.push_back(0xFFFFFFFFu);
+            if (PL.small_why[i]) {
+                if (skips.empty() || skips.back().stage != 0 || skips.back().cid != PL.small_cid[i] || skips.back().pack != PL.small_pack[i])
+                    skips.push_back(skip_t{PL.small_cid[i], PL.small_pack[i], 0u, {}});
+                skips.back().rids.push_back(PL.small[i].rid);
+            }
+        }
+    }
 
     std::vector<uint32_t> olen(n1 + 1, 0), tfront(n1 + 1, 0), tback(n1 + 1, 0);
-    std::vector<uint32_t> cons_len2, cons_len3, pk_slot, cl_slot(n_clusters, 0);
-    std::vector<uint8_t> cons2, cons3;               // consensi of stage 2b+3a / 3b, concatenated at the stage's coff
+    std::vector<uint8_t> pk_dead(n_packs, 0);       // stage at which a pack was given up (this rank's packs: exact; others: from the exchange)
+    std::vector<std::string> pk_cons(n_packs);       // pack consensus (POA #2), filled for every pack by the exchanges
+    std::vector<uint8_t> pk_has(n_packs, 0);
     std::vector<std::string> cl_cons(n_clusters);
-    stage S2a, S2, S3;
+    std::vector<uint8_t> cl_has(n_clusters, 0);
     dbuf<uint8_t> d_os, d_oq;                        // corrected reads, compacted on the device
     std::thread d2h;
     hipError_t d2h_err = hipSuccess;
     struct joiner { std::thread &t; ~joiner() { if (t.joinable()) t.join(); } } d2h_join{d2h};      // also on error returns
-    if (n_packs) {
+    std::vector<uint32_t> cor_pack;
+
+    if (nm) {
         // ---- reads -> HBM, oriented pack members gathered into stage 1 (:343-346)
         const uint64_t total_in = off[n_reads];
         dbuf<uint8_t> d_rseq, d_rqual;
@@ -292,6 +407,12 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
         d_rseq.release(); d_rqual.release();
         S1.seq.release(); S1.qual.release(); S1.col.release();
+        for (uint32_t k = 0; k < nm; ++k)
+            if (S1.skipped[k]) {                      // POA #1 did not fit: the pack's reads stay as they are
+                pk_dead[mine[k]] = 1;
+                skips.push_back(skip_t{PL.pk_cid[mine[k]], PL.pk_local[mine[k]], 1u, {}});
+                for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) { skips.back().rids.push_back(S1r[q].rid); olen[q] = 0; tfront[q] = 0; tback[q] = 0; }
+            }
 
         // ---- corrected reads in pack order (:413-425): compacted on the device, one download
         {
@@ -299,10 +420,10 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             std::vector<gather_desc> od;
             std::vector<uint32_t> oq;
             uint64_t tot = 0;
-            for (uint32_t p = 0; p < n_packs; ++p)
-                for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q) {
+            for (uint32_t k = 0; k < nm; ++k)
+                for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) {
                     if (olen[q] == 0) continue;
-                    od.push_back(gather_desc{S1.moff[p] + (uint64_t)(q - S1.first[p]) * S1.width[p], tot, olen[q], 0u});
+                    od.push_back(gather_desc{S1.moff[k] + (uint64_t)(q - S1.first[k]) * S1.width[k], tot, olen[q], 0u});
                     oq.push_back(q);
                     tot += olen[q];
                 }
@@ -313,10 +434,12 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             C.n_reads = (int32_t *)malloc(std::max<size_t>(1, nc) * 4); C.off = (uint64_t *)malloc((nc + 1) * 8);
             C.seq = (char *)malloc(tot + 1); C.qual = (char *)malloc(tot + 1);
             C.seq[tot] = 0; C.qual[tot] = 0;
-            uint32_t p = 0;
+            cor_pack.resize(nc);
+            uint32_t k = 0;
             for (size_t i = 0; i < nc; ++i) {
-                while (oq[i] >= S1.first[p + 1]) ++p;
-                C.read_id[i] = S1r[oq[i]].rid; C.cluster_id[i] = pk_cid[p]; C.n_reads[i] = 0; C.off[i] = od[i].dst;
+                while (oq[i] >= S1.first[k + 1]) ++k;
+                C.read_id[i] = S1r[oq[i]].rid; C.cluster_id[i] = PL.pk_cid[mine[k]]; C.n_reads[i] = 0; C.off[i] = od[i].dst;
+                cor_pack[i] = mine[k];
             }
             C.off[nc] = tot;
             if (nc) {
@@ -340,118 +463,170 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             }
         }
         // reads whose corrected sequence came out empty: uncorrected, as fix_msa_ends left them (:289-293)
-        for (uint32_t p = 0; p < n_packs; ++p)
-            for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q)
-                if (olen[q] == 0) { uncorrected.push_back(oriented_read(seq, qual, off, S1r[q], tfront[q], tback[q])); unc_cid.push_back(pk_cid[p]); }
-
-        // ---- POA #2 over the corrected reads, stably sorted by length desc (:427-445), + consensus vote;
-        // per-cluster consensus (:489-556) with POA #3 for clusters of more than one pack.
-        // A POA #3 pack is sequential in its number of packs, so the clusters with many packs would
-        // leave the device to one workgroup each at the end.  When there are enough of them, their
-        // packs go through POA #2 first (stage 2a) and their POA #3 shares a pass with the POA #2 of
-        // everything else (stage 2b+3a); the remaining small POA #3 groups follow (stage 3b).
-        // (RATTLE_BIG_CLUSTER_PACKS / RATTLE_BIG_MIN_PACKS override the two thresholds: tests force the split on small inputs)
-        const uint32_t BIG = std::max(2, getenv("RATTLE_BIG_CLUSTER_PACKS") ? atoi(getenv("RATTLE_BIG_CLUSTER_PACKS")) : 48);
-        const uint64_t big_min = getenv("RATTLE_BIG_MIN_PACKS") ? (uint64_t)atoll(getenv("RATTLE_BIG_MIN_PACKS")) : 1024;
-        std::vector<uint8_t> big(n_clusters, 0);
-        {
-            uint64_t big_packs = 0;
-            for (uint32_t c = 0; c < n_clusters; ++c) if (cl_np[c] >= BIG) big_packs += cl_np[c];
-            if (big_packs >= big_min) for (uint32_t c = 0; c < n_clusters; ++c) big[c] = cl_np[c] >= BIG;
-        }
-        std::vector<uint32_t> rows;
-        auto add_pack2 = [&](stage &S, std::vector<gather_desc> &d, uint32_t p) {       // pack p's corrected reads, length-sorted
-            rows.clear();
-            for (uint32_t q = S1.first[p]; q < S1.first[p + 1]; ++q) if (olen[q]) rows.push_back(q);
-            std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return olen[a] > olen[b]; });
-            for (uint32_t q : rows) {
-                d.push_back(gather_desc{S1.moff[p] + (uint64_t)(q - S1.first[p]) * S1.width[p], S.off.back(), olen[q], 0u});
-                S.off.push_back(S.off.back() + olen[q]);
-            }
-            S.first.push_back((uint32_t)S.off.size() - 1);
-        };
-        pk_slot.assign(n_packs, 0);
-        // stage 2a: packs of the big clusters
-        std::vector<uint32_t> len2a;
-        {
-            std::vector<gather_desc> d;
-            S2a.first.assign(1, 0); S2a.off.assign(1, 0);
-            for (uint32_t p = 0; p < n_packs; ++p) if (big[pk_cid[p]]) { pk_slot[p] = S2a.n_packs(); add_pack2(S2a, d, p); }
-            if (S2a.n_packs()) {
-                phase_timer T("correct: stage 2a");
-                RT_TRY(run_stage(ctx, S2a, d, {gather_part{0, (uint32_t)d.size(), S1.rowc.p, nullptr}}, 2, P, order, counters));
-                len2a.assign(S2a.n_packs(), 0);
-                RT_HIP(hipMemcpyAsync(len2a.data(), S2a.cons_len.p, (size_t)S2a.n_packs() * 4, hipMemcpyDeviceToHost, st));
-                RT_HIP(hipStreamSynchronize(st));
-            }
-        }
-        // stage 2b+3a: POA #3 groups of the big clusters first, then the packs of all other clusters
-        {
-            phase_timer T("correct: stage 2b+3a");
-            std::vector<gather_desc> d;
-            S2.first.assign(1, 0); S2.off.assign(1, 0);
-            for (uint32_t c = 0; c < n_clusters; ++c) {
-                if (!big[c]) continue;
-                cl_slot[c] = S2.n_packs();
-                for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) {
-                    d.push_back(gather_desc{S2a.coff[pk_slot[p]], S2.off.back(), len2a[pk_slot[p]], 0u});
-                    S2.off.push_back(S2.off.back() + len2a[pk_slot[p]]);
+        for (uint32_t k = 0; k < nm; ++k)
+            for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q)
+                if (olen[q] == 0) {
+                    uncorrected.push_back(oriented_read(seq, qual, off, S1r[q], tfront[q], tback[q]));
+                    unc_cid.push_back(PL.pk_cid[mine[k]]); unc_pack.push_back(mine[k]);
                 }
-                S2.first.push_back((uint32_t)S2.off.size() - 1);
-            }
-            const uint32_t n3a = (uint32_t)d.size();
-            for (uint32_t p = 0; p < n_packs; ++p) if (!big[pk_cid[p]]) { pk_slot[p] = S2.n_packs(); add_pack2(S2, d, p); }
-            RT_TRY(run_stage(ctx, S2, d, {gather_part{0, n3a, S2a.cons_out.p, nullptr}, gather_part{n3a, (uint32_t)d.size() - n3a, S1.rowc.p, nullptr}},
-                             2, P, order, counters));
-            cons_len2.assign(S2.n_packs() + 1, 0);
-            cons2.resize(S2.cols + 1);
-            RT_HIP(hipMemcpyAsync(cons_len2.data(), S2.cons_len.p, (size_t)S2.n_packs() * 4, hipMemcpyDeviceToHost, st));
-            if (S2.cols) RT_HIP(hipMemcpyAsync(cons2.data(), S2.cons_out.p, S2.cols, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipStreamSynchronize(st));
-        }
-        S1.release(); S2a.release();
-        // stage 3b: POA #3 of the other clusters with more than one pack
-        {
-            std::vector<gather_desc> d;
-            S3.first.assign(1, 0); S3.off.assign(1, 0);
-            for (uint32_t c = 0; c < n_clusters; ++c) {
-                if (cl_np[c] <= 1 || big[c]) continue;
-                cl_slot[c] = S3.n_packs();
-                for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) {
-                    d.push_back(gather_desc{S2.coff[pk_slot[p]], S3.off.back(), cons_len2[pk_slot[p]], 0u});
-                    S3.off.push_back(S3.off.back() + cons_len2[pk_slot[p]]);
-                }
-                S3.first.push_back((uint32_t)S3.off.size() - 1);
-            }
-            if (S3.n_packs()) {
-                phase_timer T("correct: stage 3b");
-                RT_TRY(run_stage(ctx, S3, d, {gather_part{0, (uint32_t)d.size(), S2.cons_out.p, nullptr}}, 2, P, order, counters));
-                cons_len3.assign(S3.n_packs(), 0);
-                cons3.resize(S3.cols + 1);
-                RT_HIP(hipMemcpyAsync(cons_len3.data(), S3.cons_len.p, (size_t)S3.n_packs() * 4, hipMemcpyDeviceToHost, st));
-                if (S3.cols) RT_HIP(hipMemcpyAsync(cons3.data(), S3.cons_out.p, S3.cols, hipMemcpyDeviceToHost, st));
-                RT_HIP(hipStreamSynchronize(st));
-            }
-        }
-        S2.release(); S3.release();
-        for (uint32_t c = 0; c < n_clusters; ++c) {          // where each cluster's consensus ended up
-            if (cl_np[c] == 0) continue;
-            if (big[c]) cl_cons[c] = std::string((const char *)cons2.data() + S2.coff[cl_slot[c]], cons_len2[cl_slot[c]]);
-            else if (cl_np[c] > 1) cl_cons[c] = std::string((const char *)cons3.data() + S3.coff[cl_slot[c]], cons_len3[cl_slot[c]]);
-            else cl_cons[c] = std::string((const char *)cons2.data() + S2.coff[pk_slot[cl_p0[c]]], cons_len2[pk_slot[cl_p0[c]]]);
-        }
     } else {
         fill_set(R->corrected, {}, {}, {});
+    }
+
+    // ---- POA #2 over the corrected reads of a pack, stably sorted by length desc (:427-445), + consensus vote;
+    // per-cluster consensus (:489-556) with POA #3 for clusters of more than one pack.
+    // A POA #3 group is sequential in its number of packs, so the clusters with many packs would leave the
+    // device to one workgroup each at the end.  When there are enough of them, their packs go through
+    // POA #2 first (stage 2a) and their POA #3 shares a pass with the POA #2 of everything else
+    // (stage 2b+3a); the remaining small POA #3 groups follow (stage 3b).  With several ranks each stage
+    // covers this rank's packs / groups and ends with an all-gather of its consensi.
+    // (RATTLE_BIG_CLUSTER_PACKS / RATTLE_BIG_MIN_PACKS override the two thresholds: tests force the split on small inputs)
+    const uint32_t BIG = std::max(2, getenv("RATTLE_BIG_CLUSTER_PACKS") ? atoi(getenv("RATTLE_BIG_CLUSTER_PACKS")) : 48);
+    const uint64_t big_min = getenv("RATTLE_BIG_MIN_PACKS") ? (uint64_t)atoll(getenv("RATTLE_BIG_MIN_PACKS")) : 1024;
+    std::vector<uint8_t> big(n_clusters, 0);
+    {
+        uint64_t big_packs = 0;
+        for (uint32_t c = 0; c < n_clusters; ++c) if (PL.cl_np[c] >= BIG) big_packs += PL.cl_np[c];
+        if (big_packs >= big_min) for (uint32_t c = 0; c < n_clusters; ++c) big[c] = PL.cl_np[c] >= BIG;
+    }
+    std::vector<uint32_t> slot_of(n_packs, 0xFFFFFFFFu);   // my pack -> index in `mine`
+    for (uint32_t k = 0; k < nm; ++k) slot_of[mine[k]] = k;
+
+    std::vector<uint32_t> rows;
+    auto add_pack2 = [&](stage &S, std::vector<gather_desc> &d, uint32_t k) {       // my pack k's corrected reads, length-sorted
+        rows.clear();
+        for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) if (olen[q]) rows.push_back(q);
+        std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return olen[a] > olen[b]; });
+        for (uint32_t q : rows) {
+            d.push_back(gather_desc{S1.moff[k] + (uint64_t)(q - S1.first[k]) * S1.width[k], S.off.back(), olen[q], 0u});
+            S.off.push_back(S.off.back() + olen[q]);
+        }
+        S.first.push_back((uint32_t)S.off.size() - 1);
+    };
+    // the live packs of a cluster in the order their consensi enter POA #3
+    auto group_of = [&](uint32_t c, std::vector<uint32_t> &g) {
+        g.clear();
+        for (uint32_t t = 0; t < PL.cl_np[c]; ++t) {
+            const uint32_t p = PL.cl_p0[c] + (cl_perm.empty() || cl_perm[c].empty() ? t : cl_perm[c][t]);
+            if (pk_has[p]) g.push_back(p);
+        }
+    };
+    // exchange the results of one stage: pack consensi (kind 0) and cluster consensi (kind 1), dead flags included
+    auto exchange_stage = [&](std::vector<uint8_t> &mine_bytes) -> int {
+        std::vector<std::vector<uint8_t>> all;
+        if (nranks > 1) RT_TRY(xchg_allgatherv(ctx, mine_bytes, all));
+        else { all.resize(1); all[0].swap(mine_bytes); }
+        for (const std::vector<uint8_t> &b : all) {
+            size_t at = 0;
+            while (at + 12 <= b.size()) {
+                uint32_t id, flag, len;
+                memcpy(&id, b.data() + at, 4); memcpy(&flag, b.data() + at + 4, 4); memcpy(&len, b.data() + at + 8, 4);
+                const char *s = (const char *)b.data() + at + 12;
+                at += 12 + len;
+                const uint32_t kind = flag & 1u, dead = flag >> 1;
+                if (kind == 0) { if (dead) pk_dead[id] = (uint8_t)dead; else { pk_cons[id].assign(s, len); pk_has[id] = 1; } }
+                else if (!dead) { cl_cons[id].assign(s, len); cl_has[id] = 1; }
+            }
+        }
+        return 0;
+    };
+    // POA #2 over a list of my packs (slots in `mine`) + POA #3 over a list of clusters (groups of pack consensi
+    // from the host) in one device pass; results into `bytes`
+    auto cons_pass = [&](const char *name, const std::vector<uint32_t> &slots2, const std::vector<uint32_t> &clusters3, std::vector<uint8_t> &bytes) -> int {
+        if (slots2.empty() && clusters3.empty()) return 0;
+        phase_timer T(name);
+        cons_stage C;
+        stage &S = C.S;
+        std::vector<gather_desc> d;
+        S.first.assign(1, 0); S.off.assign(1, 0);
+        std::vector<uint32_t> g;
+        for (uint32_t c : clusters3) {
+            group_of(c, g);
+            for (uint32_t p : g) {
+                d.push_back(gather_desc{(uint64_t)C.h_in.size(), S.off.back(), (uint32_t)pk_cons[p].size(), 0u});
+                C.h_in.insert(C.h_in.end(), pk_cons[p].begin(), pk_cons[p].end());
+                S.off.push_back(S.off.back() + pk_cons[p].size());
+            }
+            S.first.push_back((uint32_t)S.off.size() - 1);
+        }
+        const uint32_t n3 = (uint32_t)d.size();
+        for (uint32_t k : slots2) add_pack2(S, d, k);
+        dbuf<uint8_t> d_in;
+        RT_TRY(d_in.reserve(C.h_in.size() + 64));
+        if (!C.h_in.empty()) RT_HIP(hipMemcpyAsync(d_in.p, C.h_in.data(), C.h_in.size(), hipMemcpyHostToDevice, st));
+        RT_TRY(run_stage(ctx, S, d, {gather_part{0, n3, d_in.p, nullptr}, gather_part{n3, (uint32_t)d.size() - n3, S1.rowc.p, nullptr}}, 2, P, order, counters));
+        RT_TRY(fetch_consensi(ctx, C));
+        uint32_t slot = 0;
+        for (uint32_t c : clusters3) {
+            if (S.skipped[slot]) {
+                skips.push_back(skip_t{(int32_t)c, 0u, 3u, {}});
+                put_rec(bytes, c, 1u | (3u << 1), nullptr, 0);
+            } else put_rec(bytes, c, 1u, (const char *)C.cons.data() + S.coff[slot], C.len[slot]);
+            ++slot;
+        }
+        for (uint32_t k : slots2) {
+            const uint32_t p = mine[k];
+            if (S.skipped[slot]) {
+                skips.push_back(skip_t{PL.pk_cid[p], PL.pk_local[p], 2u, {}});
+                for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) skips.back().rids.push_back(S1r[q].rid);
+                put_rec(bytes, p, 2u << 1, nullptr, 0);
+            } else put_rec(bytes, p, 0u, (const char *)C.cons.data() + S.coff[slot], C.len[slot]);
+            ++slot;
+        }
+        return 0;
+    };
+
+    {
+        std::vector<uint8_t> bytes;
+        // packs given up in stage 1 are announced with the first exchange
+        for (uint32_t k = 0; k < nm; ++k) if (pk_dead[mine[k]] == 1) put_rec(bytes, mine[k], 1u << 1, nullptr, 0);
+        // stage 2a: my packs of the big clusters
+        std::vector<uint32_t> s2a, s2b;
+        for (uint32_t k = 0; k < nm; ++k) if (!pk_dead[mine[k]]) (big[PL.pk_cid[mine[k]]] ? s2a : s2b).push_back(k);
+        RT_TRY(cons_pass("correct: stage 2a", s2a, {}, bytes));
+        bool any_big = false;
+        for (uint32_t c = 0; c < n_clusters; ++c) any_big |= big[c] != 0;
+        if (any_big) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
+        // stage 2b+3a: POA #3 groups of the big clusters (LPT over ranks), then my packs of all other clusters
+        std::vector<uint32_t> g3a_all, g3a;
+        std::vector<uint64_t> cost;
+        std::vector<uint32_t> own, g;
+        for (uint32_t c = 0; c < n_clusters; ++c) {
+            if (!big[c]) continue;
+            group_of(c, g);
+            if (g.size() > 1) { g3a_all.push_back(c); cost.push_back((uint64_t)g.size() * g.size() * pk_cons[g[0]].size()); }
+            else if (g.size() == 1) { cl_cons[c] = pk_cons[g[0]]; cl_has[c] = 1; }
+        }
+        lpt_assign(cost, nranks, own);
+        for (size_t i = 0; i < g3a_all.size(); ++i) if ((int)own[i] == rank) g3a.push_back(g3a_all[i]);
+        RT_TRY(cons_pass("correct: stage 2b+3a", s2b, g3a, bytes));
+        RT_TRY(exchange_stage(bytes)); bytes.clear();
+        if (d2h.joinable()) d2h.join();                  // S1.rowc is no longer needed once the download is done
+        S1.release();
+        // stage 3b: POA #3 of the other clusters with more than one live pack
+        std::vector<uint32_t> g3b_all, g3b;
+        cost.clear();
+        for (uint32_t c = 0; c < n_clusters; ++c) {
+            if (big[c] || PL.cl_np[c] == 0) continue;
+            group_of(c, g);
+            if (g.size() > 1) { g3b_all.push_back(c); cost.push_back((uint64_t)g.size() * g.size() * pk_cons[g[0]].size()); }
+            else if (g.size() == 1) { cl_cons[c] = pk_cons[g[0]]; cl_has[c] = 1; }
+        }
+        lpt_assign(cost, nranks, own);
+        for (size_t i = 0; i < g3b_all.size(); ++i) if ((int)own[i] == rank) g3b.push_back(g3b_all[i]);
+        RT_TRY(cons_pass("correct: stage 3b", {}, g3b, bytes));
+        if (!g3b_all.empty()) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
     }
     if (d2h.joinable()) d2h.join();
     d_os.release(); d_oq.release();
     if (d2h_err != hipSuccess) { set_error(std::string("corrected reads download: ") + hipGetErrorString(d2h_err)); return RATTLE_ERR_HIP; }
+
     std::vector<hread> consensi;
     std::vector<int32_t> con_cid, con_n;
     for (uint32_t c = 0; c < n_clusters; ++c) {
-        if (cl_np[c] == 0) continue;
+        if (!cl_has[c]) continue;
         int total = 0;
-        for (uint32_t p = cl_p0[c]; p < cl_p0[c] + cl_np[c]; ++p) total += (int)(S1.first[p + 1] - S1.first[p]);
+        for (uint32_t p = PL.cl_p0[c]; p < PL.cl_p0[c] + PL.cl_np[c]; ++p) if (pk_has[p]) total += (int)(PL.first[p + 1] - PL.first[p]);
         const std::string &s = cl_cons[c];
         consensi.push_back(hread{s, std::string(s.size(), 'K'), -1});
         con_cid.push_back((int32_t)c);
@@ -459,6 +634,24 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     }
     fill_set(R->uncorrected, uncorrected, unc_cid, {});
     fill_set(R->consensi, consensi, con_cid, con_n);
+    R->corrected_pack = (uint32_t *)malloc(std::max<size_t>(1, cor_pack.size()) * 4);
+    if (!cor_pack.empty()) memcpy(R->corrected_pack, cor_pack.data(), cor_pack.size() * 4);
+    R->uncorrected_pack = (uint32_t *)malloc(std::max<size_t>(1, unc_pack.size()) * 4);
+    if (!unc_pack.empty()) memcpy(R->uncorrected_pack, unc_pack.data(), unc_pack.size() * 4);
+    {
+        rattle_skip_list &K = R->skipped;
+        const size_t n = skips.size();
+        K.n = (uint32_t)n;
+        K.cluster_id = (int32_t *)malloc(std::max<size_t>(1, n) * 4); K.pack = (uint32_t *)malloc(std::max<size_t>(1, n) * 4);
+        K.stage = (uint32_t *)malloc(std::max<size_t>(1, n) * 4); K.read_off = (uint64_t *)malloc((n + 1) * 8);
+        uint64_t tot = 0;
+        for (size_t i = 0; i < n; ++i) { K.cluster_id[i] = skips[i].cid; K.pack[i] = skips[i].pack; K.stage[i] = skips[i].stage; K.read_off[i] = tot; tot += skips[i].rids.size(); }
+        K.read_off[n] = tot;
+        K.read_id = (int32_t *)malloc(std::max<uint64_t>(1, tot) * 4);
+        for (size_t i = 0; i < n; ++i) if (!skips[i].rids.empty()) memcpy(K.read_id + K.read_off[i], skips[i].rids.data(), skips[i].rids.size() * 4);
+        counters[3] = n;
+        counters[4] = tot;
+    }
     memcpy(R->counters, counters, sizeof(counters));
     return 0;
 }

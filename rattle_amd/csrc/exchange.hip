@@ -1,0 +1,450 @@
+// One job over the GPUs of a node: the all-gather(v) behind the sharded `cluster` / `correct` paths
+//  and the reassembly of a sharded correction.
+//
+// The reference parallelises the candidate loop of a seed (cluster.cpp:138-158,189-209), the --iso gene
+// clusters (main.cpp:281-318) and the pack queue (correct.cpp:377-392) with host threads in one address
+// space.  Here each of those axes is cut over ranks (one per GPU); what the ranks must tell each other
+// is small (hit lists, cluster sets, pack consensi), so the exchange is an all-gather of one byte
+// string per rank, and once per `correct` a gather of the corrected reads to the root.
+//   * RCCL transport: device staging buffers, ncclAllGather of the sizes, then one ncclBroadcast per
+//     rank inside a group (= all-gather-v) on the context's stream; xGMI is point-to-point, so the
+//     broadcasts of different roots use different links.  librccl.so is dlopen'ed on first use: a
+//     single-GPU process never loads it.
+//   * host transport: a caller-supplied all-gather-v on host buffers (MPI, gloo, tests).
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "common.h"
+
+namespace rattle {
+
+namespace {
+
+// the part of the RCCL API used here (rccl.h; types restated so the header is not needed at build time)
+struct nccl_uid { char internal[128]; };
+typedef void *nccl_comm;
+enum { NCCL_UINT8 = 1, NCCL_UINT64 = 5 };
+struct rccl_api {
+    void *h = nullptr;
+    int (*GetUniqueId)(nccl_uid *) = nullptr;
+    int (*CommInitRank)(nccl_comm *, int, nccl_uid, int) = nullptr;
+    int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+rccl_api &rccl() { static rccl_api A; return A; }
+
+int load_rccl() {
+    rccl_api &A = rccl();
+    if (A.h) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) { A.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (A.h) break; }
+    if (!A.h) { set_error(std::string("librccl.so not found: ") + dlerror()); return RATTLE_ERR_HIP; }
+#define SYM(field, name) *(void **)(&A.field) = dlsym(A.h, name); if (!A.field) { set_error("librccl.so lacks " name); A.h = nullptr; return RATTLE_ERR_HIP; }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return 0;
+}
+
+#define RT_NCCL(call)                                                                                    \
+    do {                                                                                                 \
+        int r__ = (call);                                                                                \
+        if (r__ != 0) {                                                                                  \
+            set_error(std::string(#call) + ": " + rccl().GetErrorString(r__) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+            return RATTLE_ERR_HIP;                                                                       \
+        }                                                                                                \
+    } while (0)
+
+// all-gather-v of device buffers through RCCL: piece r (bytes[r] long) lands at recv + displ[r]
+int rccl_allgatherv(rattle_ctx *ctx, const uint8_t *d_send, uint8_t *d_recv, const std::vector<uint64_t> &bytes) {
+    exchange &X = ctx->xchg;
+    rccl_api &A = rccl();
+    RT_NCCL(A.GroupStart());
+    uint64_t at = 0;
+    for (int r = 0; r < X.nranks; ++r) {
+        if (bytes[r]) RT_NCCL(A.Broadcast(r == X.rank ? d_send : d_recv + at, d_recv + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, ctx->stream));
+        at += bytes[r];
+    }
+    RT_NCCL(A.GroupEnd());
+    return 0;
+}
+
+}  // namespace
+
+int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all) {
+    exchange &X = ctx->xchg;
+    all.assign((size_t)X.nranks, {});
+    if (X.nranks == 1) { all[0] = mine; return 0; }
+    ++X.calls;
+    std::vector<uint64_t> bytes((size_t)X.nranks, 0);
+    const uint64_t my_bytes = mine.size();
+    if (X.comm) {
+        hipStream_t st = ctx->stream;
+        dbuf<uint64_t> d_sz;
+        RT_TRY(d_sz.reserve((size_t)X.nranks + 1));
+        RT_HIP(hipMemcpyAsync(d_sz.p + X.nranks, &my_bytes, 8, hipMemcpyHostToDevice, st));
+        RT_NCCL(rccl().AllGather(d_sz.p + X.nranks, d_sz.p, 1, NCCL_UINT64, (nccl_comm)X.comm, st));
+        RT_HIP(hipMemcpyAsync(bytes.data(), d_sz.p, (size_t)X.nranks * 8, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        uint64_t total = 0;
+        for (uint64_t b : bytes) total += b;
+        dbuf<uint8_t> d_send, d_recv;
+        RT_TRY(d_send.reserve(my_bytes + 16)); RT_TRY(d_recv.reserve(total + 16));
+        if (my_bytes) RT_HIP(hipMemcpyAsync(d_send.p, mine.data(), my_bytes, hipMemcpyHostToDevice, st));
+        RT_TRY(rccl_allgatherv(ctx, d_send.p, d_recv.p, bytes));
+        std::vector<uint8_t> flat(total);
+        if (total) RT_HIP(hipMemcpyAsync(flat.data(), d_recv.p, total, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        uint64_t at = 0;
+        for (int r = 0; r < X.nranks; ++r) { all[r].assign(flat.begin() + at, flat.begin() + at + bytes[r]); at += bytes[r]; }
+        X.bytes += total;
+        return 0;
+    }
+    if (!X.fn) { set_error("several ranks but no exchange transport (rattle_hip_comm_init / rattle_hip_set_exchange)"); return RATTLE_ERR_STATE; }
+    std::vector<uint64_t> eight((size_t)X.nranks, 8);
+    if (X.fn(X.user, &my_bytes, 8, bytes.data(), eight.data()) != 0) { set_error("exchange callback failed (sizes)"); return RATTLE_ERR_HIP; }
+    uint64_t total = 0;
+    for (uint64_t b : bytes) total += b;
+    std::vector<uint8_t> flat(total + 1);
+    static const uint8_t none = 0;
+    if (X.fn(X.user, my_bytes ? mine.data() : &none, my_bytes, flat.data(), bytes.data()) != 0) { set_error("exchange callback failed (payload)"); return RATTLE_ERR_HIP; }
+    uint64_t at = 0;
+    for (int r = 0; r < X.nranks; ++r) { all[r].assign(flat.begin() + at, flat.begin() + at + bytes[r]); at += bytes[r]; }
+    X.bytes += total;
+    return 0;
+}
+
+// gather of one byte string per rank on `root` (all[] stays empty elsewhere).  RCCL: send / recv pairs in a
+// group; host transport: the caller's all-gather-v.
+static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int root, std::vector<std::vector<uint8_t>> &all) {
+    exchange &X = ctx->xchg;
+    if (X.nranks == 1 || !X.comm) {
+        RT_TRY(xchg_allgatherv(ctx, mine, all));
+        if (X.rank != root) all.assign((size_t)X.nranks, {});
+        return 0;
+    }
+    ++X.calls;
+    all.assign((size_t)X.nranks, {});
+    hipStream_t st = ctx->stream;
+    std::vector<uint64_t> bytes((size_t)X.nranks, 0);
+    const uint64_t my_bytes = mine.size();
+    dbuf<uint64_t> d_sz;
+    RT_TRY(d_sz.reserve((size_t)X.nranks + 1));
+    RT_HIP(hipMemcpyAsync(d_sz.p + X.nranks, &my_bytes, 8, hipMemcpyHostToDevice, st));
+    RT_NCCL(rccl().AllGather(d_sz.p + X.nranks, d_sz.p, 1, NCCL_UINT64, (nccl_comm)X.comm, st));
+    RT_HIP(hipMemcpyAsync(bytes.data(), d_sz.p, (size_t)X.nranks * 8, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
+    rccl_api &A = rccl();
+    if (X.rank != root) {
+        dbuf<uint8_t> d_send;
+        RT_TRY(d_send.reserve(my_bytes + 16));
+        if (my_bytes) {
+            RT_HIP(hipMemcpyAsync(d_send.p, mine.data(), my_bytes, hipMemcpyHostToDevice, st));
+            RT_NCCL(A.Send(d_send.p, my_bytes, NCCL_UINT8, root, (nccl_comm)X.comm, st));
+        }
+        RT_HIP(hipStreamSynchronize(st));
+        return 0;
+    }
+    uint64_t total = 0;
+    for (int r = 0; r < X.nranks; ++r) if (r != root) total += bytes[r];
+    dbuf<uint8_t> d_recv;
+    RT_TRY(d_recv.reserve(total + 16));
+    RT_NCCL(A.GroupStart());
+    uint64_t at = 0;
+    for (int r = 0; r < X.nranks; ++r) {
+        if (r == root || !bytes[r]) continue;
+        RT_NCCL(A.Recv(d_recv.p + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, st));
+        at += bytes[r];
+    }
+    RT_NCCL(A.GroupEnd());
+    at = 0;
+    for (int r = 0; r < X.nranks; ++r) {
+        if (r == root) { all[r] = mine; continue; }
+        all[r].resize(bytes[r]);
+        if (bytes[r]) RT_HIP(hipMemcpyAsync(all[r].data(), d_recv.p + at, bytes[r], hipMemcpyDeviceToHost, st));
+        at += bytes[r];
+    }
+    RT_HIP(hipStreamSynchronize(st));
+    X.bytes += total;
+    return 0;
+}
+
+// ---- (de)serialisation of a correction for the gather -------------------------------------------------
+namespace {
+
+template <typename T>
+void put(std::vector<uint8_t> &b, const T *p, size_t n) {
+    const size_t at = b.size();
+    b.resize(at + n * sizeof(T));
+    if (n) memcpy(b.data() + at, p, n * sizeof(T));
+}
+template <typename T>
+const T *take(const std::vector<uint8_t> &b, size_t &at, size_t n) {
+    const T *p = (const T *)(b.data() + at);
+    at += n * sizeof(T);
+    return p;
+}
+
+// reads of a set as (key, piece index) so the root can order them; sequences are copied by the merge
+struct rec_ref { uint64_t key; uint32_t piece, idx; };
+
+struct piece_view {                      // one rank's serialised set
+    uint32_t n = 0;
+    const int32_t *read_id = nullptr, *cluster_id = nullptr, *n_reads = nullptr;
+    const uint32_t *pack = nullptr;
+    const uint64_t *off = nullptr;
+    const char *seq = nullptr, *qual = nullptr;
+};
+
+void put_set(std::vector<uint8_t> &b, const rattle_read_set &S, const uint32_t *pack) {
+    const uint64_t n = S.n;
+    put(b, &n, 1);
+    put(b, S.off, n + 1);                // 8-byte fields first: every array stays naturally aligned
+    put(b, S.read_id, n); put(b, S.cluster_id, n); put(b, S.n_reads, n);
+    std::vector<uint32_t> none;
+    if (!pack) { none.assign(n, 0); pack = none.data(); }
+    put(b, pack, n);                     // 4 x 4n bytes: still 8-byte aligned
+    const uint64_t tot = S.off[n];
+    put(b, S.seq, tot); put(b, S.qual, tot);
+    const uint64_t pad = (8 - (2 * tot) % 8) % 8;
+    const char z[8] = {0};
+    put(b, z, pad);
+}
+
+piece_view take_set(const std::vector<uint8_t> &b, size_t &at) {
+    piece_view V;
+    const uint64_t n = *take<uint64_t>(b, at, 1);
+    V.n = (uint32_t)n;
+    V.off = take<uint64_t>(b, at, n + 1);
+    V.read_id = take<int32_t>(b, at, n); V.cluster_id = take<int32_t>(b, at, n); V.n_reads = take<int32_t>(b, at, n);
+    V.pack = take<uint32_t>(b, at, n);
+    const uint64_t tot = V.off[n];
+    V.seq = take<char>(b, at, tot); V.qual = take<char>(b, at, tot);
+    at += (8 - (2 * tot) % 8) % 8;
+    return V;
+}
+
+void alloc_set(rattle_read_set &S, uint32_t n, uint64_t tot) {
+    S.n = n;
+    const size_t m = std::max<size_t>(1, n);
+    S.read_id = (int32_t *)malloc(m * 4); S.cluster_id = (int32_t *)malloc(m * 4); S.n_reads = (int32_t *)malloc(m * 4);
+    S.off = (uint64_t *)malloc(((size_t)n + 1) * 8);
+    S.seq = (char *)malloc(tot + 1); S.qual = (char *)malloc(tot + 1);
+    S.seq[tot] = 0; S.qual[tot] = 0;
+}
+
+// merge the pieces' records in key order (stable: equal keys keep piece order, then record order)
+void merge_sets(const std::vector<piece_view> &V, rattle_read_set &S, uint32_t **pack_out) {
+    std::vector<rec_ref> refs;
+    uint64_t tot = 0;
+    for (uint32_t p = 0; p < V.size(); ++p) {
+        for (uint32_t i = 0; i < V[p].n; ++i) {
+            // members of packs that never entered the queue come first (the reference pushes them while it builds the packs)
+            const uint64_t key = V[p].pack[i] == 0xFFFFFFFFu ? 0 : 1 + (uint64_t)V[p].pack[i];
+            refs.push_back(rec_ref{key, p, i});
+        }
+        tot += V[p].n ? V[p].off[V[p].n] : 0;
+    }
+    std::stable_sort(refs.begin(), refs.end(), [](const rec_ref &a, const rec_ref &b) { return a.key < b.key; });
+    alloc_set(S, (uint32_t)refs.size(), tot);
+    uint32_t *pk = (uint32_t *)malloc(std::max<size_t>(1, refs.size()) * 4);
+    uint64_t at = 0;
+    for (size_t i = 0; i < refs.size(); ++i) {
+        const piece_view &P = V[refs[i].piece];
+        const uint32_t j = refs[i].idx;
+        const uint64_t len = P.off[j + 1] - P.off[j];
+        S.read_id[i] = P.read_id[j]; S.cluster_id[i] = P.cluster_id[j]; S.n_reads[i] = P.n_reads[j];
+        S.off[i] = at;
+        memcpy(S.seq + at, P.seq + P.off[j], len); memcpy(S.qual + at, P.qual + P.off[j], len);
+        pk[i] = P.pack[j];
+        at += len;
+    }
+    S.off[refs.size()] = at;
+    if (pack_out) *pack_out = pk; else free(pk);
+}
+
+}  // namespace
+
+int correction_gather(rattle_ctx *ctx, const rattle_correction *L, int root, rattle_correction **merged) {
+    exchange &X = ctx->xchg;
+    *merged = nullptr;
+    if (root < 0 || root >= X.nranks) { set_error("root out of range"); return RATTLE_ERR_ARG; }
+    std::vector<uint8_t> mine;
+    put_set(mine, L->corrected, L->corrected_pack);
+    put_set(mine, L->uncorrected, L->uncorrected_pack);
+    {
+        const rattle_skip_list &K = L->skipped;
+        const uint64_t n = K.n, tot = K.read_off[K.n];
+        put(mine, &n, 1); put(mine, K.read_off, n + 1);
+        put(mine, K.cluster_id, n); put(mine, K.pack, n); put(mine, K.stage, n); put(mine, K.read_id, tot);
+        if ((3 * n + tot) & 1) { const uint32_t z = 0; put(mine, &z, 1); }
+        put(mine, L->counters, 8);
+    }
+    std::vector<std::vector<uint8_t>> all;
+    RT_TRY(xchg_gatherv(ctx, mine, root, all));
+    if (X.rank != root) return 0;
+    rattle_correction *R = (rattle_correction *)calloc(1, sizeof(rattle_correction));
+    std::vector<piece_view> cor, unc;
+    struct skip_ref { int32_t cid; uint32_t pack, stage; const int32_t *rid; uint64_t n; };
+    std::vector<skip_ref> sk;
+    uint64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < X.nranks; ++r) {
+        size_t at = 0;
+        cor.push_back(take_set(all[r], at));
+        unc.push_back(take_set(all[r], at));
+        const uint64_t n = *take<uint64_t>(all[r], at, 1);
+        const uint64_t *ro = take<uint64_t>(all[r], at, n + 1);
+        const int32_t *cid = take<int32_t>(all[r], at, n);
+        const uint32_t *pk = take<uint32_t>(all[r], at, n), *stg = take<uint32_t>(all[r], at, n);
+        const uint64_t tot = ro[n];
+        const int32_t *rid = take<int32_t>(all[r], at, tot);
+        if ((3 * n + tot) & 1) take<uint32_t>(all[r], at, 1);
+        const uint64_t *c8 = take<uint64_t>(all[r], at, 8);
+        for (uint64_t i = 0; i < n; ++i) sk.push_back(skip_ref{cid[i], pk[i], stg[i], rid + ro[i], ro[i + 1] - ro[i]});
+        cnt[0] += c8[0]; cnt[1] += c8[1];                 // DP cells and alignments add up; the pack count is global already
+        cnt[2] = c8[2];
+        cnt[3] += c8[3]; cnt[4] += c8[4];
+    }
+    merge_sets(cor, R->corrected, &R->corrected_pack);
+    merge_sets(unc, R->uncorrected, &R->uncorrected_pack);
+    // consensi are complete on every rank
+    {
+        const rattle_read_set &S = L->consensi;
+        alloc_set(R->consensi, S.n, S.off[S.n]);
+        memcpy(R->consensi.read_id, S.read_id, (size_t)S.n * 4); memcpy(R->consensi.cluster_id, S.cluster_id, (size_t)S.n * 4);
+        memcpy(R->consensi.n_reads, S.n_reads, (size_t)S.n * 4); memcpy(R->consensi.off, S.off, ((size_t)S.n + 1) * 8);
+        memcpy(R->consensi.seq, S.seq, S.off[S.n]); memcpy(R->consensi.qual, S.qual, S.off[S.n]);
+    }
+    // skip list ordered by (cluster, pack, stage)
+    std::stable_sort(sk.begin(), sk.end(), [](const skip_ref &a, const skip_ref &b) {
+        return a.cid != b.cid ? a.cid < b.cid : (a.pack != b.pack ? a.pack < b.pack : a.stage < b.stage);
+    });
+    {
+        rattle_skip_list &K = R->skipped;
+        const size_t n = sk.size();
+        K.n = (uint32_t)n;
+        K.cluster_id = (int32_t *)malloc(std::max<size_t>(1, n) * 4); K.pack = (uint32_t *)malloc(std::max<size_t>(1, n) * 4);
+        K.stage = (uint32_t *)malloc(std::max<size_t>(1, n) * 4); K.read_off = (uint64_t *)malloc((n + 1) * 8);
+        uint64_t tot = 0;
+        for (size_t i = 0; i < n; ++i) { K.cluster_id[i] = sk[i].cid; K.pack[i] = sk[i].pack; K.stage[i] = sk[i].stage; K.read_off[i] = tot; tot += sk[i].n; }
+        K.read_off[n] = tot;
+        K.read_id = (int32_t *)malloc(std::max<uint64_t>(1, tot) * 4);
+        for (size_t i = 0; i < n; ++i) if (sk[i].n) memcpy(K.read_id + K.read_off[i], sk[i].rid, sk[i].n * 4);
+    }
+    memcpy(R->counters, cnt, sizeof(cnt));
+    *merged = R;
+    return 0;
+}
+
+}  // namespace rattle
+
+using namespace rattle;
+
+extern "C" {
+
+int rattle_hip_set_exchange(rattle_ctx *c, int rank, int nranks, rattle_allgatherv_fn fn, void *user) {
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) { set_error("bad exchange arguments"); return RATTLE_ERR_ARG; }
+    if (c->xchg.comm) { set_error("an RCCL communicator is attached: rattle_hip_comm_destroy first"); return RATTLE_ERR_STATE; }
+    c->xchg.rank = rank; c->xchg.nranks = nranks; c->xchg.fn = fn; c->xchg.user = user;
+    return 0;
+}
+
+int rattle_hip_comm_unique_id(uint8_t *id_out) {
+    if (!id_out) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    RT_TRY(load_rccl());
+    nccl_uid id;
+    RT_NCCL(rccl().GetUniqueId(&id));
+    memcpy(id_out, id.internal, RATTLE_COMM_ID_BYTES);
+    return 0;
+}
+
+int rattle_hip_comm_init(rattle_ctx *c, int rank, int nranks, const uint8_t *id) {
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad communicator arguments"); return RATTLE_ERR_ARG; }
+    if (c->xchg.comm) { set_error("communicator already attached"); return RATTLE_ERR_STATE; }
+    if (c->device < 0) { set_error("an RCCL communicator needs a device context"); return RATTLE_ERR_STATE; }
+    RT_TRY(load_rccl());
+    RT_HIP(hipSetDevice(c->device));
+    nccl_uid u;
+    memcpy(u.internal, id, RATTLE_COMM_ID_BYTES);
+    nccl_comm comm = nullptr;
+    RT_NCCL(rccl().CommInitRank(&comm, nranks, u, rank));
+    c->xchg.comm = comm; c->xchg.rank = rank; c->xchg.nranks = nranks; c->xchg.fn = nullptr; c->xchg.user = nullptr;
+    return 0;
+}
+
+int rattle_hip_comm_destroy(rattle_ctx *c) {
+    if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
+    if (c->xchg.comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)rccl().CommDestroy((nccl_comm)c->xchg.comm);
+    }
+    c->xchg = exchange();
+    return 0;
+}
+
+int rattle_hip_comm_stats(rattle_ctx *c, uint64_t *calls, uint64_t *bytes) {
+    if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
+    if (calls) *calls = c->xchg.calls;
+    if (bytes) *bytes = c->xchg.bytes;
+    return 0;
+}
+
+int rattle_hip_correction_gather(rattle_ctx *c, const rattle_correction *local, int root, rattle_correction **merged) {
+    if (!c || !local || !merged) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    if (c->device >= 0) RT_HIP(hipSetDevice(c->device));
+    return correction_gather(c, local, root, merged);
+}
+
+int rattle_hip_plan_packs(const uint64_t *off, uint32_t n_reads, uint32_t n_clusters, const uint32_t *coff, const int32_t *mid,
+                          const uint8_t *mrev, const rattle_correct_params *P, int nranks, rattle_pack_plan **out) {
+    if (!off || !P || !out || nranks < 1 || (n_clusters && (!coff || !mid || !mrev))) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    *out = nullptr;
+    pack_plan PL;
+    RT_TRY(plan_packs(off, n_reads, n_clusters, coff, mid, mrev, P, nranks, PL));
+    rattle_pack_plan *R = (rattle_pack_plan *)calloc(1, sizeof(rattle_pack_plan));
+    const size_t np = PL.pk_cid.size(), nm = PL.members.size(), ns = PL.small.size();
+    R->n_packs = (uint32_t)np;
+    R->pack_first = (uint32_t *)malloc((np + 1) * 4);
+    memcpy(R->pack_first, PL.first.data(), (np + 1) * 4);
+    R->member_id = (int32_t *)malloc(std::max<size_t>(1, nm) * 4); R->member_rev = (uint8_t *)malloc(std::max<size_t>(1, nm));
+    for (size_t i = 0; i < nm; ++i) { R->member_id[i] = PL.members[i].rid; R->member_rev[i] = PL.members[i].rev; }
+    R->pack_cluster = (int32_t *)malloc(std::max<size_t>(1, np) * 4); R->pack_local = (uint32_t *)malloc(std::max<size_t>(1, np) * 4);
+    R->pack_cost = (uint64_t *)malloc(std::max<size_t>(1, np) * 8); R->pack_owner = (uint32_t *)malloc(std::max<size_t>(1, np) * 4);
+    if (np) {
+        memcpy(R->pack_cluster, PL.pk_cid.data(), np * 4); memcpy(R->pack_local, PL.pk_local.data(), np * 4);
+        memcpy(R->pack_cost, PL.pk_cost.data(), np * 8); memcpy(R->pack_owner, PL.pk_owner.data(), np * 4);
+    }
+    R->n_unqueued = (uint32_t)ns;
+    R->unqueued_id = (int32_t *)malloc(std::max<size_t>(1, ns) * 4); R->unqueued_cluster = (int32_t *)malloc(std::max<size_t>(1, ns) * 4);
+    for (size_t i = 0; i < ns; ++i) { R->unqueued_id[i] = PL.small[i].rid; R->unqueued_cluster[i] = PL.small_cid[i]; }
+    *out = R;
+    return 0;
+}
+
+void rattle_hip_pack_plan_free(rattle_pack_plan *p) {
+    if (!p) return;
+    free(p->pack_first); free(p->member_id); free(p->member_rev); free(p->pack_cluster); free(p->pack_local);
+    free(p->pack_cost); free(p->pack_owner); free(p->unqueued_id); free(p->unqueued_cluster);
+    free(p);
+}
+
+int rattle_hip_lpt_assign(const uint64_t *cost, uint32_t n, int nranks, uint32_t *owner_out) {
+    if ((n && (!cost || !owner_out)) || nranks < 1) { set_error("bad argument"); return RATTLE_ERR_ARG; }
+    std::vector<uint64_t> c(cost, cost + n);
+    std::vector<uint32_t> o;
+    lpt_assign(c, nranks, o);
+    if (n) memcpy(owner_out, o.data(), (size_t)n * 4);
+    return 0;
+}
+
+}  // extern "C"

@@ -143,6 +143,12 @@ static uint32_t pow2ceil(uint32_t x) {
 
 int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32_t n, int k, int both) {
     if (k < 1 || k > 16) { set_error("kmer size must be in [1,16] (main.cpp:223)"); return RATTLE_ERR_ARG; }
+    // every argument is checked before the resident index is touched
+    if (n && off[0] != 0) { set_error("offsets[0] must be 0"); return RATTLE_ERR_ARG; }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (off[i + 1] < off[i]) { set_error("offsets must be non-decreasing"); return RATTLE_ERR_ARG; }
+        if (off[i + 1] - off[i] > 0x7FFFFFF0ull) { set_error("read too long"); return RATTLE_ERR_ARG; }
+    }
     read_index &X = ctx->idx;
     X.n = n; X.k = k; X.both = both ? 1 : 0;
     X.h_off.assign(off, off + n + 1);
@@ -151,7 +157,6 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     uint64_t ko = 0;
     for (uint32_t i = 0; i < n; ++i) {
         uint64_t L = off[i + 1] - off[i];
-        if (L > 0x7FFFFFF0ull) { set_error("read too long"); return RATTLE_ERR_ARG; }
         X.h_len[i] = (uint32_t)L;
         X.h_koff[i] = ko;
         ko += L > (uint64_t)k ? L - k : 0;
@@ -160,7 +165,6 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     X.total_bases = off[n] - off[0];
     X.total_kmers = ko;
     if (n == 0) return 0;
-    if (off[0] != 0) { set_error("offsets[0] must be 0"); return RATTLE_ERR_ARG; }
 
     RT_TRY(X.seq.reserve(X.total_bases + 16));
     RT_TRY(X.off.reserve(n + 1));
@@ -175,7 +179,8 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         RT_TRY(X.pc[s].reserve(n));
     }
     hipStream_t st = ctx->stream;
-    RT_HIP(hipMemcpyAsync(X.seq.p, seq, X.total_bases, hipMemcpyDefault, st));      // host buffer or a device-resident gather
+    // host buffer, a device-resident gather, or the index's own copy (second index over the same reads: --iso)
+    if (seq != X.seq.p) RT_HIP(hipMemcpyAsync(X.seq.p, seq, X.total_bases, hipMemcpyDefault, st));
     RT_HIP(hipMemcpyAsync(X.off.p, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(X.koff.p, X.h_koff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     RT_HIP(hipMemcpyAsync(X.len.p, X.h_len.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -222,8 +227,12 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
                     if (rc) break;
                     gs = d_gs.p;
                 }
-                if (shm > 64 * 1024)
-                    (void)hipFuncSetAttribute((const void *)kmer_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                if (shm > 64 * 1024 &&
+                    hipFuncSetAttribute((const void *)kmer_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {
+                    set_error("kmer_extract: this device cannot give a workgroup " + std::to_string(shm) + " B of LDS (read of " + std::to_string(Lmax) + " nt)");
+                    rc = RATTLE_ERR_HIP;
+                    break;
+                }
                 hipLaunchKernelGGL(kmer_extract_kernel, dim3(m, ns), dim3(256), shm, st, X.seq.p, X.off.p, X.koff.p,
                                    d_items.p + done + b, k, P, Lmax, X.uh.p, X.kh[0].p, X.kp[0].p, X.kh[1].p, X.kp[1].p,
                                    X.bv[0].p, X.bv[1].p, X.pc[0].p, X.pc[1].p, gs, d_bad.p);

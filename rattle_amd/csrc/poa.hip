@@ -70,6 +70,7 @@ struct poa_args {
     uint32_t *out_width;           // per pack
     uint32_t *status;              // per pack: 0 ok, else error code
     unsigned long long *counters;  // [0] DP cells, [1] alignments, [2] final nodes, [3] rows, [4..7] phase ticks
+    unsigned long long *prof;      // POA_PROFILE builds: per class [0] plan [1] DP [2] ties [3] traceback [4] add_alignment [5] merge_order [6] final sort + columns [7] whole packs
 };
 
 #ifdef POA_PROFILE
@@ -1043,8 +1044,10 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
         const uint32_t pk = A.queue[qi];
         const uint32_t q0 = A.pack_first[pk], q1 = A.pack_first[pk + 1];
         S.n_nodes = 0; S.n_edges = 0; S.err = 0; S.sp = 0; S.spilled = 0;
-        unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0, t_tie = 0;
-        (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add; (void)t_tie;
+        unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0, t_tie = 0, t_merge = 0;
+        (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add; (void)t_tie; (void)t_merge;
+        const unsigned long long t_pack0 = PT_NOW();
+        (void)t_pack0;
 
         for (uint32_t q = q0; q < q1 && !S.err; ++q) {
             const uint64_t so = A.off[q];
@@ -1538,6 +1541,8 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
             S.n_edges = s_bc[3]; S.err = s_bc[4];
             __syncthreads();
             // ---- 6. merge_order: insert the new nodes into the row order (all threads) ----
+            const unsigned long long t4 = PT_NOW();
+            (void)t4;
             if (!S.err) {
                 const uint32_t T = S.n_nodes - n_old;
                 if (T > 0) {
@@ -1560,9 +1565,12 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                 }
             }
             t_add += PT_NOW() - t3;
+            t_merge += PT_NOW() - t4;
         }
 
         // ---- generate_multiple_sequence_alignment: column per node, then per base ----
+        const unsigned long long t5 = PT_NOW();
+        (void)t5;
         __syncthreads();
         if (tid == 0) { s_bc[6] = 0; s_bc[4] = S.err; }
         __syncthreads();
@@ -1597,6 +1605,9 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
             atomicAdd(&A.counters[5], t_dp);           // DP rows
             atomicAdd(&A.counters[6], t_tb);           // best cell + traceback
             atomicAdd(&A.counters[7], t_add);          // add_alignment
+            const unsigned long long t_end = PT_NOW();
+            atomicAdd(&A.prof[0], t_topo); atomicAdd(&A.prof[1], t_dp); atomicAdd(&A.prof[2], t_tie); atomicAdd(&A.prof[3], t_tb - t_tie);
+            atomicAdd(&A.prof[4], t_add - t_merge); atomicAdd(&A.prof[5], t_merge); atomicAdd(&A.prof[6], t_end - t5); atomicAdd(&A.prof[7], t_end - t_pack0);
 #endif
         }
     }
@@ -1639,11 +1650,14 @@ static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIAN
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
+// skipped != nullptr: packs that do not fit the device are flagged there (1) instead of failing the call;
+// their width is 0 and their columns are undefined.
 int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_off_in, const uint64_t *off, uint32_t n_seqs,
                    const uint32_t *pack_first, uint32_t n_packs, uint32_t *d_col_out, uint32_t *d_width_out, uint32_t *h_width_out,
-                   unsigned long long *h_cnt) {
+                   unsigned long long *h_cnt, std::vector<uint8_t> *skipped) {
     hipStream_t st = ctx->stream;
     for (int i = 0; i < 16; ++i) h_cnt[i] = 0;
+    if (skipped) skipped->assign(n_packs, 0);
     if (n_packs == 0 || n_seqs == 0) { for (uint32_t p = 0; p < n_packs; ++p) h_width_out[p] = 0; return 0; }
     if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
 
@@ -1656,7 +1670,11 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) m = std::max<uint32_t>(m, (uint32_t)(off[q + 1] - off[q]));
         pbases[p] = off[pack_first[p + 1]] - off[pack_first[p]];
         pmaxL[p] = m;
-        if (m > POA_MAX_LEN) { set_error("sequence longer than " + std::to_string(POA_MAX_LEN) + " nt in a POA pack"); return RATTLE_ERR_ARG; }
+        if (m > POA_MAX_LEN) {
+            if (skipped) { (*skipped)[p] = 1; continue; }
+            set_error("sequence longer than " + std::to_string(POA_MAX_LEN) + " nt in a POA pack");
+            return RATTLE_ERR_ARG;
+        }
         int cls = 0;
         while (cls < POA_CLASSES - 1 && m > k_class_cols[cls]) ++cls;
         by_class[cls].push_back(p);
@@ -1671,9 +1689,13 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     RT_HIP(hipMemcpyAsync(d_pf.p, pack_first, (n_packs + 1) * 4, hipMemcpyHostToDevice, st));
     RT_HIP(hipMemsetAsync(d_cnt.p, 0, 160 * 8, st));
     RT_HIP(hipMemsetAsync(d_status.p, 0xFF, n_packs * 4, st));
+    RT_HIP(hipMemsetAsync(d_width.p, 0, n_packs * 4, st));         // skipped packs keep width 0 (kernel D then leaves them alone)
     std::vector<uint32_t> h_status(n_packs);
 #ifdef POA_HIST
     unsigned long long h_hist[160] = {0};
+#endif
+#ifdef POA_PROFILE
+    unsigned long long h_prof[POA_CLASSES * 8] = {0};
 #endif
 
     size_t free_b = 0, total_b = 0;
@@ -1701,6 +1723,8 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         size_t shm = 0;
         uint32_t n_slots = 0;
         int bpc = 1;
+        int rounds = 0;                            // passes this class has taken
+        bool clamped = false;                      // cell_cap was cut to what one slot can get: packs that still fail are skipped
         const poa_variant *V = nullptr;
     } C[POA_CLASSES];
     // RATTLE_POA_WAVES=1 selects the one/two-wave variants (measured slower than four waves per pack even
@@ -1712,76 +1736,106 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
         if (c < 3 && getenv("RATTLE_POA_UNPACKED")) C[c].V = &k_unpacked[c];
     }
-    // round 0: many slots with a modest arena; later rounds: failed packs with larger arenas.
-    // The column classes of one round run concurrently on their own streams.
-    for (int round = 0; round < 6 && rc == 0; ++round) {
+    // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
+    // The column classes of one pass run concurrently on their own streams.
+    // (RATTLE_POA_BUDGET_MB: tests shrink the arena to exercise the skip path)
+    const uint64_t budget = getenv("RATTLE_POA_BUDGET_MB") ? (uint64_t)atoll(getenv("RATTLE_POA_BUDGET_MB")) << 20 : (uint64_t)(free_b * 0.85);
+    // slot layout of class c for its current capacities; returns bytes per slot
+    auto plan_class = [&](int c, uint64_t tb, uint32_t tl) {
+        cls_plan &P = C[c];
+        const uint32_t cpl = P.V->cpl;
+        const bool long_rows = c == POA_CLASSES - 1;     // int32 cells, sequence read in place (no LDS copy)
+        uint32_t ncap = (uint32_t)std::min<uint64_t>(P.node_cap, tb + 1);
+        ncap = (ncap + 31u) & ~31u;
+        const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
+        const uint32_t acap = tl + ncap + 16;
+        const uint32_t scap = ncap + POA_STACK;
+        const uint32_t qcap = ((tl + cpl - 1) / cpl * cpl + 15u) & ~15u;
+        const uint64_t ccap = std::min<uint64_t>(P.cell_cap, (uint64_t)(ncap + 1) * qcap);
+        poa_args &A = P.A;
+        uint64_t o = 0;
+        auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
+        A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
+        A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
+        A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
+        A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
+        const uint64_t cell_bytes = long_rows ? 4 : 2;
+        if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
+            const uint64_t eb = cpl == 4 ? 1 : cpl <= 8 ? 2 : 4;
+            A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * eb);
+        } else if (P.V->pk == 0) {         // H int16 plus a nibble per column (min(H-F,3), min(H-E,3))
+            A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * ((cpl + 7) / 8) * 4);
+        } else {                           // segmented int32 rows: H int32 plus a nibble per column
+            A.o_H = take(ccap * cell_bytes); A.o_F = take(0); A.o_E = take(ccap / 2 + 64);
+        }
+        A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
+        P.per_slot = o;
+        A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
+        const uint32_t lds_seq = long_rows ? 16u : qcap;
+        auto lds_bytes = [&](const poa_variant *V) {
+            const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
+            return (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 16 + 64;
+        };
+        if ((c == 4 || c == 5) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 4];
+        P.shm = lds_bytes(P.V);
+        A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = lds_seq;
+        return o;
+    };
+    auto give_up = [&](cls_plan &P) -> int {       // the class's remaining packs do not fit this device
+        if (!skipped) { set_error("poa: " + std::to_string(P.todo.size()) + " pack(s) exceed the device arena"); return RATTLE_ERR_HIP; }
+        for (uint32_t p : P.todo) (*skipped)[p] = 1;
+        P.todo.clear();
+        return 0;
+    };
+    for (int pass = 0; pass < 64 && rc == 0; ++pass) {
         bool any = false;
         uint64_t want_bytes = 0;
-        for (int c = 0; c < POA_CLASSES; ++c) {
+        for (int c = 0; c < POA_CLASSES && rc == 0; ++c) {
             cls_plan &P = C[c];
             P.n_slots = 0;
             if (P.todo.empty()) continue;
-            any = true;
-            const uint32_t cpl = P.V->cpl;
+            if (P.rounds >= 6) { rc = give_up(P); continue; }
             std::sort(P.todo.begin(), P.todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
             uint64_t tb = 0; uint32_t tl = 0;
             for (uint32_t p : P.todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
-            const bool long_rows = c == POA_CLASSES - 1;     // int32 cells, sequence read in place (no LDS copy)
-            if (round == 0 && !getenv("RATTLE_POA_NODE_CAP")) {
-                // first-round capacity: a pack of ~200 reads at 10 % error grows to ~5 nodes per base of its
+            if (P.rounds == 0 && !getenv("RATTLE_POA_NODE_CAP")) {
+                // first-pass capacity: a pack of ~200 reads at 10 % error grows to ~5 nodes per base of its
                 // longest read; packs that still outgrow it are re-run with 4x nodes
                 P.node_cap = std::max<uint32_t>(P.node_cap, (uint32_t)std::min<uint64_t>(6ull * tl, 1u << 20));
                 P.cell_cap = std::max<uint64_t>(P.cell_cap, (uint64_t)(std::min<uint64_t>(P.node_cap, tb + 1) + 64) * (tl + 32));
             }
-            uint32_t ncap = (uint32_t)std::min<uint64_t>(P.node_cap, tb + 1);
-            ncap = (ncap + 31u) & ~31u;
-            const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
-            const uint32_t acap = tl + ncap + 16;
-            const uint32_t scap = ncap + POA_STACK;
-            const uint32_t qcap = ((tl + cpl - 1) / cpl * cpl + 15u) & ~15u;
-            const uint64_t ccap = std::min<uint64_t>(P.cell_cap, (uint64_t)(ncap + 1) * qcap);
-            poa_args &A = P.A;
-            uint64_t o = 0;
-            auto take = [&](uint64_t bytes) { uint64_t r = o; o += (bytes + 255) & ~(uint64_t)255; return r; };
-            A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
-            A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
-            A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
-            A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
-            const uint64_t cell_bytes = long_rows ? 4 : 2;
-            if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
-                const uint64_t eb = cpl == 4 ? 1 : cpl <= 8 ? 2 : 4;
-                A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * eb);
-            } else if (P.V->pk == 0) {         // H int16 plus a nibble per column (min(H-F,3), min(H-E,3))
-                A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * ((cpl + 7) / 8) * 4);
-            } else {                           // segmented int32 rows: H int32 plus a nibble per column
-                A.o_H = take(ccap * cell_bytes); A.o_F = take(0); A.o_E = take(ccap / 2 + 64);
+            uint64_t per = plan_class(c, tb, tl);
+            if (per > budget) {
+                // one slot does not fit the HBM that is left: cut the DP record to what does fit; a pack that
+                // still fails with that is beyond this device (skip-and-report, or an error for the MSA entry)
+                const uint64_t cell_b2 = c == POA_CLASSES - 1 ? 9 : 4;                   // twice the bytes per cell
+                const uint64_t fixed = per - (P.A.cell_cap * cell_b2 + 1) / 2;
+                if (P.clamped || fixed + (1ull << 20) >= budget) { rc = give_up(P); continue; }
+                P.cell_cap = (budget - fixed - (1ull << 20)) * 2 / cell_b2;
+                P.clamped = true;
+                per = plan_class(c, tb, tl);
+                if (per > budget) { rc = give_up(P); continue; }
             }
-            A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
-            P.per_slot = o;
-            A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
-            const uint32_t lds_seq = long_rows ? 16u : qcap;
-            auto lds_bytes = [&](const poa_variant *V) {
-                const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
-                return (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 16 + 64;
-            };
-            if ((c == 4 || c == 5) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 4];
-            P.shm = lds_bytes(P.V);
+            any = true;
             P.bpc = P.V->max_blocks(P.shm);
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
-            A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = lds_seq;
             want_bytes += P.per_slot * P.n_slots;
         }
-        if (!any) break;
-        const uint64_t budget = (uint64_t)(free_b * 0.85);
-        if (want_bytes > budget) {             // scale every class down proportionally (at least one slot each)
+        if (rc || !any) break;
+        if (want_bytes > budget) {
+            // scale every class down proportionally (at least one slot each); classes whose single slots do
+            // not fit side by side wait for a later pass
             const double f = (double)budget / (double)want_bytes;
             want_bytes = 0;
-            for (int c = 0; c < POA_CLASSES; ++c) if (C[c].n_slots) {
+            for (int c = POA_CLASSES - 1; c >= 0; --c) if (C[c].n_slots) {
                 C[c].n_slots = std::max<uint32_t>(1, (uint32_t)(C[c].n_slots * f));
+                if (want_bytes + C[c].per_slot * C[c].n_slots > budget) {
+                    C[c].n_slots = (uint32_t)((budget - want_bytes) / C[c].per_slot);     // may become 0: deferred
+                }
                 want_bytes += C[c].per_slot * C[c].n_slots;
             }
         }
-        phase_timer T_round("    poa round (arena+kernels)");
+        phase_timer T_round("    poa pass (arena+kernels)");
         if (ctx->poa_arena_bytes < want_bytes) {
             if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
             ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
@@ -1804,12 +1858,12 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             poa_args &A = P.A;
             A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p + qoff; A.n_queue = (uint32_t)P.todo.size();
             A.queue_head = d_heads.p + c; A.arena = ctx->poa_arena + aoff; A.slot_stride = P.per_slot;
-            A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p;
+            A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p; A.prof = d_cnt.p + 32 + 8 * c;
             aoff += P.per_slot * P.n_slots;
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
-                fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, ring %u) round %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        c == POA_CLASSES - 1 ? "> 6144: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, round, P.todo.size(), P.n_slots,
+                fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, ring %u) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
+                        c == POA_CLASSES - 1 ? "> 6144: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, pass, P.todo.size(), P.n_slots,
                         P.per_slot / 1e6, P.bpc);
         }
         if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
@@ -1833,6 +1887,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         for (int c = 0; c < POA_CLASSES && rc == 0; ++c) {
             cls_plan &P = C[c];
             if (!P.n_slots) continue;
+            ++P.rounds;
             std::vector<uint32_t> again;
             for (uint32_t p : P.todo) {
                 const uint32_t s = h_status[p];
@@ -1841,7 +1896,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 else { set_error("poa_kernel: pack " + std::to_string(p) + " failed with status " + std::to_string(s)); rc = RATTLE_ERR_HIP; break; }
             }
             P.todo.swap(again);
-            if (!P.todo.empty()) { P.node_cap = std::min<uint32_t>(P.node_cap * 4, 1u << 20); P.cell_cap *= 8; }
+            if (!P.todo.empty()) {
+                if (P.clamped) { rc = give_up(P); continue; }
+                P.node_cap = std::min<uint32_t>(P.node_cap * 4, 1u << 20); P.cell_cap *= 8;
+            }
         }
     }
     d_heads.release();
@@ -1853,6 +1911,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     if (rc == 0) {
         hipError_t e = hipMemcpyAsync(h_width_out, d_width.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt.p, 128, hipMemcpyDeviceToHost, st);
+#ifdef POA_PROFILE
+        if (e == hipSuccess) e = hipMemcpyAsync(h_prof, d_cnt.p + 32, sizeof(h_prof), hipMemcpyDeviceToHost, st);
+#endif
 #ifdef POA_HIST
         if (e == hipSuccess) e = hipMemcpyAsync(h_hist, d_cnt.p, 160 * 8, hipMemcpyDeviceToHost, st);
 #endif
@@ -1861,9 +1922,30 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     }
     d_pf.release(); d_queue.release(); d_status.release(); d_cnt.release();
     if (rc) return rc;
+    if (skipped) for (uint32_t p = 0; p < n_packs; ++p) if ((*skipped)[p]) h_width_out[p] = 0;
 #ifdef POA_HIST
     fprintf(stderr, "[rattle] predecessor row distance histogram (first in-edge | further in-edges), d = 1..62, 63+:\n");
     for (int d = 1; d < 64; ++d) fprintf(stderr, "  d%-2d %12llu %12llu\n", d, h_hist[16 + d], h_hist[80 + d]);
+#endif
+#ifdef POA_PROFILE
+    {
+        // phase breakdown per column class (ticks of the 100 MHz wall clock, summed over the class's workgroups)
+        static const char *names[8] = {"plan", "dp_rows", "ties", "traceback", "add_alignment", "merge_order", "final_sort_columns", "pack_total"};
+        FILE *jf = getenv("RATTLE_POA_PROFILE_JSON") ? fopen(getenv("RATTLE_POA_PROFILE_JSON"), "a") : nullptr;
+        for (int c = 0; c < POA_CLASSES; ++c) {
+            const unsigned long long *q = h_prof + 8 * c;
+            if (!q[7]) continue;
+            fprintf(stderr, "[rattle] poa class %d (%u cols) phases, %% of workgroup time:", c, c < POA_CLASSES - 1 ? k_class_cols[c] : 0u);
+            for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f", names[i], 100.0 * (double)q[i] / (double)q[7]);
+            fprintf(stderr, "  (total %.3f block-seconds)\n", (double)q[7] * 1e-8);
+            if (jf) {
+                fprintf(jf, "{\"class\": %d, \"cols\": %u, \"n_packs\": %zu, \"block_seconds\": %.6f", c, c < POA_CLASSES - 1 ? k_class_cols[c] : 0u, by_class[c].size(), (double)q[7] * 1e-8);
+                for (int i = 0; i < 7; ++i) fprintf(jf, ", \"%s_pct\": %.2f", names[i], 100.0 * (double)q[i] / (double)q[7]);
+                fprintf(jf, "}\n");
+            }
+        }
+        if (jf) fclose(jf);
+    }
 #endif
 #ifdef POA_BARPROF
     fprintf(stderr, "[rattle] barrier cycles / dp cycles per wave: %.3f %.3f %.3f %.3f  (dp cycles per row, wave 0: %.0f)\n", (double)h_cnt[8] / h_cnt[12], (double)h_cnt[9] / h_cnt[13],
@@ -1892,7 +1974,7 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
     RT_HIP(hipMemcpyAsync(d_off.p, off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
     std::vector<uint32_t> h_width(n_packs);
     unsigned long long h_cnt[16];
-    int rc = poa_device_run(ctx, d_seq.p, d_off.p, off, n_seqs, pack_first, n_packs, d_col.p, d_width.p, h_width.data(), h_cnt);
+    int rc = poa_device_run(ctx, d_seq.p, d_off.p, off, n_seqs, pack_first, n_packs, d_col.p, d_width.p, h_width.data(), h_cnt, nullptr);
     if (rc == 0) {
         phase_timer T_d2h("    poa readback");
         rc = ctx->h_poa_col.reserve(total);

@@ -378,9 +378,14 @@ int mode_correct(int argc, char **argv) {
         {"clusters", {"-c", "--clusters"}, true}, {"output", {"-o", "--output"}, true}, {"gap-occ", {"-g", "--gap-occ"}, true},
         {"min-occ", {"-m", "--min-occ"}, true}, {"split", {"-s", "--split"}, true}, {"min-reads", {"-r", "--min-reads"}, true},
         {"threads", {"-t", "--threads"}, true}, {"verbose", {"--verbose"}, false}, {"device", {"--device"}, true},
-        {"vote-order", {"--vote-order"}, true}};
+        {"vote-order", {"--vote-order"}, true}, {"max-pack-cells", {"--max-pack-cells"}, true}};
     args_t a = parse(argc, argv, defs);
-    if (a.has("help")) { std::cerr << "rattle correct -i reads.fq -c clusters.out [-o dir] ... (flags of RATTLE's correct mode)\n"; return EXIT_SUCCESS; }
+    if (a.has("help")) {
+        std::cerr << "rattle correct -i reads.fq -c clusters.out [-o dir] ... (flags of RATTLE's correct mode)\n"
+                     "  --max-pack-cells N   leave packs whose largest alignment needs more than N DP cells uncorrected (default: only\n"
+                     "                       packs that do not fit the device are skipped); skipped packs are listed in skipped_packs.tsv\n";
+        return EXIT_SUCCESS;
+    }
     if (!a.has("input")) die("ERROR: No input file provided");
     if (!a.has("clusters")) die("ERROR: No clusters file provided");
     std::cerr << "Reading fasta file... ";
@@ -413,6 +418,7 @@ int mode_correct(int argc, char **argv) {
     P.split = a.i("split", 200); P.min_reads = a.i("min-reads", 5); P.n_threads = 0;
     std::string vo = a.str("vote-order", "");
     if (vo.size() == 6) memcpy(P.vote_order, vo.data(), 6);
+    if (a.has("max-pack-cells")) P.max_pack_cells = std::stoull(a.str("max-pack-cells", "0"));
     rattle_ctx *ctx = nullptr;
     chk(rattle_hip_ctx_create(a.i("device", 0), &ctx));
     rattle_correction *R = nullptr;
@@ -479,6 +485,15 @@ int mode_correct(int argc, char **argv) {
     write_set(R->corrected, true, outdir + "/corrected.fq");
     write_set(R->uncorrected, false, outdir + "/uncorrected.fq");
     write_fastq_file(consensi, outdir + "/consensi.fq");
+    if (R->skipped.n) {
+        // packs whose POA did not fit the device (or the --max-pack-cells budget): their reads are in uncorrected.fq
+        std::ofstream f(outdir + "/skipped_packs.tsv");
+        f << "cluster\tpack\tstage\treads\n";
+        for (uint32_t i = 0; i < R->skipped.n; ++i)
+            f << R->skipped.cluster_id[i] << "\t" << R->skipped.pack[i] << "\t" << R->skipped.stage[i] << "\t"
+              << (R->skipped.read_off[i + 1] - R->skipped.read_off[i]) << "\n";
+        std::cerr << R->skipped.n << " pack(s) with " << R->counters[4] << " reads were not corrected (DP beyond the device or the budget): skipped_packs.tsv" << std::endl;
+    }
     rattle_hip_correction_free(R);
     rattle_hip_ctx_destroy(ctx);
     std::cerr << "Done" << std::endl;

@@ -11,7 +11,7 @@ shipped fixtures:
     cseq    := svarint(seq_id) u8(rev) svarint(gene_id)      # current, 3-field
     cseq    := svarint(seq_id) u8(rev)                       # old, 2-field
 
-The product codec is the C++ one in rattle_amd/csrc/hps_codec.cpp; this file is
+The product codec is the C++ one in rattle_amd/csrc/rattle_main.cpp; this file is
 the independent restatement the tests compare it with.
 """
 from __future__ import annotations

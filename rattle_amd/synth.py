@@ -85,12 +85,25 @@ def fastq_text(seqs, quals, prefix="r") -> bytes:
     return b"".join(out)
 
 
+def mixed_transcriptome(n_tx: int, seed: int = 20260928, lo: int = 150, hi: int = 100000, body_hi: int = 8000, tail_frac: float = 0.01):
+    """Transcripts for BASELINE configs[4]: lengths log-uniform on [lo, hi] "truncated so that
+    the mean is ~2 kb": a body log-uniform on [lo, body_hi] (mean (body_hi - lo) / ln(body_hi / lo) ~ 2 kb for 150..8000)
+    plus a thin tail (tail_frac of the transcripts) log-uniform on [body_hi, hi].  Random ACGT, no exon structure."""
+    rng = np.random.default_rng(seed)
+    tail = rng.random(n_tx) < tail_frac
+    u = rng.random(n_tx)
+    lens = np.where(tail, np.exp(np.log(body_hi) + u * (np.log(hi) - np.log(body_hi))), np.exp(np.log(lo) + u * (np.log(body_hi) - np.log(lo))))
+    lens = np.clip(np.rint(lens), lo, hi).astype(np.int64)
+    return [_ACGT[rng.integers(0, 4, int(l))] for l in lens]
+
+
 def reads_packed(n: int, genes: int, isoforms: int = 1, both_strands: bool = True, seed: int = 20260929,
-                 tx_seed: int = 20260928, sub=0.04, ins=0.03, dele=0.03, exon=(80, 300), chunk: int = 500):
+                 tx_seed: int = 20260928, sub=0.04, ins=0.03, dele=0.03, exon=(80, 300), chunk: int = 500, tx=None):
     """Vectorised variant of reads() for large n: same model, returns packed arrays
     (seq uint8, qual uint8, offsets uint64[n+1], tx_id, strand).  Different random stream than
-    reads() (chunked numpy draws), same distributions."""
-    tx, _ = transcriptome(genes, isoforms, tx_seed, exon)
+    reads() (chunked numpy draws), same distributions.  tx: explicit transcript list (e.g. mixed_transcriptome)."""
+    if tx is None:
+        tx, _ = transcriptome(genes, isoforms, tx_seed, exon)
     txlen = np.array([len(t) for t in tx], np.int64)
     txoff = np.zeros(len(tx) + 1, np.int64)
     txoff[1:] = np.cumsum(txlen)

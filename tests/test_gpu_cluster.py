@@ -148,3 +148,33 @@ def test_cluster_unsorted_matches_cluster_command(gpu_ctx, oracle):
     cat, off = pack_reads(seqs)
     got = gpu_ctx.cluster_unsorted_packed(cat, off).as_list()
     assert got == want
+
+
+@pytest.mark.parametrize("is_rna", [False, True])
+def test_cluster_iso_unsorted_matches_iso_flow(gpu_ctx, is_rna):
+    """rattle_hip_cluster_iso_unsorted == the two-level flow of main.cpp:254-323 as cluster_command runs it
+    (itself checked against the oracle above): same transcript clusters, gene ids and order; also with staged reads."""
+    from rattle_amd.api import pack_reads
+    seqs, _, _, _ = synth.reads(1200, 8, 3, not is_rna, seed=35)
+    want, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))), iso=True, is_rna=is_rna)
+    cat, off = pack_reads(seqs)
+    for staged in (False, True):
+        if staged:
+            gpu_ctx.stage_reads(cat, None, off)
+        try:
+            cl, gid, ng = gpu_ctx.cluster_iso_unsorted_packed(cat, off, is_rna=is_rna)
+        finally:
+            if staged:
+                gpu_ctx.unstage_reads()
+        got = [((m[0], m[1], int(g)), [(s[0], s[1], int(g)) for s in mem]) for (m, mem), g in zip(cl.as_list(), gid)]
+        assert got == want
+        assert ng == len(set(g for (_, _, g), _ in want))
+
+
+def test_rna_mode_rejects_a_both_strand_index(gpu_ctx):
+    """cluster.cpp:42 returns before the reverse test in --rna mode; a both-strand index would let reverse hits through."""
+    from rattle_amd._lib import RattleError
+    seqs, _, _, _ = synth.reads(50, 2, 1, True, seed=1)
+    gpu_ctx.load_reads(sorted(seqs, key=lambda s: -len(s)), 10, True)
+    with pytest.raises(RattleError):
+        gpu_ctx.cluster_reads(is_rna=True)

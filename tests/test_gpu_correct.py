@@ -102,3 +102,112 @@ def test_correct_with_a_cluster_of_long_reads(gpu_ctx, oracle):
     got = correct_command(gpu_ctx, headers, seqs, quals, clusters)
     want = oracle.correct(headers, seqs, quals, hps.encode(clusters))
     assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+
+
+def test_whole_toyset_fixture_consensi_and_uncorrected(gpu_ctx, toyset, toyset_clusters):
+    """The reference's whole `correct` fixture through the HIP path: all 175 consensi of
+    toyset/rna/output/consensi.fq -- including the 8 clusters of more than 200 reads that go through POA #3
+    (correct.cpp:489-556), fed in the worker completion orders recorded in tests/test_oracle_correct.py --
+    and the 739 records of uncorrected.fq, in order (old fixture build's vote order)."""
+    from test_oracle_correct import PACK_ORDER, fixture_consensi
+    want = fixture_consensi()
+    seqs = [r[1] for r in toyset]; quals = [r[2] for r in toyset]
+    res = gpu_ctx.correct_reads(seqs, quals, toyset_clusters, vote_order=b"U-GTAC", pack_order=PACK_ORDER)
+    got = {r[1]: r[3].decode() for r in res["consensi"]}
+    assert len(want) == 175 and set(got) == set(want)
+    bad = [c for c in want if got[c] != want[c]]
+    assert not bad, bad
+    multi = [c for c in want if len(toyset_clusters[c][1]) > 200]
+    assert sorted(multi) == sorted(PACK_ORDER) and len(multi) == 8
+    ids = [toyset[r[0]][0].decode() for r in res["uncorrected"]]
+    assert ids == open(os.path.join(GOLDEN, "toyset_rna.uncorrected.ids")).read().split()
+    assert len(res["corrected"]) + len(res["uncorrected"]) == len(toyset) and res["skipped"] == []
+
+
+def test_pack_consensus_order_matches_oracle(gpu_ctx, oracle):
+    """rattle_correct_params::pack_order (the completion order of correct.cpp:469): same permutation through
+    the oracle and through the HIP path, on clusters with 3+ packs; a rejected non-permutation."""
+    from rattle_amd._lib import RattleError
+    seqs, quals, _, _ = synth.reads(700, 5, 1, True, seed=8)
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    big = [c for c, (_, mem) in enumerate(clusters) if len(mem) > 80]
+    assert big
+    po = {}
+    for c in big:
+        n = len(clusters[c][1])
+        nf = (n - 1) // 40 + 1
+        po[c] = list(reversed(range(nf)))
+    base = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=40)
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=40, pack_order=po)
+    want = oracle.correct(headers, seqs, quals, hps.encode(clusters), split=40, pack_order=po)
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    assert got[0] == base[0] and got[1] == base[1]                 # only the cluster consensi can depend on the order
+    with pytest.raises(RattleError):
+        correct_command(gpu_ctx, headers, seqs, quals, clusters, split=40, pack_order={big[0]: [0, 0, 1]})
+
+
+def test_uncorrected_records_keep_their_annotation_line(gpu_ctx, oracle):
+    """correct.cpp:362-366,289-293 push the ORIGINAL read_t (third line included) into uncorrected.fq."""
+    seqs, quals, _, _ = synth.reads(200, 6, 1, True, seed=3)
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    ann = [b"+note%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    out = correct_command(gpu_ctx, headers, seqs, quals, clusters, ann=ann)
+    lines = out[1].split(b"\n")
+    assert len(lines) > 4
+    for i in range(0, len(lines) - 1, 4):
+        rid = int(lines[i].split(b",")[0][2:])
+        assert lines[i + 2] == ann[rid]
+    assert all(l == b"+" for l in out[0].split(b"\n")[2::4])
+
+
+def test_packs_beyond_the_device_are_skipped_and_reported(gpu_ctx, oracle, monkeypatch):
+    """A pack whose DP record does not fit the arena is left out, not fatal: its reads come back untouched in
+    `uncorrected`, it contributes no consensus, it is listed in rattle_correction::skipped, and everything
+    else equals the oracle run on the remaining packs.  Forced with a tiny arena budget; then the static
+    max_pack_cells rule."""
+    seqs, quals, _, _ = synth.reads(300, 4, 1, True, seed=4)
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    tx = acgt[rng.integers(0, 4, 5200)]
+    long_ids = []
+    for _ in range(9):                       # one cluster of 5 kb reads: ~16 x the DP record of the 1 kb clusters
+        r = rng.random(len(tx))
+        s = tx.copy()
+        sub = (r >= 0.03) & (r < 0.06)
+        s[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        s = s[r >= 0.03]
+        long_ids.append(len(seqs))
+        seqs.append(s.tobytes())
+        quals.append(bytes(rng.integers(40, 70, len(s)).astype(np.uint8)))
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    lc = [c for c, (_, mem) in enumerate(clusters) if mem[0][0] in long_ids]
+    assert len(lc) == 1 and len(clusters[lc[0]][1]) == 9
+    full = correct_command(gpu_ctx, headers, seqs, quals, clusters, with_skipped=True)
+    assert full[4] == []
+    # without the long cluster (made a singleton list so cluster ids stay the same): what a skip must leave
+    rest = [(m, mem if c != lc[0] else mem[:0]) for c, (m, mem) in enumerate(clusters)]
+    want = oracle.correct(headers, seqs, quals, hps.encode([(m, mem) if mem else (m, [m]) for m, mem in rest]))
+    # (a) dynamic: the arena is too small for the long pack
+    monkeypatch.setenv("RATTLE_POA_BUDGET_MB", "64")
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters, with_skipped=True)
+    monkeypatch.delenv("RATTLE_POA_BUDGET_MB")
+    sk = got[4]
+    assert len(sk) == 1 and sk[0]["cluster"] == lc[0] and sk[0]["stage"] == 1 and sorted(sk[0]["reads"]) == sorted(long_ids)
+    assert int(got[3][3]) == 1 and int(got[3][4]) == 9
+    assert got[0] == want[0]                                       # corrected reads of every other pack
+    assert got[2] == want[2]                                       # and every other cluster's consensus; none for the skipped one
+    unc = got[1].split(b"\n")
+    by_id = {int(unc[i].split(b",")[0][2:]): (unc[i + 1], unc[i + 3]) for i in range(0, len(unc) - 1, 4)}
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for (rid, rev, _) in clusters[lc[0]][1]:
+        s, q = by_id[rid]
+        assert s == (seqs[rid].translate(comp)[::-1] if rev else seqs[rid]) and q == (quals[rid][::-1] if rev else quals[rid])
+    n_rec = lambda t: t.count(b"\n") // 4
+    assert n_rec(got[0]) + n_rec(got[1]) == len(seqs)
+    # (b) static rule: (6 L + 64) L cells for the longest read of the pack
+    got2 = correct_command(gpu_ctx, headers, seqs, quals, clusters, with_skipped=True, max_pack_cells=60_000_000)
+    assert len(got2[4]) == 1 and got2[4][0]["stage"] == 0 and sorted(got2[4][0]["reads"]) == sorted(long_ids)
+    assert got2[0] == want[0] and n_rec(got2[0]) + n_rec(got2[1]) == len(seqs)

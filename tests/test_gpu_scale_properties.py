@@ -1,6 +1,8 @@
 """Size-independent properties of the hot path at a BASELINE-sized input (1e5 reads, configs[1]):
 the oracle cannot run at this size in seconds, so correctness is checked through invariants of
 the reference's algorithm."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,3 +102,81 @@ def test_cluster_100k_bit_exact_with_oracle(gpu_ctx, oracle, big):
     # and the unsorted entry point translates the same clusters back to input ids
     tr = [((order[m[0]], m[1], -1), [(order[s[0]], s[1], -1) for s in mem]) for m, mem in want]
     assert cl.as_list() == tr
+
+
+# ---- BASELINE configs[2]: `cluster --iso` two-level at size (property checks; exact parity at 900 / 4000 reads is in
+# tests/test_gpu_cluster.py, tests/test_gpu_cli.py and tests/test_gpu_dist.py) ----------------------------------------
+def test_iso_two_level_properties_at_100k(gpu_ctx):
+    n = 100000
+    cat, qcat, off, tid, flip = synth.reads_packed(n, n // 600, 3, True, seed=78, exon=(50, 210))
+    iso, gid, ng = gpu_ctx.cluster_iso_unsorted_packed(cat, off)
+    gene = gpu_ctx.cluster_unsorted_packed(cat, off)
+    assert len(gene.main_id) == ng
+    # a partition of the reads, transcript clusters grouped by gene in gene order (main.cpp:283-316)
+    assert len(iso.member_id) == n and np.array_equal(np.sort(iso.member_id), np.arange(n))
+    assert np.all(np.diff(gid) >= 0) and gid[0] == 0 and gid[-1] == ng - 1
+    sizes = np.diff(iso.offsets.astype(np.int64))
+    owner_iso = np.empty(n, np.int64); owner_iso[iso.member_id] = np.repeat(gid, sizes)
+    gsizes = np.diff(gene.offsets.astype(np.int64))
+    owner_gene = np.empty(n, np.int64); owner_gene[gene.member_id] = np.repeat(np.arange(ng), gsizes)
+    assert np.array_equal(owner_iso, owner_gene)                      # the second level only splits gene clusters
+    # members ordered by length desc within a transcript cluster (cluster.cpp:71-77)
+    lens = np.diff(off.astype(np.int64))
+    same = np.ones(n, bool); same[iso.offsets[:-1].astype(np.int64)] = False
+    l = lens[iso.member_id]
+    assert np.all((l[1:] <= l[:-1]) | ~same[1:])
+    # quality on well separated synthetic isoforms: most big transcript clusters are pure
+    starts = iso.offsets[:-1].astype(np.int64)
+    pure = sum(1 for c in np.argsort(-sizes)[:100] if len(set(tid[iso.member_id[starts[c]:starts[c] + sizes[c]]])) == 1)
+    assert pure >= 85 and len(sizes) >= len(set(tid)) * 0.8
+    # determinism
+    iso2, gid2, ng2 = gpu_ctx.cluster_iso_unsorted_packed(cat, off)
+    assert np.array_equal(iso.member_id, iso2.member_id) and np.array_equal(gid, gid2) and ng == ng2
+
+
+# ---- BASELINE configs[4]: mixed-length --rna reads (150 .. 100 000 nt) through cluster -> correct -> polish -----------
+def test_mixed_length_rna_cluster_correct_polish(gpu_ctx, tmp_path):
+    """Does not fall over: reads up to ~70 kb cluster (global-memory sort / oversize pair paths of kernels K and B), packs
+    whose alignments exceed the DP budget are skipped and reported, everything else is corrected; every read comes back
+    exactly once; polish runs on the consensi.  Through the drop-in CLI, files on disk."""
+    import subprocess
+    from rattle_amd import hps
+    rattle = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rattle_amd", "csrc", "rattle")
+    n = 20000
+    tx = synth.mixed_transcriptome(400, seed=5)
+    cat, qcat, off, tid, _ = synth.reads_packed(n, 0, 1, False, seed=6, tx=tx, chunk=50)
+    lens = np.diff(off.astype(np.int64))
+    assert lens.max() > 50000 and (lens > 6144).sum() > 500 and lens.min() >= 130
+    fq = tmp_path / "mixed.fastq"
+    with open(fq, "wb") as f:
+        for i in range(n):
+            f.write(b"@r%d\n" % i); f.write(cat[int(off[i]):int(off[i + 1])].tobytes()); f.write(b"\n+\n"); f.write(qcat[int(off[i]):int(off[i + 1])].tobytes()); f.write(b"\n")
+    r = subprocess.run([rattle, "cluster", "-i", str(fq), "-o", str(tmp_path), "--rna", "--lower-length", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    clusters = hps.decode((tmp_path / "clusters.out").read_bytes(), fields=3)
+    members = sorted(s[0] for _, mem in clusters for s in mem)
+    assert members == list(range(n))
+    assert all(s[1] == 0 for _, mem in clusters for s in mem)                 # --rna: forward strand only
+    budget = (6 * 9000 + 64) * 9000                                            # alignments of reads up to ~9 kb
+    r = subprocess.run([rattle, "correct", "-i", str(fq), "-c", str(tmp_path / "clusters.out"), "-o", str(tmp_path), "--max-pack-cells", str(budget)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def ids(path):
+        return [int(l.split(b",")[0][2:]) for l in open(path, "rb").read().split(b"\n")[0::4] if l]
+    cor, unc = ids(tmp_path / "corrected.fq"), ids(tmp_path / "uncorrected.fq")
+    assert sorted(cor + unc) == list(range(n))                               # every read exactly once
+    skipped = [l.split("\t") for l in open(tmp_path / "skipped_packs.tsv").read().split("\n")[1:] if l]
+    assert skipped and all(s[2] == "0" for s in skipped)                     # the budget rule, nothing beyond the device
+    long_reads = set(int(i) for i in np.nonzero(lens > 9000)[0])
+    in_big_packs = [i for i in unc if i in long_reads]
+    assert len(in_big_packs) == len(long_reads)                              # reads beyond the budget are all uncorrected ...
+    assert len(cor) > 0.8 * (n - sum(int(s[3]) for s in skipped))            # ... and the others overwhelmingly corrected
+    cons = open(tmp_path / "consensi.fq", "rb").read().split(b"\n")
+    assert len(cons) // 4 > 100
+    r = subprocess.run([rattle, "polish", "-i", str(tmp_path / "consensi.fq"), "-o", str(tmp_path), "--rna"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tr = open(tmp_path / "transcriptome.fq", "rb").read().split(b"\n")
+    assert 0 < len(tr) // 4 <= len(cons) // 4
+    total = sum(int(l.split(b"total_reads=")[1].split()[0]) for l in tr[0::4] if l)
+    assert total == sum(int(l.split(b"reads=")[1].split()[0]) for l in cons[0::4] if l)

@@ -1,10 +1,14 @@
-"""Pin the POA + correction oracle against toyset/rna/output/consensi.fq.
+"""Pin the POA + correction oracle against toyset/rna/output/consensi.fq and uncorrected.fq.
 
 The fixture was produced by an older RATTLE build whose column-vote tie order had A before C
-("U-GTAC"; the current source gives "U-GTCA" with libstdc++, see oracle/orc_correct.hpp).
-With that order selected, every single-pack cluster's consensus is reproduced exactly; the 6
-multi-pack clusters that differ do so only through the pack completion order of the fixture's
-threaded run, recorded in PACK_ORDER and checked separately (slow, opt-in).
+("U-GTAC"; the current source gives "U-GTCA" with libstdc++, see oracle/orc_correct.hpp and
+test_vote_order_is_libstdcxx_iteration_order below).  With that order selected, every single-pack
+cluster's consensus is reproduced exactly; the 8 multi-pack clusters (> 200 reads, POA #3,
+correct.cpp:489-556) depend on the order in which the fixture's worker threads finished their packs
+(correct.cpp:469): PACK_ORDER records, per cluster, the completion order under which the fixture's
+sequence is reproduced (found by search over the permutations; 2 of the 8 need none).  The whole-fixture
+check -- all 175 consensi and the 739 uncorrected records in order -- takes ~6 CPU-minutes and is opt-in
+here (RATTLE_SLOW=1); the same check runs through the HIP path by default (tests/test_gpu_correct.py).
 """
 import gzip
 import os
@@ -28,7 +32,7 @@ def fixture_consensi():
     return out
 
 
-def run_subset(oracle, toyset, toyset_clusters, cids):
+def run_subset(oracle, toyset, toyset_clusters, cids, pack_order=None):
     """`correct` restricted to the chosen clusters (cluster ids are preserved by keeping
     empty placeholders out: we renumber and map back)."""
     sub = [toyset_clusters[c] for c in cids]
@@ -36,7 +40,8 @@ def run_subset(oracle, toyset, toyset_clusters, cids):
     headers = [r[0] for r in toyset]
     seqs = [r[1] for r in toyset]
     quals = [r[2] for r in toyset]
-    corrected, uncorrected, consensi, counters = oracle.correct(headers, seqs, quals, b)
+    po = {cids.index(c): v for c, v in (pack_order or {}).items() if c in cids}
+    corrected, uncorrected, consensi, counters = oracle.correct(headers, seqs, quals, b, pack_order=po)
     lines = consensi.decode().split("\n")
     got = {}
     for i in range(0, len(lines) - 1, 4):
@@ -83,3 +88,38 @@ def test_all_single_pack_consensi_and_uncorrected(oracle, toyset, toyset_cluster
     finally:
         oracle.set_cv_order(b"U-GTCA")
     assert all(got[c] == want[c] for c in cids) and len(cids) == 167
+
+
+@pytest.mark.skipif(not os.environ.get("RATTLE_SLOW"), reason="~6 CPU-minutes; RATTLE_SLOW=1 to run")
+def test_whole_fixture_consensi_and_uncorrected(oracle, toyset, toyset_clusters):
+    """Every cluster of the fixture: 175 consensi (the 8 multi-pack ones with the recorded completion orders)
+    and uncorrected.fq's 739 records, in order."""
+    want = fixture_consensi()
+    cids = list(range(len(toyset_clusters)))
+    oracle.set_cv_order(b"U-GTAC")
+    try:
+        got, unc, _ = run_subset(oracle, toyset, toyset_clusters, cids, PACK_ORDER)
+    finally:
+        oracle.set_cv_order(b"U-GTCA")
+    assert len(want) == 175 and set(got) == set(want)
+    bad = [c for c in want if got[c] != want[c]]
+    assert not bad, bad
+    ids = [l.split(",")[0] for l in unc.split("\n")[0::4] if l]
+    assert ids == open(os.path.join(GOLDEN, "toyset_rna.uncorrected.ids")).read().split()
+
+
+def test_vote_order_is_libstdcxx_iteration_order(tmp_path):
+    """correct.cpp:105-110 inserts A, C, T, U, G, '-' into an unordered_map<char, ...> and :174 iterates it:
+    the tie order of the column vote is that container's iteration order.  Measured here with the host's
+    libstdc++ (the product default "U-GTCA" and the oracle default must equal it)."""
+    import subprocess
+    src = tmp_path / "probe.cpp"
+    src.write_text('#include <cstdio>\n#include <unordered_map>\nint main(){std::unordered_map<char,int> m;'
+                   'for(char c:{\'A\',\'C\',\'T\',\'U\',\'G\',\'-\'})m[c]=0;for(auto&kv:m)putchar(kv.first);return 0;}\n')
+    exe = tmp_path / "probe"
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-o", str(exe), str(src)])
+    order = subprocess.check_output([str(exe)]).decode()
+    assert order == "U-GTCA"
+    from rattle_amd import _lib
+    assert b'"U-GTCA"' in open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "correct_driver.hip"), "rb").read()
+    assert b'"U-GTCA"' in open(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "orc_correct.hpp"), "rb").read()
