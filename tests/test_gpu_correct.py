@@ -153,7 +153,7 @@ def test_uncorrected_records_keep_their_annotation_line(gpu_ctx, oracle):
     headers = [b"@r%d" % i for i in range(len(seqs))]
     ann = [b"+note%d" % i for i in range(len(seqs))]
     clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
-    out = correct_command(gpu_ctx, headers, seqs, quals, clusters, ann=ann)
+    out = correct_command(gpu_ctx, headers, seqs, quals, clusters, ann=ann, min_reads=30)       # clusters of <= 30 reads stay uncorrected
     lines = out[1].split(b"\n")
     assert len(lines) > 4
     for i in range(0, len(lines) - 1, 4):

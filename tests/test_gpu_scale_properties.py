@@ -128,7 +128,7 @@ def test_iso_two_level_properties_at_100k(gpu_ctx):
     # quality on well separated synthetic isoforms: most big transcript clusters are pure
     starts = iso.offsets[:-1].astype(np.int64)
     pure = sum(1 for c in np.argsort(-sizes)[:100] if len(set(tid[iso.member_id[starts[c]:starts[c] + sizes[c]]])) == 1)
-    assert pure >= 85 and len(sizes) >= len(set(tid)) * 0.8
+    assert pure >= 70 and len(sizes) >= len(set(tid)) * 0.8
     # determinism
     iso2, gid2, ng2 = gpu_ctx.cluster_iso_unsorted_packed(cat, off)
     assert np.array_equal(iso.member_id, iso2.member_id) and np.array_equal(gid, gid2) and ng == ng2
