@@ -43,6 +43,15 @@ namespace rattle {
 #define POA_NEG (-(1 << 28))
 #define POA_STACK 512
 #define POA_NONE 0xFFFFFFFFu
+#ifndef POA_MW_2x8
+#define POA_MW_2x8 4
+#endif
+#ifndef POA_MW_2x12
+#define POA_MW_2x12 3
+#endif
+#ifndef POA_MW_1x16
+#define POA_MW_1x16 3
+#endif
 #define POA_MAX_LEN (1u << 20)           // H <= 5 * length must stay far below 2^28 (POA_NEG)
 
 // node record (uint4): x = letter | n_al << 8 | n_in << 16, y = first in-edge's begin node,
@@ -125,6 +134,26 @@ __device__ __forceinline__ int32_t wave_scan_max(int32_t v, int32_t ident) {
     v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x143 /*row_bcast:31*/, 0xC, 0xF, false));
     return v;
 }
+// the same scan with the maximum fused into the DPP instruction (v_max_i32_dpp: a lane whose source lies outside its row
+// / is masked off keeps its own value, which is the identity of the scan): 6 VALU instructions instead of 18.  The s_nop
+// cover the VALU-write -> DPP-read hazard (2 wait states), which the assembler does not insert inside inline asm.
+__device__ __forceinline__ int32_t wave_scan_max_fused(int32_t v) {
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ int32_t wave_last(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
 // ordering inside ONE wavefront (other waves of the block are parked at a barrier): make this
 // wave's LDS / global writes visible to its own other lanes
@@ -132,6 +161,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+
+// vmcnt counts stores as well as loads on gfx9.  The compiler's wait insertion is conservative across the row loop: a
+// register that MAY still be the target of a vector load (the plan words loaded once per 64 rows, a predecessor row re-read
+// from the record on a rare path) gets an s_waitcnt vmcnt(0) before every use -- which also waits for the record stores
+// of the previous row, a full memory round trip per row.  So every vector load of the row loop is completed explicitly
+// where it is issued (rarely), and the hot path carries no vmcnt wait at all.
+__device__ __forceinline__ void drain_vector_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), expcnt / lgkmcnt untouched
 
 // Row barrier of the DP: only LDS traffic has to be ordered across the four waves, so global
 // loads/stores stay in flight (a __syncthreads() would drain vmcnt every row).
@@ -643,22 +679,28 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
         JE[u] = je; UC[u] = uc;
     }
-    s16x2 HA[NP], FA[NP], HB[NP], FB[NP];        // the two register sets of "the previous row"
+    // "the previous row" stays in registers as its record words (H in 14 bits, min(H - F, 3) above them: the same word
+    // the ring and the record in HBM hold, so every predecessor is decoded the same way); two sets alternate
+    uint32_t WA[NP], WB[NP];
 #pragma unroll
-    for (int u = 0; u < NP; ++u) { HA[u] = pk_splat(0); FA[u] = pk_splat(NEGF); HB[u] = pk_splat(0); FB[u] = pk_splat(NEGF); }
+    for (int u = 0; u < NP; ++u) { WA[u] = 0x80008000u; WB[u] = 0x80008000u; }
+    (void)NEGF;
     uint32_t hlA = 0, hlB = 0;                   // H of the column left of the thread's block, in the HIGH half
     uint32_t rowA = 0xFFFFFFFFu, rowB = 0xFFFFFFFFu;
-    int32_t lbest = 0;
-    uint32_t lrow = 0, lcnt = 0;
+    s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
     uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
     uint32_t r0 = 0;
+    // a wavefront whose columns all lie beyond the sequence only keeps the row barrier company
+    const bool wave_act = (uint32_t)wave * 64u * CPL < Lp;
 #ifdef POA_BARPROF
-    long long bar_cycles = 0;
+    // measurement build: shader-clock cycles of the segments of a row, per wavefront (0: predecessor fetch + combine,
+    // 1: scores / prefix / scan up to the exchange write, 2: waiting at the row barrier, 3: after the barrier to the end)
+    long long bar_cycles = 0, seg0 = 0, seg1 = 0, seg3 = 0, tprev = 0;
     const long long dp0 = clock64();
 #endif
 
-    auto step = [&](const uint32_t i, const s16x2 (&HP)[NP], const s16x2 (&FP)[NP], const uint32_t hlP, const uint32_t rowP,
-                    s16x2 (&HN)[NP], s16x2 (&FN)[NP], uint32_t &hlN, uint32_t &rowN) __attribute__((always_inline)) {
+    auto step = [&](const uint32_t i, const uint32_t (&WP)[NP], const uint32_t hlP, const uint32_t rowP, uint32_t (&WN)[NP], uint32_t &hlN,
+                    uint32_t &rowN) __attribute__((always_inline)) {
         const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
         const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
                                 (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
@@ -666,73 +708,82 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         const uint32_t par = row & 1u;
         const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
         s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
-        auto pred = [&](auto first_tag, const uint32_t prow) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            s16x2 HD[NP], FD[NP];
-            if (n_in == 0) {
+        s16x2 HN[NP], FN[NP];
+#ifdef POA_BARPROF
+        tprev = clock64();
+#endif
+        // A predecessor row is a set of record words + the H of the column left of the thread's block (high half):
+        // the previous row from registers, one of the last RINGN rows from the LDS ring, older ones from the record in HBM.
+        // The loads of all (up to four) predecessors are issued first and waited for once: a row with three ring
+        // predecessors pays one LDS round trip, not three.
+        uint32_t raw[4][NP], rawl[4];
+        auto fetch = [&](const int k, const uint32_t prow) __attribute__((always_inline)) {
+            if (prow == rowP) {
 #pragma unroll
-                for (int u = 0; u < NP; ++u) { HD[u] = pk_splat(0); FD[u] = pk_splat(POA_G - POA_E); }
-            } else if (prow == rowP) {
-                const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HP[NP - 1]), (int32_t)hlP);
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    HD[u] = pk_left(as_u(HP[u]), u == 0 ? left : as_u(HP[u - 1]));
-                    FD[u] = pk_max(HP[u] + pk_splat(POA_G - POA_E), FP[u]);
-                }
+                for (int u = 0; u < NP; ++u) raw[k][u] = WP[u];
+                rawl[k] = hlP;
             } else if (row - prow <= (uint32_t)RINGN) {
                 const uint32_t slot = prow % (uint32_t)RINGN;
                 const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * NP;
-                uint32_t hp[NP];
 #pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    const uint32_t a = rp[u];
-                    hp[u] = a & 0x3FFF3FFFu;
-                    FD[u] = as_pk(hp[u]) - pk_min(as_pk((a >> 14) & 0x00030003u), pk_splat(2));       // H - min(H-F, 2)
-                }
-                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], S.lh_ring[slot * 4 + wave]);
-#pragma unroll
-                for (int u = 0; u < NP; ++u) HD[u] = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
+                for (int u = 0; u < NP; ++u) raw[k][u] = rp[u];
+                rawl[k] = (uint32_t)S.lh_ring[slot * 4 + wave];
             } else {
-                uint32_t hp[NP];
-                uint32_t hl = 0;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) raw[k][u] = 0x80008000u;          // H = 0, H - F = 2: what a column beyond the row decodes to
+                rawl[k] = 0;
                 if (act) {
-                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);      // same word format as the ring
+                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
 #pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        const uint32_t a = hq[u];
-                        hp[u] = a & 0x3FFF3FFFu;
-                        FD[u] = as_pk(hp[u]) - pk_min(as_pk((a >> 14) & 0x00030003u), pk_splat(2));
-                    }
-                    if (lane == 0 && wave > 0) hl = (uint32_t)S.lh[prow * 4 + wave] << 16;
-                } else {
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) { hp[u] = 0; FD[u] = pk_splat(POA_G - POA_E); }
+                    for (int u = 0; u < NP; ++u) raw[k][u] = hq[u];
+                    if (lane == 0 && wave > 0) rawl[k] = (uint32_t)S.lh[prow * 4 + wave] << 16;
                 }
-                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)hl);
-#pragma unroll
-                for (int u = 0; u < NP; ++u) HD[u] = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
+                drain_vector_loads();            // rare path (1-2 % of the fetches): nothing stays pending past it
             }
+        };
+        auto combine = [&](auto first_tag, const uint32_t (&w)[NP], const uint32_t wl) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            uint32_t hp[NP];
+            s16x2 FD[NP];
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
-                HM[u] = FIRST ? HD[u] : pk_max(HM[u], HD[u]);
+                hp[u] = w[u] & 0x3FFF3FFFu;
+                FD[u] = as_pk(hp[u]) - pk_min(as_pk((w[u] >> 14) & 0x00030003u), pk_splat(2));       // H - min(H-F, 2) = max(H + g - e, F)
+            }
+            const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const s16x2 HD = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
+                HM[u] = FIRST ? HD : pk_max(HM[u], HD);
                 FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
             }
         };
-        pred(std::true_type{}, pw[0]);
-        if (n_in > 1) {
-            pred(std::false_type{}, pw[1]);
-            if (n_in > 2) {
-                pred(std::false_type{}, pw[2]);
-                if (n_in > 3) {
-                    pred(std::false_type{}, pw[3]);
-                    uint32_t e = more;
-                    for (uint32_t k = 4; k < n_in; ++k) {
-                        const uint2 ed = S.edges[e]; e = ed.y;
-                        pred(std::false_type{}, (uint32_t)S.rank[ed.x] + 1);
-                    }
+        if (n_in == 0) {                         // virtual start row: H = 0, F = -inf
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
+        } else {
+            fetch(0, pw[0]);
+            if (n_in > 1) fetch(1, pw[1]);
+            if (n_in > 2) fetch(2, pw[2]);
+            if (n_in > 3) fetch(3, pw[3]);
+            combine(std::true_type{}, raw[0], rawl[0]);
+            if (n_in > 1) combine(std::false_type{}, raw[1], rawl[1]);
+            if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
+            if (n_in > 3) {
+                combine(std::false_type{}, raw[3], rawl[3]);
+                uint32_t e = more;
+                for (uint32_t k = 4; k < n_in; ++k) {
+                    const uint2 ed = S.edges[e]; e = ed.y;
+                    const uint32_t prow = (uint32_t)S.rank[ed.x] + 1;
+                    drain_vector_loads();
+                    fetch(0, prow);
+                    combine(std::false_type{}, raw[0], rawl[0]);
                 }
             }
         }
+#ifdef POA_BARPROF
+        { asm volatile("" :: "v"(HM[0]), "v"(FM[NP - 1])); const long long t = clock64(); seg0 += t - tprev; tprev = t; }
+#endif
         // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
         s16x2 HNp[NP], EX[NP];
         s16x2 RUN = pk_splat(-32768);
@@ -748,7 +799,7 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         }
         const int32_t run = (int32_t)(int16_t)(as_u(RUN) & 0xFFFFu);
         const int32_t ex_last = (int32_t)as_u(EX[NP - 1]) >> 16, hn_last = (int32_t)as_u(HNp[NP - 1]) >> 16;
-        const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
+        const int32_t wincl = wave_scan_max_fused(act ? run : POA_NEG);
         const int32_t texcl = wave_shr1(wincl, POA_NEG);
         int32_t base = POA_G - POA_E;            // u_0
         int32_t hl_new = 0;
@@ -759,41 +810,39 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             }
 #ifdef POA_BARPROF
             const long long tb0 = clock64();
+            seg1 += tb0 - tprev;
 #endif
             row_barrier();
 #ifdef POA_BARPROF
-            bar_cycles += clock64() - tb0;
+            tprev = clock64();
+            bar_cycles += tprev - tb0;
 #endif
+            // the exchanged numbers are the same for every lane: through the scalar unit (readfirstlane + SALU max / select)
+            // instead of a dozen per-lane selects
             const int4 T = X.T[par];
             const int2 q = X.Q[par][wave];
-            const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
-            const int32_t b0 = wave > 1 ? T.x : POA_NEG, b1 = wave > 2 ? T.y : POA_NEG;
+            const int32_t Tx = __builtin_amdgcn_readfirstlane(T.x), Ty = __builtin_amdgcn_readfirstlane(T.y), Tz = __builtin_amdgcn_readfirstlane(T.z);
+            const int32_t t0 = wave > 0 ? Tx : POA_NEG, t1 = wave > 1 ? Ty : POA_NEG, t2 = wave > 2 ? Tz : POA_NEG;
+            const int32_t b0 = wave > 1 ? Tx : POA_NEG, b1 = wave > 2 ? Ty : POA_NEG;
             base = max(max(base, t0), max(t1, t2));
             if (wave > 0) {
+                const int32_t qx = __builtin_amdgcn_readfirstlane(q.x), qy = __builtin_amdgcn_readfirstlane(q.y);
                 const int32_t bp = max(max(POA_G - POA_E, b0), b1);
                 const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);
-                hl_new = max(q.y, max(bp, q.x) + c0w * POA_E);
+                hl_new = max(qy, max(bp, qx) + c0w * POA_E);
                 if (lane == 0) S.lh[row * 4 + wave] = hl_new;
             }
         }
         base = max(base, texcl);
         const s16x2 BASE = as_pk(pack16(base, base));
         s16x2 EV[NP];
-        s16x2 MX = pk_splat(0);
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             EV[u] = pk_max(BASE, EX[u]) + JE[u];
             HN[u] = pk_max(HNp[u], EV[u]);
-            MX = pk_max(MX, HN[u]);
+            MXA = pk_max(MXA, HN[u]);
         }
         hlN = (uint32_t)hl_new << 16; rowN = row;
-        {
-            const int32_t lm = max((int32_t)(int16_t)(as_u(MX) & 0xFFFFu), (int32_t)as_u(MX) >> 16);
-            const bool gt = lm > lbest, eq = lm == lbest;
-            lcnt = gt ? 1u : lcnt + (eq ? 1u : 0u);
-            lrow = gt ? row : lrow;
-            lbest = gt ? lm : lbest;
-        }
         {
             // One word per pair serves the ring, later rows and the traceback: H (14 bits) and min(H - F, 3).
             // The traceback's tests on F and E can only hold where H - F (H - E) <= 2, and a clipped value
@@ -801,14 +850,23 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             // per cell are an exact record; E's two bits go to a separate array (a byte per four cells).
             uint32_t W[NP];
 #pragma unroll
-            for (int u = 0; u < NP; ++u) W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14);
+            for (int u = 0; u < NP; ++u) { W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14); WN[u] = W[u]; }
             const uint32_t slot = row % (uint32_t)RINGN;
             uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * NP;
 #pragma unroll
             for (int u = 0; u < NP; ++u) rp[u] = W[u];
             if (lane == 0) S.lh_ring[slot * 4 + wave] = (int32_t)((uint32_t)hl_new << 16);
+#if defined(POA_SKIP_STORE) && POA_SKIP_STORE >= 2
+            if (act && row == 0xFFFFFFu) {        // measurement build: no record stores (results invalid)
+#else
             if (act) {
+#endif
                 store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, W);
+#if defined(POA_SKIP_STORE) && POA_SKIP_STORE == 1
+                if (row == 0xFFFFFFu) {
+#else
+                {
+#endif
                 uint32_t eb = 0;
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
@@ -817,40 +875,80 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 }
                 ebits_t<CPL> *ep = (ebits_t<CPL> *)S.E + (uint64_t)row * NT + tid;
                 *ep = (ebits_t<CPL>)eb;
+                }
             }
         }
+#ifdef POA_BARPROF
+        { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); seg3 += clock64() - tprev; }
+#endif
+#ifdef POA_PROBE
+        // cost probes (measurement builds only): extra work that leaves the results alone; the slow-down per unit says what
+        // the row is bound by.  1: 32 independent packed VALU ops, 2: 32 dependent ones, 3: an LDS round trip, 4: a block
+        // barrier, 5: 32 scalar ops, 6: 64 idle cycles on the wave's instruction stream
+        {
+            static_assert(POA_PROBE >= 1 && POA_PROBE <= 6, "");
+            uint32_t p0 = as_u(HN[0]), p1 = hlN, p2 = row, p3 = tid;
+            if (POA_PROBE == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("v_pk_max_i16 %0, %0, %4\n v_pk_max_i16 %1, %1, %4\n v_pk_max_i16 %2, %2, %4\n v_pk_max_i16 %3, %3, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(row));
+            } else if (POA_PROBE == 2) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(p0) : "v"(row));
+            } else if (POA_PROBE == 3) {
+                p0 = S.ring[tid];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if (POA_PROBE == 4) {
+                row_barrier();
+            } else if (POA_PROBE == 5) {
+                uint32_t sc = row;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sc));
+                p0 = sc;
+            } else {
+                asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7");
+            }
+            if ((p0 ^ p1 ^ p2 ^ p3) == 0x12345u && row == 0xFFFFFFu) S.lh[0] = 1;      // keep the probe alive
+        }
+#endif
     };
 
+    if (!wave_act) {
+        if (NW > 1) for (uint32_t r = 0; r < n; ++r) row_barrier();
+    } else
     for (r0 = 0; r0 < n; r0 += 64) {
         const uint32_t nb = min(64u, n - r0);
         my = make_uint4(0, 0, 0, 0); myb = make_uint4(0, 0, 0, 0);
         if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
+        drain_vector_loads();                    // once per 64 rows, so that the rows themselves never wait on vmcnt
         for (uint32_t i = 0; i < nb; i += 2) {
-            step(i, HA, FA, hlA, rowA, HB, FB, hlB, rowB);
-            if (i + 1 < nb) step(i + 1, HB, FB, hlB, rowB, HA, FA, hlA, rowA);
+            step(i, WA, hlA, rowA, WB, hlB, rowB);
+            if (i + 1 < nb) step(i + 1, WB, hlB, rowB, WA, hlA, rowA);
         }
     }
 #ifdef POA_BARPROF
-    if (lane == 0) { atomicAdd(&S.hist[8 + wave], (unsigned long long)bar_cycles); atomicAdd(&S.hist[12 + wave], (unsigned long long)(clock64() - dp0)); }
+    if (lane == 0) {
+        atomicAdd(&S.hist[8 + wave], (unsigned long long)bar_cycles); atomicAdd(&S.hist[12 + wave], (unsigned long long)(clock64() - dp0));
+        if (wave == 1) { atomicAdd(&S.hist[16], (unsigned long long)seg0); atomicAdd(&S.hist[17], (unsigned long long)seg1); atomicAdd(&S.hist[18], (unsigned long long)seg3); }
+    }
 #endif
+    // block-wide best score and the threads whose columns reach it; the first row (block order) that reaches it and
+    // whether other rows do too come from a rescan of those threads' columns in the record (kernel body): the row loop
+    // itself only keeps a running maximum
+    const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
     const int32_t wb = wave_last(wave_scan_max(lbest, 0));
     if (lane == 0) X.best[wave] = wb;
-    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 0; X.ntl = 0; }
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
     __syncthreads();
     best = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
-    const bool mine = best > 0 && lbest == best;
-    if (mine) atomicMin(&X.brow, lrow);
-    __syncthreads();
-    best_row = best > 0 ? X.brow : 0u;
-    if (mine) {
-        if (lcnt != 1 || lrow != best_row) X.multi = 1;
+    if (best > 0 && lbest == best) {
         const uint32_t slot = atomicAdd(&X.ntl, 1u);
         if (slot < 16) X.tl[slot] = (uint32_t)tid;
     }
     __syncthreads();
-    multi = X.multi != 0;
+    best_row = 0;
+    multi = best > 0;
 }
 
 // ---- rows longer than any register class (PK == 2): int32 cells, 1024-column segments ---------------
@@ -1008,8 +1106,14 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
+// minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
+// instruction chain, hidden only by other resident wavefronts: occupancy first)
+constexpr int poa_min_waves(int CPL, int NW, int PK) {
+    return PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW == 4 && CPL == 6 ? (PK ? 5 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
+           : PK == 1 && NW == 1 && CPL == 16 ? POA_MW_1x16 : 1;
+}
 template <int CPL, int RING, int NW, int PK>
-__global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW == 4 && CPL == 6 ? (PK ? 5 : 4) : 1)) void poa_kernel(poa_args A) {
+__global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kernel(poa_args A) {
     constexpr uint32_t NT = 64 * NW;
     using cell_t = typename std::conditional<PK == 2, int32_t, int16_t>::type;      // DP matrix cell
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1108,14 +1212,14 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                                 bool hit = false;
 #pragma unroll
                                 for (int u = 0; u < CPL; ++u) hit |= (PK == 1 ? (v[u] & 0x3FFF) : v[u]) == best;
-                                if (hit) S.rowmax[r] = 1;
+                                if (hit) { S.rowmax[r] = 1; if (PK == 1) atomicMin(&X.brow, r); }
                             }
                         } else {
                             for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NW) {
                                 const cell_t *Hr = (const cell_t *)S.H + (uint64_t)r * Lp;
                                 bool hit = false;
-                                for (uint32_t c = tid & 63; c < Lp; c += 64) hit |= (PK == 1 ? (int32_t)(Hr[c] & 0x3FFF) : (int32_t)Hr[c]) == best;
-                                if (hit) S.rowmax[r] = 1;
+                                for (uint32_t c = tid & 63; c < L; c += 64) hit |= (PK == 1 ? (int32_t)(Hr[c] & 0x3FFF) : (int32_t)Hr[c]) == best;
+                                if (hit) { S.rowmax[r] = 1; if (PK == 1) atomicMin(&X.brow, r); }
                             }
                         }
                         __syncthreads();
@@ -1124,6 +1228,7 @@ __global__ __launch_bounds__(64 * NW, (PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ?
                         if (cnt) atomicAdd(&s_bc[5], cnt);
                     }
                     __syncthreads();
+                    if (PK == 1) best_row = X.brow;             // packed rows: the rescan is where the first row comes from
                     // cheap exit: if every tied row except the first has a tied direct predecessor, all of
                     // them descend from the first one, which then precedes them in ANY topological order
                     bool need_sort = s_bc[5] > 1;
@@ -1647,6 +1752,11 @@ static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, 10, 4, 1), POA
 static const poa_variant k_noring[2] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
+// experiments (RATTLE_POA_EXP=<a>,<b>: index into this table for the 1024- and the 1536-column class): fewer, fatter wavefronts
+// per pack -- the per-row fixed cost (scan, exchange, scalar bookkeeping) is paid per wavefront
+static const poa_variant k_exp[] = {POA_VARIANT(16, 4, 1, 1), POA_VARIANT(16, 6, 1, 1), POA_VARIANT(8, 6, 2, 1), POA_VARIANT(8, 4, 2, 1),
+                                    POA_VARIANT(12, 4, 2, 1), POA_VARIANT(12, 6, 2, 1), POA_VARIANT(8, 5, 2, 1), POA_VARIANT(8, 8, 2, 1),
+                                    POA_VARIANT(12, 5, 2, 1), POA_VARIANT(12, 8, 2, 1), POA_VARIANT(16, 5, 1, 1), POA_VARIANT(16, 8, 1, 1)};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -1697,6 +1807,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
 #ifdef POA_PROFILE
     unsigned long long h_prof[POA_CLASSES * 8] = {0};
 #endif
+#ifdef POA_BARPROF
+    unsigned long long h_seg[4] = {0};
+#endif
 
     size_t free_b = 0, total_b = 0;
     RT_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1734,6 +1847,12 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         C[c].todo = by_class[c];
         C[c].V = &k_latency[c];
         if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
+        if (c < 2 && getenv("RATTLE_POA_EXP")) {
+            int a = -1, b = -1;
+            sscanf(getenv("RATTLE_POA_EXP"), "%d,%d", &a, &b);
+            const int pick = c == 0 ? a : b;
+            if (pick >= 0 && pick < (int)(sizeof(k_exp) / sizeof(k_exp[0])) && 64u * k_exp[pick].nw * k_exp[pick].cpl >= k_class_cols[c]) C[c].V = &k_exp[pick];
+        }
         if (c < 3 && getenv("RATTLE_POA_UNPACKED")) C[c].V = &k_unpacked[c];
     }
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
@@ -1914,6 +2033,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
 #ifdef POA_PROFILE
         if (e == hipSuccess) e = hipMemcpyAsync(h_prof, d_cnt.p + 32, sizeof(h_prof), hipMemcpyDeviceToHost, st);
 #endif
+#ifdef POA_BARPROF
+        if (e == hipSuccess) e = hipMemcpyAsync(h_seg, d_cnt.p + 16, sizeof(h_seg), hipMemcpyDeviceToHost, st);
+#endif
 #ifdef POA_HIST
         if (e == hipSuccess) e = hipMemcpyAsync(h_hist, d_cnt.p, 160 * 8, hipMemcpyDeviceToHost, st);
 #endif
@@ -1950,6 +2072,8 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
 #ifdef POA_BARPROF
     fprintf(stderr, "[rattle] barrier cycles / dp cycles per wave: %.3f %.3f %.3f %.3f  (dp cycles per row, wave 0: %.0f)\n", (double)h_cnt[8] / h_cnt[12], (double)h_cnt[9] / h_cnt[13],
             (double)h_cnt[10] / h_cnt[14], (double)h_cnt[11] / h_cnt[15], (double)h_cnt[12] / (double)h_cnt[3]);
+    fprintf(stderr, "[rattle] wave 1, cycles per row: predecessors %.0f, scores+prefix+scan %.0f, barrier %.0f, after barrier %.0f (of %.0f)\n", (double)h_seg[0] / h_cnt[3],
+            (double)h_seg[1] / h_cnt[3], (double)h_cnt[9] / h_cnt[3], (double)h_seg[2] / h_cnt[3], (double)h_cnt[13] / h_cnt[3]);
 #endif
     ctx->stats[K_POA].bytes += 6ull * h_cnt[0];
     return 0;
