@@ -59,7 +59,7 @@ namespace rattle {
 // aligned record (uint4): aligned_nodes_ids in insertion order.
 // edge (uint2): x = begin node, y = next edge.
 // plan records, one pair per DP row: plan = {node info, node id, edge index of the 5th in-edge
-// (or none), 0}; planb = rows of the first four predecessors.
+// (or none), edge index of the 9th in-edge (or none)}; planb / planc = rows of predecessors 1-4 / 5-8.
 
 struct poa_args {
     const uint8_t *seq;
@@ -70,7 +70,7 @@ struct poa_args {
     uint32_t *queue_head;
     uint8_t *arena;                // n_slots * slot_stride bytes
     uint64_t slot_stride;
-    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_order2, o_srank, o_rowmax, o_lh, o_nn, o_plan, o_planb, o_H, o_F, o_E, o_aln, o_ainfo, o_spill;
+    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_order2, o_srank, o_rowmax, o_lh, o_nn, o_plan, o_planb, o_planc, o_H, o_F, o_E, o_aln, o_ainfo, o_spill;
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
@@ -91,7 +91,7 @@ struct poa_args {
 enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_ERR_ALN = 4, POA_ERR_SPILL = 5, POA_ERR_GRAPH = 6 };
 
 struct poa_ws {                    // per-block workspace: global pointers + LDS + wave-uniform state
-    uint4 *nrec, *nal, *plan, *planb;
+    uint4 *nrec, *nal, *plan, *planb, *planc;
     uint2 *edges;
     int32_t *rank;                         // node -> DP row - 1 (block order), MSA column in the final pass
     uint32_t *order, *order2;              // DP row - 1 -> node (double buffer for the incremental merge)
@@ -490,6 +490,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
 #pragma unroll
                     for (int t = 0; t < CPL; ++t) { hp[t] = 0; fd[t] = POA_G - POA_E; }
                 }
+                drain_vector_loads();            // rare path: leave no vector load pending for the hot path to wait on (see drain_vector_loads)
                 const int32_t hleft = wave_shr1(hp[CPL - 1], hl);
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) hd[t] = t == 0 ? hleft : hp[t - 1];
@@ -510,7 +511,9 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
                     uint32_t e = more;
                     for (uint32_t k = 4; k < n_in; ++k) {
                         const uint2 ed = S.edges[e]; e = ed.y;
-                        pred(std::false_type{}, (uint32_t)S.rank[ed.x] + 1);
+                        const uint32_t prow = (uint32_t)S.rank[ed.x] + 1;
+                        drain_vector_loads();
+                        pred(std::false_type{}, prow);
                     }
                 }
             }
@@ -615,6 +618,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
         const uint32_t nb = min(64u, n - r0);
         my = make_uint4(0, 0, 0, 0); myb = make_uint4(0, 0, 0, 0);
         if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
+        drain_vector_loads();
         for (uint32_t i = 0; i < nb; i += 2) {
             step(i, hA, fA, hlA, rowA, hB, fB, hlB, rowB);
             if (i + 1 < nb) step(i + 1, hB, fB, hlB, rowB, hA, fA, hlA, rowA);
@@ -688,7 +692,7 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     uint32_t hlA = 0, hlB = 0;                   // H of the column left of the thread's block, in the HIGH half
     uint32_t rowA = 0xFFFFFFFFu, rowB = 0xFFFFFFFFu;
     s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
-    uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0);
+    uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0), myc = make_uint4(0, 0, 0, 0);
     uint32_t r0 = 0;
     // a wavefront whose columns all lie beyond the sequence only keeps the row barrier company
     const bool wave_act = (uint32_t)wave * 64u * CPL < Lp;
@@ -701,7 +705,7 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 
     auto step = [&](const uint32_t i, const uint32_t (&WP)[NP], const uint32_t hlP, const uint32_t rowP, uint32_t (&WN)[NP], uint32_t &hlN,
                     uint32_t &rowN) __attribute__((always_inline)) {
-        const uint32_t info = __builtin_amdgcn_readlane(my.x, i), more = __builtin_amdgcn_readlane(my.z, i);
+        const uint32_t info = __builtin_amdgcn_readlane(my.x, i);
         const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
                                 (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
         const uint32_t row = r0 + i + 1;
@@ -771,13 +775,29 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
             if (n_in > 3) {
                 combine(std::false_type{}, raw[3], rawl[3]);
-                uint32_t e = more;
-                for (uint32_t k = 4; k < n_in; ++k) {
-                    const uint2 ed = S.edges[e]; e = ed.y;
-                    const uint32_t prow = (uint32_t)S.rank[ed.x] + 1;
-                    drain_vector_loads();
-                    fetch(0, prow);
+                if (n_in > 4) {
+                    // predecessors 5-8 also come from the plan (backbone nodes of a 200-read graph collect that many in-edges);
+                    // only beyond eight is the in-edge list walked in memory
+                    const uint32_t pc[4] = {(uint32_t)__builtin_amdgcn_readlane(myc.x, i), (uint32_t)__builtin_amdgcn_readlane(myc.y, i),
+                                            (uint32_t)__builtin_amdgcn_readlane(myc.z, i), (uint32_t)__builtin_amdgcn_readlane(myc.w, i)};
+                    fetch(0, pc[0]);
+                    if (n_in > 5) fetch(1, pc[1]);
+                    if (n_in > 6) fetch(2, pc[2]);
+                    if (n_in > 7) fetch(3, pc[3]);
                     combine(std::false_type{}, raw[0], rawl[0]);
+                    if (n_in > 5) combine(std::false_type{}, raw[1], rawl[1]);
+                    if (n_in > 6) combine(std::false_type{}, raw[2], rawl[2]);
+                    if (n_in > 7) combine(std::false_type{}, raw[3], rawl[3]);
+                    if (n_in > 8) {
+                        uint32_t e = __builtin_amdgcn_readlane(my.w, i);
+                        for (uint32_t k = 8; k < n_in; ++k) {
+                            const uint2 ed = S.edges[e]; e = ed.y;
+                            const uint32_t prow = (uint32_t)S.rank[ed.x] + 1;
+                            drain_vector_loads();
+                            fetch(0, prow);
+                            combine(std::false_type{}, raw[0], rawl[0]);
+                        }
+                    }
                 }
             }
         }
@@ -918,7 +938,7 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     for (r0 = 0; r0 < n; r0 += 64) {
         const uint32_t nb = min(64u, n - r0);
         my = make_uint4(0, 0, 0, 0); myb = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; }
+        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; myc = S.planc[r0 + lane]; }
         drain_vector_loads();                    // once per 64 rows, so that the rows themselves never wait on vmcnt
         for (uint32_t i = 0; i < nb; i += 2) {
             step(i, WA, hlA, rowA, WB, hlB, rowB);
@@ -1128,7 +1148,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         uint8_t *base = A.arena + (uint64_t)blockIdx.x * A.slot_stride;
         S.nrec = (uint4 *)(base + A.o_nrec); S.nal = (uint4 *)(base + A.o_nal); S.edges = (uint2 *)(base + A.o_edges);
         S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.order2 = (uint32_t *)(base + A.o_order2);
-        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb);
+        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb); S.planc = (uint4 *)(base + A.o_planc);
         S.H = (int16_t *)(base + A.o_H); S.F = (int16_t *)(base + A.o_F); S.E = (int16_t *)(base + A.o_E);
         S.aln = (int32_t *)(base + A.o_aln); S.ainfo = (uint4 *)(base + A.o_ainfo); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = (A.node_cap + 31) / 32;
@@ -1171,15 +1191,18 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     const uint32_t v = S.order[r];
                     const uint4 rec = S.nrec[v];
                     const uint32_t n_in = rd_nin(rec.x);
-                    uint4 pr = make_uint4(0, 0, 0, 0);
-                    uint32_t e = rec.z;
-                    for (uint32_t k = 0; k < n_in && k < 4; ++k) {
+                    uint4 pr = make_uint4(0, 0, 0, 0), pr2 = make_uint4(0, 0, 0, 0);
+                    uint32_t e = rec.z, e5 = POA_NONE;
+                    for (uint32_t k = 0; k < n_in && k < 8; ++k) {
                         uint32_t b;
+                        if (k == 4) e5 = e;
                         if (k == 0) b = rec.y; else { const uint2 ed = S.edges[e]; e = ed.y; b = ed.x; }
-                        u4_set(pr, k, (uint32_t)S.rank[b] + 1);
+                        if (k < 4) u4_set(pr, k, (uint32_t)S.rank[b] + 1); else u4_set(pr2, k - 4, (uint32_t)S.rank[b] + 1);
                     }
-                    S.plan[r] = make_uint4(rec.x, v, e, 0);
+                    if (n_in <= 4) e5 = e;
+                    S.plan[r] = make_uint4(rec.x, v, e5, e);        // .z: 5th in-edge (general code paths), .w: 9th (packed rows)
                     S.planb[r] = pr;
+                    if (PK == 1) S.planc[r] = pr2;
                 }
                 if (PK != 2) for (uint32_t t = tid; t < Lp; t += NT) S.sq[t] = t < L ? s[t] : 0;       // long rows read the sequence in place
                 __syncthreads();
@@ -1877,7 +1900,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
         A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
         A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
-        A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16);
+        A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16);
         const uint64_t cell_bytes = long_rows ? 4 : 2;
         if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
             const uint64_t eb = cpl == 4 ? 1 : cpl <= 8 ? 2 : 4;
