@@ -109,6 +109,7 @@ struct poa_ws {                    // per-block workspace: global pointers + LDS
     int32_t *lh_ring;                      // LDS: left-column H of the last RING rows per wave
     uint8_t *sq;                           // LDS copy of the sequence, 16-byte aligned
     uint32_t n_nodes, n_edges, sp, spilled, err;
+    uint32_t plain;                        // the pack's letters so far are all in {A,C,G,T} or all in {A,C,G,U}: scores by table look-up
 };
 
 __device__ __forceinline__ bool bit_get(const uint32_t *b, uint32_t i) { return (b[i >> 5] >> (i & 31)) & 1u; }
@@ -675,6 +676,19 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 #pragma unroll
         for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
     }
+    // Match scores by table look-up (v_perm_b32) when the pack's alphabet allows it: (c >> 1) & 3 maps A, C, T/U, G to 0, 1, 2, 3,
+    // so a row's letter gives an 8-byte table {5 or -4 as int16 halves} and a per-thread selector word per column pair picks
+    // the two scores in ONE instruction (against two compares, two selects and a pack).  Columns beyond the sequence get -1.
+    // T and U share an index: a pack that mixes them (or holds any other byte) takes the compare path (S.plain == 0).
+    uint32_t SEL[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
+        const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
+        const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
+        SEL[u] = sa | (sb << 16);
+    }
+    const bool plain = S.plain != 0;
     s16x2 JE[NP], UC[NP];                        // per column: j*e and g - (j+1)*e
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
@@ -740,7 +754,8 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                     const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
 #pragma unroll
                     for (int u = 0; u < NP; ++u) raw[k][u] = hq[u];
-                    if (lane == 0 && wave > 0) rawl[k] = (uint32_t)S.lh[prow * 4 + wave] << 16;
+                    // H of the column left of the wavefront's first column: the last cell of the previous wavefront's part of the row
+                    if (lane == 0 && wave > 0) rawl[k] = ((uint32_t)((const uint16_t *)S.H)[(uint64_t)prow * Lp + c0 - 1] & 0x3FFFu) << 16;
                 }
                 drain_vector_loads();            // rare path (1-2 % of the fetches): nothing stays pending past it
             }
@@ -805,14 +820,25 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         { asm volatile("" :: "v"(HM[0]), "v"(FM[NP - 1])); const long long t = clock64(); seg0 += t - tprev; tprev = t; }
 #endif
         // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
-        s16x2 HNp[NP], EX[NP];
+        s16x2 HNp[NP], EX[NP], SC[NP];
         s16x2 RUN = pk_splat(-32768);
+        if (plain) {
+            const uint32_t li = (letter >> 1) & 3u;
+            const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));      // low / high bytes of {-4, -4, -4, -4} with 5 at li
+#pragma unroll
+            for (int u = 0; u < NP; ++u) SC[u] = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                SC[u] = as_pk(pack16(s0, s1));
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-            const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
             FN[u] = FM[u] + pk_splat(POA_E);
-            HNp[u] = pk_max(pk_max(HM[u] + as_pk(pack16(s0, s1)), FN[u]), pk_splat(0));
+            HNp[u] = pk_max(pk_max(HM[u] + SC[u], FN[u]), pk_splat(0));
             const uint32_t uu = as_u(HNp[u] + UC[u]);
             EX[u] = pk_max(RUN, as_pk((uu << 16) | 0x8000u));              // (run, max(run, u_a))
             RUN = pk_max(RUN, pk_max(as_pk(uu), as_pk(__builtin_amdgcn_alignbit(uu, uu, 16))));
@@ -850,7 +876,6 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 const int32_t bp = max(max(POA_G - POA_E, b0), b1);
                 const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);
                 hl_new = max(qy, max(bp, qx) + c0w * POA_E);
-                if (lane == 0) S.lh[row * 4 + wave] = hl_new;
             }
         }
         base = max(base, texcl);
@@ -1138,6 +1163,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
     using cell_t = typename std::conditional<PK == 2, int32_t, int16_t>::type;      // DP matrix cell
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
+    __shared__ uint32_t s_alpha;              // letters seen in the pack so far: bit 0 T, bit 1 U, bit 2 anything but A, C, G, T, U
     __shared__ uint32_t s_bc[8];
     __shared__ uint32_t s_tied[8];
     __shared__ dp_xchg X;
@@ -1168,6 +1194,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         const uint32_t pk = A.queue[qi];
         const uint32_t q0 = A.pack_first[pk], q1 = A.pack_first[pk + 1];
         S.n_nodes = 0; S.n_edges = 0; S.err = 0; S.sp = 0; S.spilled = 0;
+        if (tid == 0) s_alpha = 0;
         unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0, t_tie = 0, t_merge = 0;
         (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add; (void)t_tie; (void)t_merge;
         const unsigned long long t_pack0 = PT_NOW();
@@ -1179,6 +1206,18 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
             const uint8_t *s = A.seq + so;
             uint32_t *path = A.out_col + so;
             if (L == 0) continue;                                   // Graph::add_alignment ignores an empty sequence
+            if (PK == 1) {
+                // alphabet of the pack (this sequence included): decides whether the packed rows may take the score table
+                uint32_t fl = 0;
+                for (uint32_t t = tid; t < L; t += NT) {
+                    const uint8_t c = s[t];
+                    fl |= c == 'T' ? 1u : c == 'U' ? 2u : (c == 'A' || c == 'C' || c == 'G') ? 0u : 4u;
+                }
+                __syncthreads();
+                if (fl) atomicOr(&s_alpha, fl);
+                __syncthreads();
+                S.plain = (s_alpha & 4u) == 0 && (s_alpha & 3u) != 3u;
+            }
             uint32_t n_aln = 0;
             if (S.n_nodes > 0) {
                 const uint32_t n = S.n_nodes;
