@@ -892,7 +892,7 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             // One word per pair serves the ring, later rows and the traceback: H (14 bits) and min(H - F, 3).
             // The traceback's tests on F and E can only hold where H - F (H - E) <= 2, and a clipped value
             // H - 3 can never satisfy them (H of the cell above / left is at most 8 higher), so two bits
-            // per cell are an exact record; E's two bits go to a separate array (a byte per four cells).
+            // per cell are an exact record of F.  E is not recorded at all: the traceback rebuilds it from the row (Eat).
             uint32_t W[NP];
 #pragma unroll
             for (int u = 0; u < NP; ++u) { W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14); WN[u] = W[u]; }
@@ -901,27 +901,7 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 #pragma unroll
             for (int u = 0; u < NP; ++u) rp[u] = W[u];
             if (lane == 0) S.lh_ring[slot * 4 + wave] = (int32_t)((uint32_t)hl_new << 16);
-#if defined(POA_SKIP_STORE) && POA_SKIP_STORE >= 2
-            if (act && row == 0xFFFFFFu) {        // measurement build: no record stores (results invalid)
-#else
-            if (act) {
-#endif
-                store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, W);
-#if defined(POA_SKIP_STORE) && POA_SKIP_STORE == 1
-                if (row == 0xFFFFFFu) {
-#else
-                {
-#endif
-                uint32_t eb = 0;
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    const uint32_t d = as_u(pk_min(HN[u] - EV[u], pk_splat(3)));
-                    eb |= ((d | (d >> 14)) & 0xFu) << (4 * u);
-                }
-                ebits_t<CPL> *ep = (ebits_t<CPL> *)S.E + (uint64_t)row * NT + tid;
-                *ep = (ebits_t<CPL>)eb;
-                }
-            }
+            if (act) store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, W);
         }
 #ifdef POA_BARPROF
         { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); seg3 += clock64() - tprev; }
@@ -1446,9 +1426,16 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         auto Eat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return POA_NEG;
                             if (PK == 1) {
-                                const uint32_t t = (c - 1) / CPL, k = (c - 1) % CPL;
-                                const uint32_t bits = ((const ebits_t<CPL> *)S.E)[(uint64_t)r * NT + t];
-                                return ((int32_t)H[(uint64_t)r * Lp + c - 1] & 0x3FFF) - (int32_t)((bits >> (2 * k)) & 3u);
+                                // The packed rows keep no E record: E[r][c] = max over k < c of H[r][k] + g + (c-1-k) e (H[r][0] = 0) is
+                                // rebuilt from the row's H cells by the whole wavefront when the traceback asks for it -- only at
+                                // horizontal moves, a few dozen times per alignment, against a store per thread and row in the DP.
+                                int32_t m = POA_NEG;
+                                const uint16_t *Hr = (const uint16_t *)S.H + (uint64_t)r * Lp;
+                                for (uint32_t k = lane; k < c; k += 64) {
+                                    const int32_t h = k == 0 ? 0 : (int32_t)(Hr[k - 1] & 0x3FFFu);
+                                    m = max(m, h - (int32_t)k * POA_E);
+                                }
+                                return wave_last(wave_scan_max(m, POA_NEG)) + POA_G + ((int32_t)c - 1) * POA_E;
                             }
                             return (int32_t)H[(uint64_t)r * Lp + c - 1] - (int32_t)((nib(r, c) >> 2) & 3u);
                         };
@@ -1942,8 +1929,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16);
         const uint64_t cell_bytes = long_rows ? 4 : 2;
         if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
-            const uint64_t eb = cpl == 4 ? 1 : cpl <= 8 ? 2 : 4;
-            A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * eb);
+            A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(0);      // E is rebuilt on demand by the traceback
         } else if (P.V->pk == 0) {         // H int16 plus a nibble per column (min(H-F,3), min(H-E,3))
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * ((cpl + 7) / 8) * 4);
         } else {                           // segmented int32 rows: H int32 plus a nibble per column
