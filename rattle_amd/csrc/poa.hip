@@ -2037,7 +2037,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         {
             ktimer T(ctx, K_POA, 0);
             e = hipEventRecord(ctx->poa_go, st);
-            for (int c = 0; c < POA_CLASSES && e == hipSuccess; ++c) {
+            // longest class first: its persistent blocks take the device, the shorter classes move in as its queue drains,
+            // and the pass ends on short packs (a small tail) instead of on the longest ones
+            for (int c = POA_CLASSES - 1; c >= 0 && e == hipSuccess; --c) {
                 cls_plan &P = C[c];
                 if (!P.n_slots) continue;
                 hipStream_t cs = ctx->poa_st[c];
