@@ -309,7 +309,7 @@ def main():
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
             "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items() if v > 0},
             "phase_reads_per_s": {k: n_reads / (v / a.steps) for k, v in PHASES.items() if v > 0},
-            "cluster_counters": {"bv_pair_tests": int(cl.counters[0]), "full_comparisons": int(cl.counters[1]), "kmer_matches": int(cl.counters[2]),
+            "cluster_counters": {"bv_pair_tests": int(cl.counters[0]), "full_comparisons": int(cl.counters[1]), "kmer_matches": int(cl.counters[2]), "pairs_past_the_count_bound": int(cl.counters[5]),
                                  "seed_rounds": int(cl.counters[3]), "kernel_launches": int(cl.counters[4])},
         }
         if sharded:

@@ -162,67 +162,93 @@ struct driver {
         RT_TRY(ctx->d_pj.reserve(nsurv));
         RT_TRY(ctx->d_ps.reserve(nsurv));
         RT_TRY(ctx->d_res.reserve((size_t)nsurv * 4));
-        RT_TRY(ctx->d_var.reserve(nsurv));
         RT_TRY(ctx->h_surv.reserve((size_t)nsurv * 2));
         RT_TRY(ctx->h_res.reserve((size_t)nsurv * 4));
-        RT_TRY(ctx->h_var.reserve(nsurv));
         hipLaunchKernelGGL(expand_pairs_kernel, dim3((nsurv + 255) / 256), dim3(256), 0, st, ctx->d_surv.p, nsurv,
                            ctx->d_seed.p, ctx->d_cand.p, ctx->d_pi.p, ctx->d_pj.p, ctx->d_ps.p);
         RT_HIP(hipMemcpyAsync(ctx->h_surv.p, ctx->d_surv.p, (size_t)nsurv * 8, hipMemcpyDeviceToHost, st));
-        RT_TRY(launch_pair_score(ctx, nsurv));
+        // ---- pass 1: |common| of every surviving pair.  bases <= k * |LIS| <= k * |common| (similarity.cpp:52-85), so a pair
+        // with double(k * |common|) / min_len < t_s cannot pass cluster.cpp:23-27 whatever its chain looks like: exact
+        // rejection without the patience search.  In the low-threshold merge passes that is nearly every pair.
+        RT_TRY(launch_pair_count(ctx, nsurv));
         counters[4] += 2;
-        RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 16, hipMemcpyDeviceToHost, st));
-        RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)nsurv * 8, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 4, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
-
-        // pairs whose match list did not fit LDS: rerun through the global-scratch variant
-        std::vector<uint32_t> big;
-        uint32_t big_m = 0;
-        for (uint32_t p = 0; p < nsurv; ++p)
-            if (ctx->h_res.p[4 * (size_t)p] == INT32_MIN) {
-                big.push_back(p);
-                big_m = std::max(big_m, (uint32_t)ctx->h_res.p[4 * (size_t)p + 3]);
-            }
-        if (!big.empty()) {
-            RT_TRY(launch_pair_score_oversize(ctx, big, big_m));
-            counters[4]++;
-            RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 16, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)nsurv * 8, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipStreamSynchronize(st));
-        }
-
-        // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic
         const double t_s = P->t_s, t_v = P->t_v;
+        const uint32_t kk = (uint32_t)ctx->idx.k;
         uint64_t alg_bytes = 0;
-        // tens of millions of survivors per level-2 round: chunks in parallel, hits concatenated in pair order
+        // tens of millions of survivors per level-2 round: chunks in parallel, results concatenated in pair order
         const uint32_t chunk = 1u << 16;
         const uint32_t n_chunks = (nsurv + chunk - 1) / chunk;
-        std::vector<std::vector<hit_t>> part(n_chunks);
+        std::vector<std::vector<uint32_t>> part(n_chunks);
         std::vector<uint64_t> part_matches(n_chunks, 0), part_bytes(n_chunks, 0);
         parallel_for(n_chunks, n_chunks > 1 ? 0 : 1, [&](size_t ch) {
             uint64_t mt = 0, ab = 0;
             const uint32_t p1 = std::min<uint32_t>(nsurv, (uint32_t)(ch + 1) * chunk);
             for (uint32_t p = (uint32_t)ch * chunk; p < p1; ++p) {
-                uint32_t a = ctx->h_surv.p[2 * (size_t)p], c = ctx->h_surv.p[2 * (size_t)p + 1];
-                uint32_t s = a >> 1;
-                const int32_t *r = ctx->h_res.p + 4 * (size_t)p;
-                mt += (uint64_t)r[3];
-                uint32_t li = rlen(seeds[s]), lj = rlen(cands[c]);
-                ab += 8ull * ((li > (uint32_t)ctx->idx.k ? li - ctx->idx.k : 0) + (lj > (uint32_t)ctx->idx.k ? lj - ctx->idx.k : 0));
-                double mn = (double)std::min<size_t>(li, lj);
-                double score = P->use_hc ? double(r[1]) / mn : double(r[0]) / mn;
-                if (score >= t_s) {
-                    if (ctx->h_var.p[p] < t_v) part[ch].push_back(hit_t{s, c, (uint8_t)(a & 1u)});
-                }
+                const uint32_t a = ctx->h_surv.p[2 * (size_t)p], c = ctx->h_surv.p[2 * (size_t)p + 1];
+                const uint64_t M = (uint32_t)ctx->h_res.p[p];
+                mt += M;
+                const uint32_t li = rlen(seeds[a >> 1]), lj = rlen(cands[c]);
+                ab += 8ull * ((li > kk ? li - kk : 0) + (lj > kk ? lj - kk : 0));
+                const double mn = (double)std::min<size_t>(li, lj);
+                if (double(M * kk) / mn >= t_s) part[ch].push_back(p);
             }
             part_matches[ch] = mt; part_bytes[ch] = ab;
         });
+        std::vector<uint32_t> todo;
         for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-            hits.insert(hits.end(), part[ch].begin(), part[ch].end());
+            todo.insert(todo.end(), part[ch].begin(), part[ch].end());
             counters[2] += part_matches[ch];
             alg_bytes += part_bytes[ch];
         }
         ctx->stats[K_SCORE].bytes += alg_bytes;
+        const uint32_t n2 = (uint32_t)todo.size();
+        counters[5] += n2;
+        if (n2 == 0) return 0;
+        // ---- pass 2: the reference's full comparison for the pairs that can still be accepted
+        {
+            std::vector<uint32_t> pi2(n2), pj2(n2);
+            std::vector<uint8_t> ps2(n2);
+            for (uint32_t q = 0; q < n2; ++q) {
+                const uint32_t a = ctx->h_surv.p[2 * (size_t)todo[q]], c = ctx->h_surv.p[2 * (size_t)todo[q] + 1];
+                pi2[q] = rid(seeds[a >> 1]); pj2[q] = rid(cands[c]); ps2[q] = (uint8_t)(a & 1u);
+            }
+            RT_TRY(ctx->d_var.reserve(n2));
+            RT_TRY(ctx->h_var.reserve(n2));
+            RT_HIP(hipMemcpyAsync(ctx->d_pi.p, pi2.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+            RT_HIP(hipMemcpyAsync(ctx->d_pj.p, pj2.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+            RT_HIP(hipMemcpyAsync(ctx->d_ps.p, ps2.data(), (size_t)n2, hipMemcpyHostToDevice, st));
+            RT_TRY(launch_pair_score(ctx, n2));
+            counters[4]++;
+            RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));             // also: pi2 / pj2 / ps2 may go out of scope
+        }
+        // pairs whose match list did not fit LDS: rerun through the global-scratch variant
+        std::vector<uint32_t> big;
+        uint32_t big_m = 0;
+        for (uint32_t q = 0; q < n2; ++q)
+            if (ctx->h_res.p[4 * (size_t)q] == INT32_MIN) {
+                big.push_back(q);
+                big_m = std::max(big_m, (uint32_t)ctx->h_res.p[4 * (size_t)q + 3]);
+            }
+        if (!big.empty()) {
+            RT_TRY(launch_pair_score_oversize(ctx, big, big_m));
+            counters[4]++;
+            RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+        }
+        // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic
+        for (uint32_t q = 0; q < n2; ++q) {
+            const uint32_t a = ctx->h_surv.p[2 * (size_t)todo[q]], c = ctx->h_surv.p[2 * (size_t)todo[q] + 1];
+            const int32_t *r = ctx->h_res.p + 4 * (size_t)q;
+            const uint32_t li = rlen(seeds[a >> 1]), lj = rlen(cands[c]);
+            const double mn = (double)std::min<size_t>(li, lj);
+            const double score = P->use_hc ? double(r[1]) / mn : double(r[0]) / mn;
+            if (score >= t_s && ctx->h_var.p[q] < t_v) hits.push_back(hit_t{a >> 1, c, (uint8_t)(a & 1u)});
+        }
         return 0;
     }
 

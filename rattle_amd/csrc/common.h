@@ -319,6 +319,8 @@ int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fw
                      uint32_t list_cap);
 // pair_score.hip : pairs in ctx->d_pi/d_pj/d_ps; results in ctx->d_res (4 ints per pair) + ctx->d_var.
 int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs);
+// the same pairs, |common| only (d_res[pair]); see pair_score.hip
+int launch_pair_count(rattle_ctx *ctx, uint32_t n_pairs);
 // poa.hip : device-resident POA over packs (sequences, offsets, column output in HBM)
 int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *h_off, uint32_t n_seqs,
                    const uint32_t *h_pack_first, uint32_t n_packs, uint32_t *d_col, uint32_t *d_width, uint32_t *h_width,

@@ -47,6 +47,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
+// COUNT: stage 1 only, and only the NUMBER of matches |common| is kept (res[pr] = count; no match arrays in LDS, so three
+// times as many pairs are resident per CU).  The greedy driver runs it over every pair that passed the bit-vector filter:
+// a pair can only be accepted if bases / min_len >= t_s (cluster.cpp:23-27) and bases <= k * |LIS| <= k * |common|, so a
+// pair with k * |common| below that bar is rejected exactly without the patience search; the few others go through the
+// full kernel.
+template <bool COUNT>
 __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
@@ -65,7 +71,9 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     uint32_t *s_bh = lds + PS_EXTRA;
     uint32_t cap;
     uint32_t *pos1, *pos2, *m, *tv, *pp;
-    if (A.gscratch) {
+    if (COUNT) {
+        cap = 0; pos1 = pos2 = m = tv = pp = nullptr;
+    } else if (A.gscratch) {
         cap = (uint32_t)A.gstride;
         uint32_t *g = A.gscratch + (uint64_t)slot * 5 * (A.gstride + 2);
         pos1 = g; pos2 = pos1 + cap + 2; m = pos2 + cap + 2; tv = m + cap + 2; pp = tv + cap + 2;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
         }
         uint32_t incl = wave_incl_scan(cnt, lane);
         uint32_t tot = __shfl(incl, 63, 64);
-        if (total + tot <= cap) {
+        if (!COUNT && total + tot <= cap) {
             uint32_t at = total + incl - cnt;
             for (uint32_t t = 0; t < cnt; ++t) { pos1[at + t] = p1; pos2[at + t] = bp_g[lo + t]; }
         }
@@ -144,6 +152,10 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
         }
     }
     if (qn) drain(qn);
+    if (COUNT) {
+        if (lane == 0) A.res[pr] = (int32_t)total;
+        return;
+    }
     int32_t *out = A.res + (uint64_t)pr * 4;
     if (total > cap) {                                  // oversize: host reruns with global scratch
         if (lane == 0) { out[0] = INT32_MIN; out[1] = 0; out[2] = 0; out[3] = (int32_t)total; A.var[pr] = 0.0; }
@@ -230,9 +242,30 @@ int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs) {
     size_t shm = (PS_EXTRA + A.bcap + 5 * (size_t)A.mcap + 8) * 4;
     // algorithmic bytes are accounted by the caller (needs the pair list on the host)
     ktimer T(ctx, K_SCORE, 0);
-    hipLaunchKernelGGL(pair_score_kernel, dim3(n_pairs), dim3(64), shm, ctx->stream, A);
+    hipLaunchKernelGGL(pair_score_kernel<false>, dim3(n_pairs), dim3(64), shm, ctx->stream, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("pair_score launch: ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
+    return 0;
+}
+
+// pairs in ctx->d_pi/d_pj/d_ps; |common| of each pair into ctx->d_res[pair] (one int per pair)
+int launch_pair_count(rattle_ctx *ctx, uint32_t n_pairs) {
+    if (n_pairs == 0) return 0;
+    read_index &X = ctx->idx;
+    ps_args A;
+    A.uh = X.uh.p; A.koff = X.koff.p;
+    A.kh[0] = X.kh[0].p; A.kp[0] = X.kp[0].p; A.kh[1] = X.kh[1].p; A.kp[1] = X.kp[1].p;
+    A.bv[0] = X.bv[0].p; A.bv[1] = X.bv[1].p;
+    A.pi = ctx->d_pi.p; A.pj = ctx->d_pj.p; A.ps = ctx->d_ps.p;
+    A.n_pairs = n_pairs; A.k = X.k;
+    A.bcap = 2048; A.mcap = 0;
+    A.res = ctx->d_res.p; A.var = nullptr;
+    A.gscratch = nullptr; A.gstride = 0; A.remap = nullptr;
+    size_t shm = (PS_EXTRA + A.bcap + 8) * 4;
+    ktimer T(ctx, K_SCORE, 0);
+    hipLaunchKernelGGL(pair_score_kernel<true>, dim3(n_pairs), dim3(64), shm, ctx->stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("pair_count launch: ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
     return 0;
 }
 
@@ -262,7 +295,7 @@ int launch_pair_score_oversize(rattle_ctx *ctx, const std::vector<uint32_t> &slo
         A.res = ctx->d_res.p; A.var = ctx->d_var.p;
         A.gscratch = ctx->d_scratch.p; A.gstride = stride; A.remap = d_remap.p + b;
         ktimer T(ctx, K_SCORE, 0);
-        hipLaunchKernelGGL(pair_score_kernel, dim3(m), dim3(64), (PS_EXTRA + A.bcap + 8) * 4, ctx->stream, A);
+        hipLaunchKernelGGL(pair_score_kernel<false>, dim3(m), dim3(64), (PS_EXTRA + A.bcap + 8) * 4, ctx->stream, A);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error(std::string("pair_score(oversize) launch: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
     }
