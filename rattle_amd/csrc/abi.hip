@@ -217,6 +217,7 @@ int rattle_hip_cluster_subsets(rattle_ctx *c, const rattle_cluster_params *P, co
         return la != lb ? la > lb : a < b;
     });
     const uint32_t n_mine = (uint32_t)order.size();
+    if (n_workers <= 0 && getenv("RATTLE_ISO_WORKERS")) n_workers = atoi(getenv("RATTLE_ISO_WORKERS"));
     const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(n_mine, n_workers > 0 ? (uint32_t)n_workers : 16u));
     std::atomic<uint32_t> next(0);
     std::atomic<int> rc_all(0);
