@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,8 +14,10 @@
 #include <functional>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rattle_hip.h"
@@ -270,6 +273,70 @@ cluster_set_t read_clusters(const std::string &path) {            // current 3-f
     die("\nError: clusters file is not an hps cluster stream\n");
 }
 
+// ---- one job over several GPUs of the node: --devices 0,1,... --------------------------------------------------
+// One host thread per device, each with its own context; every thread makes the same library calls and the library shards
+// the work (candidates of a seed batch, --iso gene clusters, `correct` packs; include/rattle_hip.h).  The exchange is RCCL
+// over xGMI; --host-exchange swaps in an in-process all-gather on host buffers (no RCCL needed; also lets several ranks
+// share one device, which RCCL refuses).
+struct host_exchange {
+    int n = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> send;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+struct rank_user { host_exchange *X; int rank; };
+int host_allgatherv(void *user, const void *send, uint64_t, void *recv, const uint64_t *recv_bytes) {
+    rank_user *u = (rank_user *)user;
+    host_exchange &X = *u->X;
+    X.send[u->rank] = send;
+    X.barrier();                                   // every rank has published its piece
+    uint64_t at = 0;
+    for (int r = 0; r < X.n; ++r) { if (recv_bytes[r]) memcpy((char *)recv + at, X.send[r], recv_bytes[r]); at += recv_bytes[r]; }
+    X.barrier();                                   // every rank has copied: the pieces may be released
+    return 0;
+}
+
+struct device_team {
+    std::vector<int> devs;
+    std::vector<rattle_ctx *> ctx;
+    host_exchange hx;
+    std::vector<rank_user> users;
+    int n() const { return (int)devs.size(); }
+    // fn(rank, ctx) on every rank at once (rank 0 on the calling thread)
+    void run(const std::function<void(int, rattle_ctx *)> &fn) {
+        std::vector<std::thread> th;
+        for (int r = 1; r < n(); ++r) th.emplace_back([&, r] { fn(r, ctx[r]); });
+        fn(0, ctx[0]);
+        for (auto &t : th) t.join();
+    }
+    void open(const args_t &a) {
+        if (a.has("devices")) for (auto &t : split_string(a.str("devices", ""), ',')) devs.push_back(std::stoi(t));
+        else devs.push_back(a.i("device", 0));
+        if (devs.empty()) die("\nError: --devices needs a list of device indices\n");
+        ctx.assign(devs.size(), nullptr);
+        const bool host = a.has("host-exchange");
+        uint8_t id[RATTLE_COMM_ID_BYTES] = {0};
+        if (n() > 1 && !host) chk(rattle_hip_comm_unique_id(id));
+        hx.n = n(); hx.send.assign(devs.size(), nullptr);
+        users.resize(devs.size());
+        for (int r = 0; r < n(); ++r) users[r] = rank_user{&hx, r};
+        run([&](int r, rattle_ctx *) {
+            chk(rattle_hip_ctx_create(devs[r], &ctx[r]));
+            if (n() > 1) chk(host ? rattle_hip_set_exchange(ctx[r], r, n(), host_allgatherv, &users[r]) : rattle_hip_comm_init(ctx[r], r, n(), id));
+        });
+        if (n() > 1) std::cerr << "One job over " << n() << " devices (" << (host ? "host exchange" : "RCCL") << ")" << std::endl;
+    }
+    void close() { for (auto *c : ctx) rattle_hip_ctx_destroy(c); ctx.clear(); }
+};
+
 // ---- device calls --------------------------------------------------------------------------------
 void load(rattle_ctx *ctx, const read_set_t &reads, int k, bool both) {
     std::string cat;
@@ -298,7 +365,8 @@ int mode_cluster(int argc, char **argv) {
         {"bv_min_threshold", {"-b", "--bv-end-threshold"}, true}, {"bv_falloff", {"-f", "--bv-falloff"}, true},
         {"min_reads_cluster", {"-r", "--min-reads-cluster"}, true}, {"repr_percentile", {"-p", "--repr-percentile"}, true},
         {"rna", {"--rna"}, false}, {"verbose", {"--verbose"}, false}, {"raw", {"--raw"}, false},
-        {"lower_len", {"--lower-length"}, true}, {"upper_len", {"--upper-length"}, true}, {"device", {"--device"}, true}};
+        {"lower_len", {"--lower-length"}, true}, {"upper_len", {"--upper-length"}, true}, {"device", {"--device"}, true},
+        {"devices", {"--devices"}, true}, {"host-exchange", {"--host-exchange"}, false}};
     args_t a = parse(argc, argv, defs);
     if (a.has("help")) { std::cerr << "rattle cluster -i reads.fq [-o dir] [--rna] [--iso] ... (flags of RATTLE's cluster mode)\n"; return EXIT_SUCCESS; }
     if (!a.has("input")) die("ERROR: No input file provided");
@@ -315,16 +383,20 @@ int mode_cluster(int argc, char **argv) {
     std::stable_sort(reads.begin(), reads.end(), [](const read_t &x, const read_t &y) { return x.seq.size() > y.seq.size(); });
     std::cerr << "Done" << std::endl;
 
-    rattle_ctx *ctx = nullptr;
-    chk(rattle_hip_ctx_create(a.i("device", 0), &ctx));
+    device_team team;
+    team.open(a);
     rattle_cluster_params P;
     P.t_s = a.d("t_s", 0.2); P.t_v = a.d("t_v", 1000000); P.bv_threshold = a.d("bv_threshold", 0.4);
     P.min_bv_threshold = a.d("bv_min_threshold", 0.2); P.bv_falloff = a.d("bv_falloff", 0.05);
     P.min_reads_cluster = a.i("min_reads_cluster", 0); P.use_hc = 0; P.repr_percentile = a.d("repr_percentile", 0.15);
     P.is_rna = is_rna ? 1 : 0;
-    load(ctx, reads, k, !is_rna);
     rattle_cluster_set *raw = nullptr;
-    chk(rattle_hip_cluster_reads(ctx, &P, &raw));
+    team.run([&](int r, rattle_ctx *ctx) {                                      // every rank ends up with the same clusters
+        load(ctx, reads, k, !is_rna);
+        rattle_cluster_set *mine = nullptr;
+        chk(rattle_hip_cluster_reads(ctx, &P, &mine));
+        if (r == 0) raw = mine; else rattle_hip_cluster_set_free(mine);
+    });
     cluster_set_t gene = to_set(raw);
     std::cerr << "Gene clustering done" << std::endl;
     std::cerr << gene.size() << " gene clusters found" << std::endl;
@@ -335,14 +407,14 @@ int mode_cluster(int argc, char **argv) {
             for (auto &s : c.seqs) s.seq_id = std::stoi(reads[s.seq_id].ann);
         }
         write_clusters(gene, out_path);
-        rattle_hip_ctx_destroy(ctx);
+        team.close();
         return EXIT_SUCCESS;
     }
     // main.cpp:281-323: second level per gene cluster with the iso parameters
-    load(ctx, reads, iso_k, !is_rna);
     P.t_s = a.d("iso_t_s", 0.3); P.t_v = a.d("iso_t_v", 25);
     cluster_set_t iso;
-    // all gene clusters at once: the subsets are independent (rattle_hip_cluster_subsets runs them concurrently)
+    // all gene clusters at once: the subsets are independent (rattle_hip_cluster_subsets runs them concurrently, and
+    // over the ranks when there are several)
     std::vector<uint32_t> ids;
     std::vector<uint64_t> sub_off(1, 0);
     for (auto &c : gene) {
@@ -354,7 +426,12 @@ int mode_cluster(int argc, char **argv) {
         sub_off.push_back(ids.size());
     }
     std::vector<rattle_cluster_set *> subs(gene.size() ? gene.size() : 1, nullptr);
-    chk(rattle_hip_cluster_subsets(ctx, &P, ids.data(), sub_off.data(), (uint32_t)gene.size(), subs.data(), 0));
+    team.run([&](int r, rattle_ctx *ctx) {
+        load(ctx, reads, iso_k, !is_rna);
+        std::vector<rattle_cluster_set *> mine(gene.size() ? gene.size() : 1, nullptr);
+        chk(rattle_hip_cluster_subsets(ctx, &P, ids.data(), sub_off.data(), (uint32_t)gene.size(), mine.data(), 0));
+        if (r == 0) subs = mine; else for (auto *x : mine) rattle_hip_cluster_set_free(x);
+    });
     int gi = 0;
     for (auto &c : gene) {
         for (auto &ic : to_set(subs[gi])) {
@@ -368,7 +445,7 @@ int mode_cluster(int argc, char **argv) {
     std::cerr << "Isoform clustering done" << std::endl;
     std::cerr << iso.size() << " isoform clusters found" << std::endl;
     write_clusters(iso, out_path);
-    rattle_hip_ctx_destroy(ctx);
+    team.close();
     return EXIT_SUCCESS;
 }
 
@@ -378,7 +455,8 @@ int mode_correct(int argc, char **argv) {
         {"clusters", {"-c", "--clusters"}, true}, {"output", {"-o", "--output"}, true}, {"gap-occ", {"-g", "--gap-occ"}, true},
         {"min-occ", {"-m", "--min-occ"}, true}, {"split", {"-s", "--split"}, true}, {"min-reads", {"-r", "--min-reads"}, true},
         {"threads", {"-t", "--threads"}, true}, {"verbose", {"--verbose"}, false}, {"device", {"--device"}, true},
-        {"vote-order", {"--vote-order"}, true}, {"max-pack-cells", {"--max-pack-cells"}, true}};
+        {"vote-order", {"--vote-order"}, true}, {"max-pack-cells", {"--max-pack-cells"}, true}, {"devices", {"--devices"}, true},
+        {"host-exchange", {"--host-exchange"}, false}};
     args_t a = parse(argc, argv, defs);
     if (a.has("help")) {
         std::cerr << "rattle correct -i reads.fq -c clusters.out [-o dir] ... (flags of RATTLE's correct mode)\n"
@@ -419,11 +497,18 @@ int mode_correct(int argc, char **argv) {
     std::string vo = a.str("vote-order", "");
     if (vo.size() == 6) memcpy(P.vote_order, vo.data(), 6);
     if (a.has("max-pack-cells")) P.max_pack_cells = std::stoull(a.str("max-pack-cells", "0"));
-    rattle_ctx *ctx = nullptr;
-    chk(rattle_hip_ctx_create(a.i("device", 0), &ctx));
+    device_team team;
+    team.open(a);
     rattle_correction *R = nullptr;
-    chk(rattle_hip_correct_reads(ctx, (const uint8_t *)cat.data(), (const uint8_t *)qcat.data(), off.data(), (uint32_t)reads.size(),
-                                 (uint32_t)clusters.size(), coff.data(), mid.data(), mrev.data(), &P, &R));
+    team.run([&](int r, rattle_ctx *ctx) {                                      // packs sharded over the ranks, result reassembled on rank 0
+        rattle_correction *mine = nullptr, *merged = nullptr;
+        chk(rattle_hip_correct_reads(ctx, (const uint8_t *)cat.data(), (const uint8_t *)qcat.data(), off.data(), (uint32_t)reads.size(),
+                                     (uint32_t)clusters.size(), coff.data(), mid.data(), mrev.data(), &P, &mine));
+        if (team.n() == 1) { R = mine; return; }
+        chk(rattle_hip_correction_gather(ctx, mine, 0, &merged));
+        rattle_hip_correction_free(mine);
+        if (r == 0) R = merged;
+    });
     auto tag = [&](int cid) {                                                    // correct.cpp:348-353
         int gid = clusters[cid].main_seq.gene_id;
         if (gid == -1) return ",gene_cluster_" + std::to_string(cid);
@@ -495,7 +580,7 @@ int mode_correct(int argc, char **argv) {
         std::cerr << R->skipped.n << " pack(s) with " << R->counters[4] << " reads were not corrected (DP beyond the device or the budget): skipped_packs.tsv" << std::endl;
     }
     rattle_hip_correction_free(R);
-    rattle_hip_ctx_destroy(ctx);
+    team.close();
     std::cerr << "Done" << std::endl;
     return EXIT_SUCCESS;
 }

@@ -87,3 +87,20 @@ def test_polish_cli_merges_similar_consensi(built, tmp_path):
     got = (a / "transcriptome.fq").read_bytes()
     assert got == (b / "transcriptome.fq").read_bytes()
     assert 1 <= got.count(b"@cluster_") < 40
+
+
+def test_cli_one_job_over_several_ranks(built, tmp_path):
+    """`--devices a,b,...`: one host thread per rank, the library shards candidates / gene clusters / packs.  Three ranks on
+    the box's one GPU through the in-process host exchange (RCCL wants one GPU per rank): every output file identical to
+    the single-device run."""
+    seqs, quals, _, _ = synth.reads(1500, 9, 2, True, seed=19)
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(synth.fastq_text(seqs, quals))
+    a = tmp_path / "one"; b = tmp_path / "three"
+    a.mkdir(); b.mkdir()
+    for out, extra in ((a, []), (b, ["--devices", "0,0,0", "--host-exchange"])):
+        subprocess.run([RATTLE, "cluster", "-i", str(fq), "-o", str(out), "--iso"] + extra, check=True, capture_output=True)
+        subprocess.run([RATTLE, "correct", "-i", str(fq), "-c", str(out / "clusters.out"), "-o", str(out), "-s", "40"] + extra, check=True, capture_output=True)
+    for f in ("clusters.out", "corrected.fq", "uncorrected.fq", "consensi.fq"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    assert (a / "corrected.fq").stat().st_size > 100000
