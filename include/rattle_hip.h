@@ -240,6 +240,9 @@ int rattle_hip_correct_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const u
                              const uint32_t *cluster_offsets, const int32_t *member_id, const uint8_t *member_rev,
                              const rattle_correct_params *params, rattle_correction **out);
 void rattle_hip_correction_free(rattle_correction *c);
+/* Optional: allocate the POA arena of correct_reads ahead of time (a caller can overlap the seconds a > 100 GB allocation takes
+ * with reading its input).  bytes is a hint, clamped to what the device has free; correct_reads grows the arena if it must. */
+int rattle_hip_reserve_arena(rattle_ctx *ctx, uint64_t bytes);
 
 /* ------------------------------------------------------------------------------------
  * One job over the GPUs of a node.  The reference parallelises the same axes with host

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rattle_hip_correct_reads": (C.c_int, [C.c_void_p, _u8p, _u8p, _u64p, C.c_uint32, C.c_uint32, _u32p, _i32p, _u8p,
                                            _P(CorrectParams), _P(_P(Correction))]),
     "rattle_hip_correction_free": (None, [_P(Correction)]),
+    "rattle_hip_reserve_arena": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rattle_hip_set_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLGATHERV_FN, C.c_void_p]),
     "rattle_hip_comm_unique_id": (C.c_int, [_u8p]),
     "rattle_hip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),

@@ -489,6 +489,20 @@ int rattle_hip_correct_reads(rattle_ctx *c, const uint8_t *seq, const uint8_t *q
     return rc;
 }
 
+int rattle_hip_reserve_arena(rattle_ctx *c, uint64_t bytes) {
+    if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
+    RT_TRY(use_device(c));
+    size_t free_b = 0, total_b = 0;
+    RT_HIP(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t take = std::min<uint64_t>(bytes, (uint64_t)((free_b + c->poa_arena_bytes) * 0.8));
+    if (take <= c->poa_arena_bytes) return 0;
+    if (c->poa_arena) (void)hipFree(c->poa_arena);
+    c->poa_arena = nullptr; c->poa_arena_bytes = 0;
+    RT_HIP(hipMalloc((void **)&c->poa_arena, take));
+    c->poa_arena_bytes = take;
+    return 0;
+}
+
 static void free_set(rattle_read_set &s) {
     free(s.read_id); free(s.cluster_id); free(s.n_reads); free(s.off); free(s.seq); free(s.qual);
 }

@@ -1968,8 +1968,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             if (P.rounds == 0 && !getenv("RATTLE_POA_NODE_CAP")) {
                 // first-pass capacity: a pack of ~200 reads at 10 % error grows to ~5 nodes per base of its
                 // longest read; packs that still outgrow it are re-run with 4x nodes
-                P.node_cap = std::max<uint32_t>(P.node_cap, (uint32_t)std::min<uint64_t>(6ull * tl, 1u << 20));
-                P.cell_cap = std::max<uint64_t>(P.cell_cap, (uint64_t)(std::min<uint64_t>(P.node_cap, tb + 1) + 64) * (tl + 32));
+                P.node_cap = std::max<uint32_t>(P.node_cap, (uint32_t)std::min<uint64_t>(7ull * tl, 1u << 20));
+                // the DP record is the arena: 7 nodes per base of the longest read (measured: ~4.5 at the end of a 200-read pack
+                // at 10 % error), not a fixed floor -- a third of the memory, and of the seconds the allocation takes
+                P.cell_cap = (uint64_t)(std::min<uint64_t>(std::max<uint64_t>(7ull * tl, 2048), tb + 1) + 64) * (tl + 32);
             }
             uint64_t per = plan_class(c, tb, tl);
             if (per > budget) {

@@ -2,10 +2,14 @@
 // `rattle correct` (:325-412) and `rattle polish` (:612-762) over librattle_hip.so's C ABI.
 // Same flags and defaults, same `clusters.out` (hps stream) and FASTQ outputs.  Host C++ only:
 // every compute step goes through include/rattle_hip.h.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +18,7 @@
 #include <functional>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -169,30 +174,6 @@ void resolve_input(std::string &filename, bool &fastq) {                        
     else die("\nError: Input file format incorrect! Please use fasta/fastq file. \n");
 }
 
-// main.cpp:16-64 + fasta.cpp:272-370: quality dropped, ann = running record index over ALL
-// records, length filter unless raw, reads containing 'N' skipped.
-read_set_t read_inputs_cluster(const std::vector<std::string> &files, const std::vector<std::string> &labels, bool raw, int lo, int hi) {
-    if (!labels.empty() && labels.size() != files.size()) die("\nError: Number of input files and number of label files do not match\n");
-    read_set_t reads;
-    int index = 0, sample = 0;
-    for (std::string fn : files) {
-        bool fastq;
-        resolve_input(fn, fastq);
-        std::string lab = labels.empty() ? "" : "," + labels[sample];
-        int n_skipped = 0;
-        for_each_record(fn, fastq, [&](const std::string &h, const std::string &s, const std::string &, const std::string &) {
-            int my = index++;
-            bool len_ok = raw || ((int)s.length() >= lo && (int)s.length() <= hi);
-            if (!len_ok) return;
-            if (s.find('N') != std::string::npos) { ++n_skipped; return; }
-            reads.push_back(read_t{h + lab, s, std::to_string(my), ""});
-        });
-        if (n_skipped) std::cerr << "\n" << n_skipped << "  reads contains N are skipped!" << std::endl;
-        ++sample;
-    }
-    return reads;
-}
-
 // main.cpp:66-112 + fasta.cpp:207-270: everything, file order, with qualities.
 read_set_t read_inputs(const std::vector<std::string> &files, const std::vector<std::string> &labels) {
     if (!labels.empty() && labels.size() != files.size()) die("\nError: Number of input files and number of label files do not match\n");
@@ -271,6 +252,178 @@ cluster_set_t read_clusters(const std::string &path) {            // current 3-f
     cluster_set_t cs;
     if (decode_clusters(b, 3, cs) || decode_clusters(b, 2, cs)) return cs;
     die("\nError: clusters file is not an hps cluster stream\n");
+}
+
+// ---- ingest for `cluster` / `correct` (fasta.cpp:7-31,207-370, main.cpp:16-112) -----------------------
+// The reference reads line by line into four std::string per record and inflates .gz inputs into a sibling file first.  Here
+// a record is four spans into the file's bytes: a plain file is mapped, a .gz one inflated in memory (the sibling file is
+// only written with --write-unzipped), records are found with memchr, and the concatenated base / quality buffers the library
+// takes are gathered from the spans in parallel.  Same semantics: '\n' separated lines, a last line without one counts, DOS
+// endings detected on the first line, FASTA sequence lines joined and upper-cased, quality '~' for FASTA.
+struct span { const char *p; uint32_t n; };
+struct read_table {
+    std::vector<std::unique_ptr<std::string>> pools;       // owned bytes (inflated input, joined FASTA sequences, label suffixes)
+    std::vector<std::pair<void *, size_t>> maps;           // mapped files
+    std::vector<span> header, seq, ann, qual;
+    std::vector<uint32_t> label;                           // 0: none, else 1 + index into labels
+    std::vector<std::string> labels;                       // "," + label
+    size_t n() const { return seq.size(); }
+    std::string head(size_t i) const { return std::string(header[i].p, header[i].n) + (label[i] ? labels[label[i] - 1] : std::string()); }
+    ~read_table() { for (auto &m : maps) munmap(m.first, m.second); }
+    read_table() = default;
+    read_table(const read_table &) = delete;
+    read_table &operator=(const read_table &) = delete;
+};
+
+template <typename F>
+void parallel_chunks(size_t n, F f) {                     // f(begin, end) on host threads
+    const size_t T = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), (n + 4095) / 4096));
+    if (T <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t) th.emplace_back([=] { f(n * t / T, n * (t + 1) / T); });
+    for (auto &x : th) x.join();
+}
+
+// bytes of an input file: mapped, or inflated in memory for .gz (main.cpp:35-57 decides by extension)
+void file_bytes(read_table &T, std::string &filename, bool &fastq, bool write_unzipped, const char *&data, size_t &size) {
+    if (access(filename.c_str(), F_OK)) die("\nError: Input file not found! \n");
+    int index = (int)filename.find_last_of(".");
+    std::string ext = filename.substr(index + 1);
+    bool gz = false;
+    std::string inner = filename;
+    if (ext == "gz") {
+        gz = true;
+        inner = filename.substr(0, index);
+        index = (int)inner.find_last_of(".");
+        ext = inner.substr(index + 1);
+    }
+    if (ext == "fq" || ext == "fastq") fastq = true;
+    else if (ext == "fasta" || ext == "fa") fastq = false;
+    else die("\nError: Input file format incorrect! Please use fasta/fastq file. \n");
+    if (gz) {
+        std::cerr << "Start decompressing file" << std::endl;
+        gzFile in = gzopen(filename.c_str(), "rb");
+        if (!in) die("Error: Failed to decompress the file");
+        gzbuffer(in, 1 << 20);
+        std::unique_ptr<std::string> buf(new std::string());
+        size_t got = 0;
+        buf->resize(64u << 20);
+        int k;
+        while ((k = gzread(in, &(*buf)[got], (unsigned)std::min<size_t>(buf->size() - got, 1u << 30))) > 0) {
+            got += (size_t)k;
+            if (buf->size() - got < (16u << 20)) buf->resize(buf->size() * 2);
+        }
+        gzclose(in);
+        buf->resize(got);
+        if (write_unzipped) {                           // the reference's side effect (fasta.cpp:7-31): the inflated sibling file
+            FILE *f = fopen(inner.c_str(), "wb");
+            if (!f) die("Error: Failed to decompress the file");
+            fwrite(buf->data(), 1, buf->size(), f);
+            fclose(f);
+        }
+        std::cerr << "Decompressing file Complete" << std::endl;
+        data = buf->data(); size = buf->size();
+        T.pools.push_back(std::move(buf));
+        return;
+    }
+    const int fd = open(filename.c_str(), O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) die("\nError: Input file not found! \n");
+    size = (size_t)st.st_size;
+    data = "";
+    if (size) {
+        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m == MAP_FAILED) die("Error: cannot map " + filename);
+        (void)madvise(m, size, MADV_SEQUENTIAL);
+        T.maps.emplace_back(m, size);
+        data = (const char *)m;
+    }
+    close(fd);
+}
+
+// all records of the input files, in file order (main.cpp:66-112: `correct`, `cluster_summary`, ... read everything)
+void read_table_inputs(read_table &T, const std::vector<std::string> &files, const std::vector<std::string> &labels, bool write_unzipped) {
+    if (!labels.empty() && labels.size() != files.size()) die("\nError: Number of input files and number of label files do not match\n");
+    for (auto &l : labels) T.labels.push_back("," + l);
+    uint32_t sample = 0;
+    for (std::string fn : files) {
+        bool fastq = true;
+        const char *d; size_t sz;
+        file_bytes(T, fn, fastq, write_unzipped, d, sz);
+        const uint32_t lab = labels.empty() ? 0u : sample + 1;
+        if (fastq) {
+            span fld[4];
+            bool dos = false, first = true;
+            int id = 0;
+            size_t pos = 0;
+            while (pos < sz) {
+                const char *nl = (const char *)memchr(d + pos, '\n', sz - pos);
+                const size_t end = nl ? (size_t)(nl - d) : sz;
+                size_t len = end - pos;
+                if (first) { dos = len > 0 && d[end - 1] == '\r'; first = false; }
+                if (dos && len > 0) --len;
+                fld[id] = span{d + pos, (uint32_t)len};
+                pos = end + 1;
+                if (++id == 4) { T.header.push_back(fld[0]); T.seq.push_back(fld[1]); T.ann.push_back(fld[2]); T.qual.push_back(fld[3]); T.label.push_back(lab); id = 0; }
+            }
+        } else {
+            // FASTA: header + joined, upper-cased sequence lines (fasta.cpp:60,131); quality '~' x length
+            std::unique_ptr<std::string> pool(new std::string());
+            pool->reserve(sz + 16);
+            struct rec { size_t h0; uint32_t hn; size_t s0, s1; };
+            std::vector<rec> recs;
+            bool dos = false, first = true, have = false;
+            rec cur{0, 0, 0, 0};
+            size_t pos = 0;
+            while (pos < sz) {
+                const char *nl = (const char *)memchr(d + pos, '\n', sz - pos);
+                const size_t end = nl ? (size_t)(nl - d) : sz;
+                size_t len = end - pos;
+                if (first) { dos = len > 0 && d[end - 1] == '\r'; first = false; }
+                if (dos && len > 0) --len;
+                if (len) {
+                    if (d[pos] == '>') {
+                        if (have) { cur.s1 = pool->size(); recs.push_back(cur); }
+                        cur = rec{pos, (uint32_t)len, pool->size(), 0}; have = true;
+                    } else {
+                        for (size_t t = 0; t < len; ++t) pool->push_back((char)toupper((unsigned char)d[pos + t]));
+                    }
+                }
+                pos = end + 1;
+            }
+            if (have) { cur.s1 = pool->size(); recs.push_back(cur); }
+            size_t longest = 0;
+            for (auto &r : recs) longest = std::max(longest, r.s1 - r.s0);
+            std::unique_ptr<std::string> tilde(new std::string(longest, '~'));
+            for (auto &r : recs) {
+                T.header.push_back(span{d + r.h0, r.hn}); T.seq.push_back(span{pool->data() + r.s0, (uint32_t)(r.s1 - r.s0)});
+                T.ann.push_back(span{"", 0}); T.qual.push_back(span{tilde->data(), (uint32_t)(r.s1 - r.s0)}); T.label.push_back(lab);
+            }
+            T.pools.push_back(std::move(pool)); T.pools.push_back(std::move(tilde));
+        }
+        ++sample;
+    }
+}
+
+// concatenated bases (and qualities, padded with '!' / cut to the sequence length) of the records `ids` in that order
+void gather_reads(const read_table &T, const std::vector<uint32_t> &ids, std::vector<uint8_t> &cat, std::vector<uint8_t> *qcat, std::vector<uint64_t> &off) {
+    const size_t n = ids.size();
+    off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + T.seq[ids[i]].n;
+    cat.resize(off[n] + 1);
+    if (qcat) qcat->resize(off[n] + 1);
+    parallel_chunks(n, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const span sq = T.seq[ids[i]];
+            memcpy(cat.data() + off[i], sq.p, sq.n);
+            if (qcat) {
+                const span q = T.qual[ids[i]];
+                const uint32_t m = std::min(q.n, sq.n);
+                memcpy(qcat->data() + off[i], q.p, m);
+                if (m < sq.n) memset(qcat->data() + off[i] + m, '!', sq.n - m);
+            }
+        }
+    });
 }
 
 // ---- one job over several GPUs of the node: --devices 0,1,... --------------------------------------------------
@@ -355,6 +508,27 @@ cluster_set_t to_set(rattle_cluster_set *cs) {
     return out;
 }
 
+// context creation (HIP start-up, ~0.5 s) and, for `correct`, the POA arena allocation (seconds for > 100 GB) run on a helper
+// thread while the main thread reads the input
+struct team_opener {
+    device_team &team;
+    std::thread th;
+    team_opener(device_team &t, const args_t &a, uint64_t arena_hint) : team(t) {
+        th = std::thread([&t, &a, arena_hint] {
+            t.open(a);
+            if (arena_hint) t.run([&](int, rattle_ctx *c) { (void)rattle_hip_reserve_arena(c, arena_hint); });
+        });
+    }
+    void wait() { if (th.joinable()) th.join(); }
+    ~team_opener() { wait(); }
+};
+
+uint64_t input_bytes(const std::vector<std::string> &files) {
+    uint64_t tot = 0;
+    for (auto &f : files) { struct stat st; if (stat(f.c_str(), &st) == 0) tot += (uint64_t)st.st_size * (f.size() > 3 && f.substr(f.size() - 3) == ".gz" ? 4 : 1); }
+    return tot;
+}
+
 int mode_cluster(int argc, char **argv) {
     std::vector<opt_def> defs = {
         {"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"label", {"-l", "--label"}, true},
@@ -366,9 +540,14 @@ int mode_cluster(int argc, char **argv) {
         {"min_reads_cluster", {"-r", "--min-reads-cluster"}, true}, {"repr_percentile", {"-p", "--repr-percentile"}, true},
         {"rna", {"--rna"}, false}, {"verbose", {"--verbose"}, false}, {"raw", {"--raw"}, false},
         {"lower_len", {"--lower-length"}, true}, {"upper_len", {"--upper-length"}, true}, {"device", {"--device"}, true},
-        {"devices", {"--devices"}, true}, {"host-exchange", {"--host-exchange"}, false}};
+        {"devices", {"--devices"}, true}, {"host-exchange", {"--host-exchange"}, false}, {"write-unzipped", {"--write-unzipped"}, false}};
     args_t a = parse(argc, argv, defs);
-    if (a.has("help")) { std::cerr << "rattle cluster -i reads.fq [-o dir] [--rna] [--iso] ... (flags of RATTLE's cluster mode)\n"; return EXIT_SUCCESS; }
+    if (a.has("help")) {
+        std::cerr << "rattle cluster -i reads.fq [-o dir] [--rna] [--iso] ... (flags of RATTLE's cluster mode)\n"
+                     "  --devices 0,1,..   one job over several GPUs (RCCL; --host-exchange: in-process exchange on host buffers)\n"
+                     "  --write-unzipped   also write the inflated copy of a .gz input next to it, as the reference does\n";
+        return EXIT_SUCCESS;
+    }
     if (!a.has("input")) die("ERROR: No input file provided");
     int k = a.i("kmer_size", 10), iso_k = a.i("iso_kmer_size", 11);
     if (k > 16 || iso_k > 16) die("\nError: maximum kmer size = 16 \n");
@@ -377,14 +556,46 @@ int mode_cluster(int argc, char **argv) {
     bool is_rna = a.has("rna");
     std::cerr << "RNA mode: " << std::boolalpha << is_rna << std::endl;
     std::cerr << "Reading fasta file... " << std::endl;
-    read_set_t reads = read_inputs_cluster(split_string(a.str("input", ""), ','), split_string(a.str("label", ""), ','), a.has("raw"),
-                                           a.i("lower_len", 150), a.i("upper_len", 100000));
-    std::cout << "Reads: " << reads.size() << std::endl;
-    std::stable_sort(reads.begin(), reads.end(), [](const read_t &x, const read_t &y) { return x.seq.size() > y.seq.size(); });
-    std::cerr << "Done" << std::endl;
-
     device_team team;
-    team.open(a);
+    team_opener opener(team, a, 0);
+    // main.cpp:16-64 + fasta.cpp:272-370: ann = running record index over ALL records, length filter unless --raw, reads that
+    // contain 'N' skipped; then sort_read_set (fasta.cpp:458-464): stable, longest first (a counting sort over the lengths)
+    read_table T;
+    read_table_inputs(T, split_string(a.str("input", ""), ','), split_string(a.str("label", ""), ','), a.has("write-unzipped"));
+    std::vector<uint32_t> order;                  // processing position -> record index (= the reference's `ann`)
+    {
+        const bool raw = a.has("raw");
+        const int lo = a.i("lower_len", 150), hi = a.i("upper_len", 100000);
+        const size_t n = T.n();
+        std::vector<uint8_t> keep(n, 0);
+        std::atomic<size_t> n_skipped(0);
+        parallel_chunks(n, [&](size_t b, size_t e) {
+            size_t sk = 0;
+            for (size_t i = b; i < e; ++i) {
+                const span sq = T.seq[i];
+                if (!(raw || ((int)sq.n >= lo && (int)sq.n <= hi))) continue;
+                if (memchr(sq.p, 'N', sq.n)) { ++sk; continue; }
+                keep[i] = 1;
+            }
+            n_skipped += sk;
+        });
+        if (n_skipped) std::cerr << "\n" << n_skipped << "  reads contains N are skipped!" << std::endl;
+        uint32_t max_len = 0;
+        for (size_t i = 0; i < n; ++i) if (keep[i]) max_len = std::max(max_len, T.seq[i].n);
+        std::vector<uint32_t> start((size_t)max_len + 2, 0);
+        for (size_t i = 0; i < n; ++i) if (keep[i]) ++start[max_len - T.seq[i].n + 1];
+        for (size_t b = 0; b <= max_len; ++b) start[b + 1] += start[b];
+        order.resize(start[(size_t)max_len + 1]);
+        for (size_t i = 0; i < n; ++i) if (keep[i]) order[start[max_len - T.seq[i].n]++] = (uint32_t)i;
+    }
+    std::cout << "Reads: " << order.size() << std::endl;
+    std::vector<uint8_t> cat;
+    std::vector<uint64_t> off;
+    gather_reads(T, order, cat, nullptr, off);
+    std::cerr << "Done" << std::endl;
+    const uint32_t n_reads = (uint32_t)order.size();
+
+    opener.wait();
     rattle_cluster_params P;
     P.t_s = a.d("t_s", 0.2); P.t_v = a.d("t_v", 1000000); P.bv_threshold = a.d("bv_threshold", 0.4);
     P.min_bv_threshold = a.d("bv_min_threshold", 0.2); P.bv_falloff = a.d("bv_falloff", 0.05);
@@ -392,7 +603,7 @@ int mode_cluster(int argc, char **argv) {
     P.is_rna = is_rna ? 1 : 0;
     rattle_cluster_set *raw = nullptr;
     team.run([&](int r, rattle_ctx *ctx) {                                      // every rank ends up with the same clusters
-        load(ctx, reads, k, !is_rna);
+        chk(rattle_hip_load_reads(ctx, cat.data(), off.data(), n_reads, k, is_rna ? 0 : 1));
         rattle_cluster_set *mine = nullptr;
         chk(rattle_hip_cluster_reads(ctx, &P, &mine));
         if (r == 0) raw = mine; else rattle_hip_cluster_set_free(mine);
@@ -403,8 +614,8 @@ int mode_cluster(int argc, char **argv) {
     const std::string out_path = outdir + "/clusters.out";
     if (!a.has("iso")) {                                                         // main.cpp:264-277
         for (auto &c : gene) {
-            c.main_seq.seq_id = std::stoi(reads[c.main_seq.seq_id].ann);
-            for (auto &s : c.seqs) s.seq_id = std::stoi(reads[s.seq_id].ann);
+            c.main_seq.seq_id = (int)order[c.main_seq.seq_id];
+            for (auto &s : c.seqs) s.seq_id = (int)order[s.seq_id];
         }
         write_clusters(gene, out_path);
         team.close();
@@ -419,15 +630,13 @@ int mode_cluster(int argc, char **argv) {
     std::vector<uint64_t> sub_off(1, 0);
     for (auto &c : gene) {
         std::stable_sort(c.seqs.begin(), c.seqs.end(), [](const cseq_t &x, const cseq_t &y) { return x.seq_id > y.seq_id; });
-        std::stable_sort(c.seqs.begin(), c.seqs.end(), [&reads](const cseq_t &x, const cseq_t &y) {
-            return reads[x.seq_id].seq.size() > reads[y.seq_id].seq.size();
-        });
+        std::stable_sort(c.seqs.begin(), c.seqs.end(), [&](const cseq_t &x, const cseq_t &y) { return off[x.seq_id + 1] - off[x.seq_id] > off[y.seq_id + 1] - off[y.seq_id]; });
         for (auto &s : c.seqs) ids.push_back((uint32_t)s.seq_id);
         sub_off.push_back(ids.size());
     }
     std::vector<rattle_cluster_set *> subs(gene.size() ? gene.size() : 1, nullptr);
     team.run([&](int r, rattle_ctx *ctx) {
-        load(ctx, reads, iso_k, !is_rna);
+        chk(rattle_hip_load_reads(ctx, cat.data(), off.data(), n_reads, iso_k, is_rna ? 0 : 1));
         std::vector<rattle_cluster_set *> mine(gene.size() ? gene.size() : 1, nullptr);
         chk(rattle_hip_cluster_subsets(ctx, &P, ids.data(), sub_off.data(), (uint32_t)gene.size(), mine.data(), 0));
         if (r == 0) subs = mine; else for (auto *x : mine) rattle_hip_cluster_set_free(x);
@@ -436,8 +645,8 @@ int mode_cluster(int argc, char **argv) {
     for (auto &c : gene) {
         for (auto &ic : to_set(subs[gi])) {
             cluster_t o;
-            o.main_seq = cseq_t{std::stoi(reads[c.seqs[ic.main_seq.seq_id].seq_id].ann), ic.main_seq.rev, gi};
-            for (auto &s : ic.seqs) o.seqs.push_back(cseq_t{std::stoi(reads[c.seqs[s.seq_id].seq_id].ann), s.rev, gi});
+            o.main_seq = cseq_t{(int)order[c.seqs[ic.main_seq.seq_id].seq_id], ic.main_seq.rev, gi};
+            for (auto &s : ic.seqs) o.seqs.push_back(cseq_t{(int)order[c.seqs[s.seq_id].seq_id], s.rev, gi});
             iso.push_back(o);
         }
         ++gi;
@@ -456,32 +665,38 @@ int mode_correct(int argc, char **argv) {
         {"min-occ", {"-m", "--min-occ"}, true}, {"split", {"-s", "--split"}, true}, {"min-reads", {"-r", "--min-reads"}, true},
         {"threads", {"-t", "--threads"}, true}, {"verbose", {"--verbose"}, false}, {"device", {"--device"}, true},
         {"vote-order", {"--vote-order"}, true}, {"max-pack-cells", {"--max-pack-cells"}, true}, {"devices", {"--devices"}, true},
-        {"host-exchange", {"--host-exchange"}, false}};
+        {"host-exchange", {"--host-exchange"}, false}, {"write-unzipped", {"--write-unzipped"}, false}};
     args_t a = parse(argc, argv, defs);
     if (a.has("help")) {
         std::cerr << "rattle correct -i reads.fq -c clusters.out [-o dir] ... (flags of RATTLE's correct mode)\n"
                      "  --max-pack-cells N   leave packs whose largest alignment needs more than N DP cells uncorrected (default: only\n"
-                     "                       packs that do not fit the device are skipped); skipped packs are listed in skipped_packs.tsv\n";
+                     "                       packs that do not fit the device are skipped); skipped packs are listed in skipped_packs.tsv\n"
+                     "  --devices 0,1,..     one job over several GPUs (RCCL; --host-exchange: in-process exchange on host buffers)\n";
         return EXIT_SUCCESS;
     }
     if (!a.has("input")) die("ERROR: No input file provided");
     if (!a.has("clusters")) die("ERROR: No clusters file provided");
     std::cerr << "Reading fasta file... ";
     std::vector<std::string> labels = split_string(a.str("label", ""), ',');
-    read_set_t reads = read_inputs(split_string(a.str("input", ""), ','), labels);
+    const std::vector<std::string> files = split_string(a.str("input", ""), ',');
+    device_team team;
+    // arena hint: ~440 kB of FASTQ per pack of 200 one-kb reads, at most a device full of resident packs, ~30 MB each
+    const uint64_t packs_hint = std::min<uint64_t>(input_bytes(files) / 440000 + 1, 3072);
+    team_opener opener(team, a, packs_hint * (45ull << 20));
+    read_table T;
+    read_table_inputs(T, files, labels, a.has("write-unzipped"));
     std::cerr << "Done" << std::endl;
     cluster_set_t clusters = read_clusters(a.str("clusters", ""));
     if (clusters.empty()) die("\nError: empty clusters file\n");
     const bool gene_mode = clusters[0].main_seq.gene_id == -1;                   // correct.cpp:322
+    const uint32_t n_reads = (uint32_t)T.n();
 
-    std::string cat, qcat;
-    std::vector<uint64_t> off(1, 0);
-    for (auto &r : reads) {
-        cat += r.seq;
-        std::string q = r.quality;
-        q.resize(r.seq.size(), '!');
-        qcat += q;
-        off.push_back(cat.size());
+    std::vector<uint8_t> cat, qcat;
+    std::vector<uint64_t> off;
+    {
+        std::vector<uint32_t> all(n_reads);
+        for (uint32_t i = 0; i < n_reads; ++i) all[i] = i;
+        gather_reads(T, all, cat, &qcat, off);
     }
     std::vector<uint32_t> coff(1, 0);
     std::vector<int32_t> mid;
@@ -497,13 +712,12 @@ int mode_correct(int argc, char **argv) {
     std::string vo = a.str("vote-order", "");
     if (vo.size() == 6) memcpy(P.vote_order, vo.data(), 6);
     if (a.has("max-pack-cells")) P.max_pack_cells = std::stoull(a.str("max-pack-cells", "0"));
-    device_team team;
-    team.open(a);
+    opener.wait();
     rattle_correction *R = nullptr;
     team.run([&](int r, rattle_ctx *ctx) {                                      // packs sharded over the ranks, result reassembled on rank 0
         rattle_correction *mine = nullptr, *merged = nullptr;
-        chk(rattle_hip_correct_reads(ctx, (const uint8_t *)cat.data(), (const uint8_t *)qcat.data(), off.data(), (uint32_t)reads.size(),
-                                     (uint32_t)clusters.size(), coff.data(), mid.data(), mrev.data(), &P, &mine));
+        chk(rattle_hip_correct_reads(ctx, cat.data(), qcat.data(), off.data(), n_reads, (uint32_t)clusters.size(), coff.data(), mid.data(),
+                                     mrev.data(), &P, &mine));
         if (team.n() == 1) { R = mine; return; }
         chk(rattle_hip_correction_gather(ctx, mine, 0, &merged));
         rattle_hip_correction_free(mine);
@@ -514,36 +728,52 @@ int mode_correct(int argc, char **argv) {
         if (gid == -1) return ",gene_cluster_" + std::to_string(cid);
         return ",gene_cluster_" + std::to_string(gid) + ",transcript_cluster_" + std::to_string(cid);
     };
-    // corrected.fq / uncorrected.fq (fasta.cpp:436-445 record layout) straight from the library's buffers
+    // corrected.fq / uncorrected.fq (fasta.cpp:436-445 record layout) straight from the library's buffers: the text of each
+    // file is laid out by record offsets and filled in parallel
     auto write_set = [&](const rattle_read_set &S, bool corrected, const std::string &path) {
+        std::vector<std::string> tags(clusters.size());
+        std::vector<uint64_t> at((size_t)S.n + 1, 0);
+        for (uint32_t i = 0; i < S.n; ++i) {
+            const uint32_t rid = (uint32_t)S.read_id[i];
+            std::string &tg = tags[S.cluster_id[i]];
+            if (tg.empty()) tg = tag(S.cluster_id[i]);
+            const uint64_t len = S.off[i + 1] - S.off[i];
+            at[i + 1] = at[i] + T.header[rid].n + (T.label[rid] ? T.labels[T.label[rid] - 1].size() : 0) + tg.size() + 1 + len + 1 +
+                        (corrected ? 1 : T.ann[rid].n) + 1 + len + 1;
+        }
+        std::vector<char> text(at[S.n]);
+        parallel_chunks(S.n, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const uint32_t rid = (uint32_t)S.read_id[i];
+                char *o = text.data() + at[i];
+                auto put = [&o](const char *p, size_t n) { memcpy(o, p, n); o += n; };
+                put(T.header[rid].p, T.header[rid].n);
+                if (T.label[rid]) put(T.labels[T.label[rid] - 1].data(), T.labels[T.label[rid] - 1].size());
+                put(tags[S.cluster_id[i]].data(), tags[S.cluster_id[i]].size()); *o++ = '\n';
+                put(S.seq + S.off[i], S.off[i + 1] - S.off[i]); *o++ = '\n';
+                if (corrected) *o++ = '+'; else put(T.ann[rid].p, T.ann[rid].n);
+                *o++ = '\n';
+                put(S.qual + S.off[i], S.off[i + 1] - S.off[i]); *o++ = '\n';
+            }
+        });
         FILE *f = fopen(path.c_str(), "wb");
         if (!f) die("Error: cannot write " + path);
-        std::string buf;
-        buf.reserve(64u << 20);
-        for (uint32_t i = 0; i < S.n; ++i) {
-            buf += reads[S.read_id[i]].header; buf += tag(S.cluster_id[i]); buf += '\n';
-            buf.append(S.seq + S.off[i], S.seq + S.off[i + 1]); buf += '\n';
-            buf += corrected ? std::string("+") : reads[S.read_id[i]].ann; buf += '\n';
-            buf.append(S.qual + S.off[i], S.qual + S.off[i + 1]); buf += '\n';
-            if (buf.size() > (60u << 20)) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
-        }
-        fwrite(buf.data(), 1, buf.size(), f);
+        fwrite(text.data(), 1, text.size(), f);
         fclose(f);
     };
     read_set_t consensi;
     // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's packs
     std::vector<std::vector<int>> label_counts(clusters.size(), std::vector<int>(labels.size(), 0));
     if (!labels.empty()) {
-        std::vector<char> in_pack(reads.size(), 0);
-        (void)in_pack;
         for (size_t c = 0; c < clusters.size(); ++c) {
             int n = (int)clusters[c].seqs.size();
+            if (n == 0) continue;
             int n_files = (n - 1) / P.split + 1;
             for (int nf = 0; nf < n_files; ++nf) {
                 int sz = (n - 1 - nf) / n_files + 1;
                 if (sz <= P.min_reads) continue;
                 for (int j = nf; j < n; j += n_files) {
-                    const std::string &h = reads[clusters[c].seqs[j].seq_id].header;
+                    const std::string h = T.head(clusters[c].seqs[j].seq_id);
                     size_t p = h.find_first_of(",");
                     std::string rest = p == std::string::npos ? "" : h.substr(p + 1);
                     std::string lab = rest.substr(0, rest.find_first_of(","));

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-to-end wall time of the drop-in CLI (parse + upload + kernels + FASTQ output): usage cli_e2e.sh READS
 set -e
-N=${1:-300000}
+N=${1:-1000000}
 D=$(mktemp -d)
 python - "$N" "$D" <<'PY'
 import sys
