@@ -354,15 +354,17 @@ __device__ __forceinline__ void load_block(const int16_t *__restrict__ p, int32_
 #pragma unroll
         for (int u = 0; u < CPL / 4; ++u) {
             const uint2 a = q[u];
-            v[4 * u] = (int16_t)(a.x & 0xFFFF); v[4 * u + 1] = (int16_t)(a.x >> 16);
-            v[4 * u + 2] = (int16_t)(a.y & 0xFFFF); v[4 * u + 3] = (int16_t)(a.y >> 16);
+            // H is never negative (local alignment): the 16-bit record is read UNSIGNED, so a register class is exact up to
+            // 5 * columns < 65536, i.e. 13107 columns
+            v[4 * u] = (int32_t)(a.x & 0xFFFF); v[4 * u + 1] = (int32_t)(a.x >> 16);
+            v[4 * u + 2] = (int32_t)(a.y & 0xFFFF); v[4 * u + 3] = (int32_t)(a.y >> 16);
         }
     } else {
         const uint32_t *q = (const uint32_t *)p;
 #pragma unroll
         for (int u = 0; u < CPL / 2; ++u) {
             const uint32_t a = q[u];
-            v[2 * u] = (int16_t)(a & 0xFFFF); v[2 * u + 1] = (int16_t)(a >> 16);
+            v[2 * u] = (int32_t)(a & 0xFFFF); v[2 * u + 1] = (int32_t)(a >> 16);
         }
     }
 }
@@ -1140,7 +1142,7 @@ constexpr int poa_min_waves(int CPL, int NW, int PK) {
 template <int CPL, int RING, int NW, int PK>
 __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kernel(poa_args A) {
     constexpr uint32_t NT = 64 * NW;
-    using cell_t = typename std::conditional<PK == 2, int32_t, int16_t>::type;      // DP matrix cell
+    using cell_t = typename std::conditional<PK == 2, int32_t, uint16_t>::type;     // DP matrix cell (16-bit records hold H >= 0 unsigned)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
     __shared__ uint32_t s_alpha;              // letters seen in the pack so far: bit 0 T, bit 1 U, bit 2 anything but A, C, G, T, U
@@ -1793,19 +1795,19 @@ struct poa_variant {
     int (*max_blocks)(size_t);
 };
 #define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, PK, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
-#define POA_CLASSES 7
-static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144};
+#define POA_CLASSES 8
+static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144, 8192};
 static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(10, 8, 4, 1),
-                                                   POA_VARIANT(16, 4, 4, 0), POA_VARIANT(24, 5, 4, 0),
-                                                   POA_VARIANT(4, 0, 4, 2) /* longer than 6144: int32 cells, segmented rows */};
-static const poa_variant k_noring[2] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
+                                                   POA_VARIANT(16, 4, 4, 0), POA_VARIANT(24, 5, 4, 0), POA_VARIANT(32, 3, 4, 0),
+                                                   POA_VARIANT(4, 0, 4, 2) /* longer than 8192: int32 cells, segmented rows */};
+static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
 // experiments (RATTLE_POA_EXP=<a>,<b>: index into this table for the 1024- and the 1536-column class): fewer, fatter wavefronts
 // per pack -- the per-row fixed cost (scan, exchange, scalar bookkeeping) is paid per wavefront
-static const poa_variant k_exp[] = {POA_VARIANT(16, 4, 1, 1), POA_VARIANT(16, 6, 1, 1), POA_VARIANT(8, 6, 2, 1), POA_VARIANT(8, 4, 2, 1),
-                                    POA_VARIANT(12, 4, 2, 1), POA_VARIANT(12, 6, 2, 1), POA_VARIANT(8, 5, 2, 1), POA_VARIANT(8, 8, 2, 1),
-                                    POA_VARIANT(12, 5, 2, 1), POA_VARIANT(12, 8, 2, 1), POA_VARIANT(16, 5, 1, 1), POA_VARIANT(16, 8, 1, 1)};
+// (measured round 2, profiles/README.md: 16 columns x 1 wavefront and 8 / 12 columns x 2 wavefronts are within noise of the
+// defaults in the full benchmark; two of them are kept selectable)
+static const poa_variant k_exp[] = {POA_VARIANT(16, 4, 1, 1), POA_VARIANT(8, 6, 2, 1), POA_VARIANT(12, 6, 2, 1)};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -1943,7 +1945,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
             return (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 16 + 64;
         };
-        if ((c == 4 || c == 5) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 4];
+        if ((c == 4 || c == 5 || c == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 4];
         P.shm = lds_bytes(P.V);
         A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = lds_seq;
         return o;
@@ -2032,7 +2034,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
                 fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, ring %u) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        c == POA_CLASSES - 1 ? "> 6144: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, pass, P.todo.size(), P.n_slots,
+                        c == POA_CLASSES - 1 ? "> 8192: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, pass, P.todo.size(), P.n_slots,
                         P.per_slot / 1e6, P.bpc);
         }
         if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }

@@ -73,9 +73,9 @@ def test_multi_segment_rows(gpu_ctx, oracle):
     assert rows[0] == want
 
 
-@pytest.mark.parametrize("length,depth", [(700, 40), (1300, 30), (1800, 25), (2300, 20), (2900, 16), (4500, 10)])
+@pytest.mark.parametrize("length,depth", [(700, 40), (1300, 30), (1800, 25), (2300, 20), (2900, 16), (4500, 10), (7000, 6)])
 def test_length_classes_match_oracle(gpu_ctx, oracle, length, depth):
-    """One pack per column class of kernel C (1024 / 1536 / 2048 / 2560 packed int16 rows, 4096 / 6144 32-bit rows):
+    """One pack per column class of kernel C (1024 / 1536 / 2048 / 2560 packed int16 rows, 4096 / 6144 / 8192 32-bit rows):
     noisy copies (sub / ins / del) of one random transcript, deep enough for bubbles, ties and far predecessors."""
     rng = np.random.default_rng(length)
     acgt = np.frombuffer(b"ACGT", np.uint8)

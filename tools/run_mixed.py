@@ -4,7 +4,8 @@ usage: run_mixed.py READS [MAX_READ_LEN_FOR_CORRECT]"""
 import json
 import sys
 import time
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from rattle_amd import synth
 from rattle_amd.api import Context, pack_reads
