@@ -8,6 +8,10 @@
 //
 // HBM traffic per read (algorithmic): L bytes read; per strand (L-k)*8 B list + 512 B
 // bit-vector written, + (L-k)*4 B position-ordered hashes for the forward strand.
+#include <cstring>
+
+#include <rocprim/block/block_radix_sort.hpp>
+
 #include "common.h"
 
 namespace rattle {
@@ -135,6 +139,90 @@ __global__ __launch_bounds__(256) void kmer_extract_kernel(const uint8_t *__rest
     }
 }
 
+// The same index with the list sorted by a block-wide LSD radix sort on the 2k hash bits (rocPRIM's block_radix_sort
+// primitive, keys and positions in registers, digits ranked through LDS): stable, so equal hashes keep their positions
+// ascending = the reference's (hash, pos) order (kmer.cpp:38-41 sorts pairs), and 2k/4 digit passes replace the
+// log^2(P)/2 compare-exchange stages of the bitonic network (55 barriers for a 1 kb read).  Thread t holds the
+// IPT consecutive positions t*IPT .. t*IPT+IPT-1; slots beyond the list carry the largest key and stay behind every real
+// k-mer (stability again).
+template <int IPT>
+__global__ __launch_bounds__(256) void kmer_extract_radix_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                                 const uint64_t *__restrict__ koff, const uint32_t *__restrict__ items,
+                                                                 int k, uint32_t Lmax, uint32_t *__restrict__ uh,
+                                                                 uint32_t *__restrict__ kh0, uint32_t *__restrict__ kp0,
+                                                                 uint32_t *__restrict__ kh1, uint32_t *__restrict__ kp1,
+                                                                 uint64_t *__restrict__ bv0, uint64_t *__restrict__ bv1,
+                                                                 uint32_t *__restrict__ pc0, uint32_t *__restrict__ pc1,
+                                                                 uint32_t *__restrict__ bad_flag) {
+    using sort_t = rocprim::block_radix_sort<uint32_t, 256, IPT, uint32_t>;
+    __shared__ typename sort_t::storage_type sort_storage;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t r = items[blockIdx.x];
+    const int strand = blockIdx.y;
+    const uint64_t o = off[r];
+    const uint32_t L = (uint32_t)(off[r + 1] - o);
+    const uint32_t nk = L > (uint32_t)k ? L - k : 0;
+    const uint32_t nb = L > 6 ? L - 6 : 0;
+    uint32_t *bits = (uint32_t *)smem;               // [bitset 128 u32][codes Lmax bytes]
+    uint8_t *code = smem + 512;
+    (void)Lmax;
+    for (uint32_t t = threadIdx.x; t < 128; t += 256) bits[t] = 0;
+    bool bad = false;
+    for (uint32_t p = threadIdx.x; p < L; p += 256) {
+        uint32_t c = strand == 0 ? base_code(seq[o + p]) : base_code(seq[o + (L - 1 - p)]);
+        if (c > 3) { bad = true; c = 0; }
+        code[p] = (uint8_t)(strand == 0 ? c : (c ^ 2u));
+    }
+    if (bad) atomicOr(bad_flag, 1u);
+    __syncthreads();
+    const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    uint32_t key[IPT], val[IPT];
+    const uint64_t ko = koff[r];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const uint32_t p = threadIdx.x * IPT + i;
+        uint32_t h = 0xFFFFFFFFu;
+        if (p < nk) {
+            h = 0;
+            for (int j = 0; j < k; ++j) h = (h << 2) | code[p + j];
+            h &= kmask;
+            if (strand == 0) uh[ko + p] = h;
+        }
+        key[i] = h; val[i] = p;
+    }
+    for (uint32_t p = threadIdx.x; p < nb; p += 256) {       // kmer.cpp:28-36, always 6-mers
+        uint32_t h = 0;
+        for (int j = 0; j < 6; ++j) h = (h << 2) | code[p + j];
+        atomicOr(&bits[h >> 5], 1u << (h & 31));
+    }
+    sort_t().sort(key, val, sort_storage, 0, (unsigned)(2 * k));
+    uint32_t *kh = strand == 0 ? kh0 : kh1;
+    uint32_t *kp = strand == 0 ? kp0 : kp1;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const uint32_t q = threadIdx.x * IPT + i;
+        if (q < nk) { kh[ko + q] = key[i]; kp[ko + q] = val[i]; }
+    }
+    __syncthreads();
+    uint64_t *bv = strand == 0 ? bv0 : bv1;
+    uint32_t *pc = strand == 0 ? pc0 : pc1;
+    if (threadIdx.x < 64) {
+        uint64_t w = (uint64_t)bits[2 * threadIdx.x] | ((uint64_t)bits[2 * threadIdx.x + 1] << 32);
+        bv[(uint64_t)r * 64 + threadIdx.x] = w;
+        uint32_t c = __popcll(w);
+        for (int sft = 32; sft > 0; sft >>= 1) c += __shfl_xor(c, sft, 64);
+        if (threadIdx.x == 0) pc[r] = c;
+    }
+}
+
+template <int IPT>
+static hipError_t launch_radix(dim3 grid, size_t shm, hipStream_t st, const uint8_t *seq, const uint64_t *off, const uint64_t *koff, const uint32_t *items,
+                               int k, uint32_t Lmax, uint32_t *uh, uint32_t *kh0, uint32_t *kp0, uint32_t *kh1, uint32_t *kp1, uint64_t *bv0, uint64_t *bv1,
+                               uint32_t *pc0, uint32_t *pc1, uint32_t *bad) {
+    hipLaunchKernelGGL(kmer_extract_radix_kernel<IPT>, grid, dim3(256), shm, st, seq, off, koff, items, k, Lmax, uh, kh0, kp0, kh1, kp1, bv0, bv1, pc0, pc1, bad);
+    return hipGetLastError();
+}
+
 static uint32_t pow2ceil(uint32_t x) {
     uint32_t p = 1;
     while (p < x) p <<= 1;
@@ -226,6 +314,25 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
                     rc = d_gs.reserve((size_t)m * ns * P);
                     if (rc) break;
                     gs = d_gs.p;
+                }
+                const bool use_bitonic = getenv("RATTLE_KMER_SORT") && !strcmp(getenv("RATTLE_KMER_SORT"), "bitonic");
+                if (in_lds && !use_bitonic && P >= 256) {
+                    // lists that fit a workgroup's registers: block radix sort, P / 256 keys per thread
+                    const size_t shm2 = 512 + ((Lmax + 15u) & ~15u);
+                    const dim3 grid(m, ns);
+                    const uint32_t *it = d_items.p + done + b;
+#define RADIX(IPT) e = launch_radix<IPT>(grid, shm2, st, X.seq.p, X.off.p, X.koff.p, it, k, Lmax, X.uh.p, X.kh[0].p, X.kp[0].p, X.kh[1].p, X.kp[1].p, X.bv[0].p, X.bv[1].p, X.pc[0].p, X.pc[1].p, d_bad.p)
+                    switch (P / 256) {
+                        case 1: RADIX(1); break;
+                        case 2: RADIX(2); break;
+                        case 4: RADIX(4); break;
+                        case 8: RADIX(8); break;
+                        case 16: RADIX(16); break;
+                        default: RADIX(32); break;
+                    }
+#undef RADIX
+                    if (e != hipSuccess) { set_error(std::string("kmer_extract (radix) launch: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
+                    continue;
                 }
                 if (shm > 64 * 1024 &&
                     hipFuncSetAttribute((const void *)kmer_extract_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) {

@@ -20,9 +20,13 @@ def small_reads():
     return [seqs[i] for i in order]
 
 
+@pytest.mark.parametrize("sort", ["radix", "bitonic"])
 @pytest.mark.parametrize("k", [6, 10, 11, 16])
-def test_kmer_index_matches_oracle(gpu_ctx, oracle, small_reads, k):
-    reads = small_reads[:64] + [b"ACGTAC", b"ACGTACG", b"A" * 40, b"ACGU" * 30]     # edge: L<=k, L=k+1, homopolymer, U
+def test_kmer_index_matches_oracle(gpu_ctx, oracle, small_reads, k, sort, monkeypatch):
+    """Kernel K with both list sorts: the block radix sort (default; lists of 256 .. 8192 k-mers) and the LDS bitonic network
+    (shorter lists, and RATTLE_KMER_SORT=bitonic)."""
+    monkeypatch.setenv("RATTLE_KMER_SORT", sort)
+    reads = small_reads[:64] + [b"ACGTAC", b"ACGTACG", b"A" * 40, b"ACGU" * 30, b"G" * 700 + b"ACGT" * 100]     # edge: L<=k, L=k+1, homopolymers, U
     gpu_ctx.load_reads(reads, k, True)
     for r, s in enumerate(reads):
         fh, fp, rh, rp, bf, br = oracle.extract_kmers(s, k, True)
