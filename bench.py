@@ -218,11 +218,33 @@ def main():
         barrier()
 
     ctx = Context(local)
+    transport = None
     if sharded:
         if a.transport == "gloo" or same_device:
             ctx.set_exchange_gloo()
+            ctx.comm_probe()
+            transport = "gloo(host)"
         else:
-            ctx.comm_init_rccl()
+            # RCCL on device buffers; if the communicator does not come up or its self-test fails on ANY rank, all
+            # ranks fall back together to host buffers over a gloo group (and the JSON line says so)
+            why = ""
+            try:
+                ctx.comm_init_rccl()
+                ctx.comm_probe()
+            except Exception as e:
+                why = str(e)
+            bad = torch.tensor([1 if why else 0], device="cuda")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            transport = "rccl"
+            if int(bad.item()):
+                try:
+                    ctx.comm_destroy()
+                except Exception:
+                    pass
+                host_group = dist.new_group(backend="gloo")
+                ctx.set_exchange_gloo(host_group)
+                ctx.comm_probe()
+                transport = "gloo(host) -- RCCL transport failed its self-test" + (f" on this rank: {why}" if why else " on another rank")
     root = 0 if sharded else None
 
     def step():
@@ -314,7 +336,7 @@ def main():
         }
         if sharded:
             calls, xbytes = ctx.comm_stats()
-            out["exchange"] = {"transport": "gloo(host)" if (a.transport == "gloo" or same_device) else "rccl", "collectives": calls, "bytes_received": xbytes}
+            out["exchange"] = {"transport": transport, "collectives": calls, "bytes_received": xbytes}
         if a.iso:
             out["config"] = {"workload": f"{n_reads} synthetic cDNA reads (mean 1 kb, 10% err, both strands, {genes} genes x 3 isoforms, Zipf abundance), "
                                          "`rattle cluster --iso` k=10 / iso k=11 (BASELINE configs[2])",

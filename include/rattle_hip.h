@@ -272,6 +272,10 @@ int rattle_hip_comm_init(rattle_ctx *ctx, int rank, int nranks, const uint8_t *i
 int rattle_hip_comm_destroy(rattle_ctx *ctx);
 /* statistics of the exchange since context creation: collective calls, payload bytes received */
 int rattle_hip_comm_stats(rattle_ctx *ctx, uint64_t *calls, uint64_t *bytes);
+/* Collective self-test of the attached transport (every rank calls it): one ragged all-gather-v and one gather
+ * to the last rank, contents verified.  0, or RATTLE_ERR_HIP with the damaged piece named.  A launcher runs it
+ * once after rattle_hip_comm_init / rattle_hip_set_exchange, before it trusts the transport with a job. */
+int rattle_hip_comm_probe(rattle_ctx *ctx);
 /* Collective: merges the per-rank results of rattle_hip_correct_reads on `root` (*merged is NULL on the
  * other ranks).  With nranks == 1 it returns a copy. */
 int rattle_hip_correction_gather(rattle_ctx *ctx, const rattle_correction *local, int root, rattle_correction **merged);

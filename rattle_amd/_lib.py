@@ -103,6 +103,7 @@ SIGNATURES = {
     "rattle_hip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),
     "rattle_hip_comm_destroy": (C.c_int, [C.c_void_p]),
     "rattle_hip_comm_stats": (C.c_int, [C.c_void_p, _u64p, _u64p]),
+    "rattle_hip_comm_probe": (C.c_int, [C.c_void_p]),
     "rattle_hip_correction_gather": (C.c_int, [C.c_void_p, _P(Correction), C.c_int, _P(_P(Correction))]),
     "rattle_hip_plan_packs": (C.c_int, [_u64p, C.c_uint32, C.c_uint32, _u32p, _i32p, _u8p, _P(CorrectParams), C.c_int,
                                         _P(_P(PackPlan))]),

@@ -425,6 +425,10 @@ class Context:
     def comm_destroy(self):
         check(self.lib.rattle_hip_comm_destroy(self.h))
 
+    def comm_probe(self):
+        """Collective self-test of the attached transport (all ranks)."""
+        check(self.lib.rattle_hip_comm_probe(self.h))
+
     def comm_stats(self):
         a = C.c_uint64(); b = C.c_uint64()
         check(self.lib.rattle_hip_comm_stats(self.h, C.byref(a), C.byref(b)))

@@ -44,9 +44,11 @@ rccl_api &rccl() { static rccl_api A; return A; }
 int load_rccl() {
     rccl_api &A = rccl();
     if (A.h) return 0;
+    const char *chosen = getenv("RATTLE_RCCL_LIB");                 // a particular RCCL build (or the tests' double)
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) { A.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (A.h) break; }
-    if (!A.h) { set_error(std::string("librccl.so not found: ") + dlerror()); return RATTLE_ERR_HIP; }
+    if (chosen && *chosen) A.h = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+    else for (const char *n : names) { A.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (A.h) break; }
+    if (!A.h) { set_error(std::string(chosen && *chosen ? chosen : "librccl.so") + " not loadable: " + dlerror()); return RATTLE_ERR_HIP; }
 #define SYM(field, name) *(void **)(&A.field) = dlsym(A.h, name); if (!A.field) { set_error("librccl.so lacks " name); A.h = nullptr; return RATTLE_ERR_HIP; }
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
@@ -396,6 +398,28 @@ int rattle_hip_comm_stats(rattle_ctx *c, uint64_t *calls, uint64_t *bytes) {
     if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
     if (calls) *calls = c->xchg.calls;
     if (bytes) *bytes = c->xchg.bytes;
+    return 0;
+}
+
+int rattle_hip_comm_probe(rattle_ctx *c) {
+    if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
+    exchange &X = c->xchg;
+    if (c->device >= 0) RT_HIP(hipSetDevice(c->device));
+    // ragged pieces (one of them empty) through both exchange shapes the sharded paths use
+    std::vector<uint8_t> mine((size_t)((X.rank * 1000 + 7) % 2501) * (X.rank % 3 != 1), (uint8_t)(X.rank + 1));
+    std::vector<std::vector<uint8_t>> all;
+    RT_TRY(xchg_allgatherv(c, mine, all));
+    for (int root = 0; root <= (X.nranks > 1); ++root) {
+        for (int r = 0; r < X.nranks; ++r) {
+            const size_t want = (size_t)((r * 1000 + 7) % 2501) * (r % 3 != 1);
+            bool ok = all[r].size() == want;
+            for (size_t i = 0; ok && i < want; ++i) ok = all[r][i] == (uint8_t)(r + 1);
+            if (!ok) { set_error("exchange probe: the piece of rank " + std::to_string(r) + " arrived damaged on rank " + std::to_string(X.rank)); return RATTLE_ERR_HIP; }
+        }
+        if (root == 1) break;
+        RT_TRY(xchg_gatherv(c, mine, X.nranks - 1, all));
+        if (X.rank != X.nranks - 1) break;
+    }
     return 0;
 }
 

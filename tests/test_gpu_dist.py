@@ -1,6 +1,6 @@
 """ONE job over several ranks with the real kernels: two (and three) processes share the box's single GPU, the
-exchange goes through host buffers (gloo) -- RCCL wants one GPU per rank, which the driver's 8-GPU run provides
--- and every sharded result must equal the unsharded one bit for bit: gene-level clusters (candidate axis),
+exchange goes through host buffers (gloo) or through exchange.hip's RCCL call path over a file-backed double of
+librccl.so (RCCL wants one GPU per rank, which only the driver's 8-GPU run provides), and every sharded result must equal the unsharded one bit for bit: gene-level clusters (candidate axis),
 `--iso` transcript clusters (gene axis), and the three outputs of `correct` (pack axis, reassembled on rank 0).
 The RCCL transport itself is exercised with a world of one rank."""
 import os
@@ -34,7 +34,11 @@ WORKER = textwrap.dedent('''
         c0.close()
     dist.barrier()
     ctx = Context(0)
-    ctx.set_exchange_gloo()
+    if os.environ.get("RATTLE_RCCL_LIB"):
+        ctx.comm_init_rccl()                       # the device-buffer transport (RCCL call pattern) over the tests' double
+    else:
+        ctx.set_exchange_gloo()
+    ctx.comm_probe()
     cl = ctx.cluster_unsorted_packed(cat, off)
     res = ctx.correct_packed(cat, qcat, off, cl, split=40, digest=True, gather_root=0)
     iso, gid, ng = ctx.cluster_iso_unsorted_packed(cat, off)
@@ -56,13 +60,30 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_job_equals_single_gpu(tmp_path, world):
+def fake_rccl(tmp_path):
+    """tests/stubs/fake_rccl.cpp built into the test's directory: librccl's entry points over files, several ranks per GPU."""
+    so = tmp_path / "libfake_rccl.so"
+    r = subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "stubs", "fake_rccl.cpp"),
+                        "-o", str(so), "-L/opt/rocm/lib", "-lamdhip64"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    box = tmp_path / "mailbox"
+    box.mkdir()
+    return {"RATTLE_RCCL_LIB": str(so), "FAKE_RCCL_DIR": str(box)}
+
+
+@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (2, "device"), (3, "device")])
+def test_sharded_job_equals_single_gpu(tmp_path, world, transport):
+    """transport "host": the caller's all-gather-v on host buffers (gloo); "device": the RCCL code path of exchange.hip
+    (sizes all-gather, grouped broadcasts, grouped send / recv to the root) with the file-backed double standing in
+    for librccl.so, since RCCL itself refuses two ranks on one device."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, RATTLE_ROOT=ROOT, MASTER_ADDR="127.0.0.1", RATTLE_HOST_THREADS="8")
+    env.pop("RATTLE_RCCL_LIB", None)
+    if transport == "device":
+        env.update(fake_rccl(tmp_path))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29700 + world), str(script)], capture_output=True, text=True, env=env, timeout=900)
+                        "--master-port", str(29700 + world + (10 if transport == "device" else 0)), str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert f"GPU_DIST_OK {world}" in r.stdout
 
