@@ -188,9 +188,8 @@ int rattle_hip_cluster_subset(rattle_ctx *c, const rattle_cluster_params *P, con
 }
 
 // Many independent subsets at once (the --iso second level: one subset per gene cluster).  Small
-// problems are launch- and synchronisation-bound, so worker threads run the unchanged greedy driver on
-// child contexts (own stream and scratch buffers, the parent's read index shared read-only) and the
-// device overlaps their kernels.
+// problems are launch- and synchronisation-bound, so the subsets' greedy rounds advance in lockstep and every
+// round is ONE evaluation on the device (cluster_driver.hip: cluster_driver_many).
 int rattle_hip_cluster_subsets(rattle_ctx *c, const rattle_cluster_params *P, const uint32_t *ids, const uint64_t *sub_off,
                                uint32_t n_subsets, rattle_cluster_set **outs, int n_workers) {
     if (!c || !P || !outs || !sub_off || (n_subsets && sub_off[n_subsets] && !ids)) { set_error("null argument"); return RATTLE_ERR_ARG; }
@@ -216,48 +215,10 @@ int rattle_hip_cluster_subsets(rattle_ctx *c, const rattle_cluster_params *P, co
         const uint64_t la = sub_off[a + 1] - sub_off[a], lb = sub_off[b + 1] - sub_off[b];
         return la != lb ? la > lb : a < b;
     });
-    const uint32_t n_mine = (uint32_t)order.size();
-    if (n_workers <= 0 && getenv("RATTLE_ISO_WORKERS")) n_workers = atoi(getenv("RATTLE_ISO_WORKERS"));
-    const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(n_mine, n_workers > 0 ? (uint32_t)n_workers : 16u));
-    std::atomic<uint32_t> next(0);
-    std::atomic<int> rc_all(0);
-    std::mutex err_mu;
-    std::string err_msg;
-    auto worker = [&]() {
-        static const uint32_t none = 0;
-        int rc = 0;
-        rattle_ctx *k = new rattle_ctx();
-        k->device = c->device;
-        k->timing = false;
-        if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&k->ev0) != hipSuccess || hipEventCreate(&k->ev1) != hipSuccess) {
-            set_error("worker stream/event creation failed");
-            rc = RATTLE_ERR_HIP;
-        }
-        if (rc == 0) {
-            read_index &X = k->idx;                              // shared, read-only view of the parent's index
-            const read_index &Y = c->idx;
-            X.n = Y.n; X.k = Y.k; X.both = Y.both; X.total_bases = Y.total_bases; X.total_kmers = Y.total_kmers;
-            X.h_len = Y.h_len;
-            X.seq.borrow(Y.seq); X.off.borrow(Y.off); X.koff.borrow(Y.koff); X.len.borrow(Y.len); X.uh.borrow(Y.uh);
-            for (int s = 0; s < 2; ++s) { X.kh[s].borrow(Y.kh[s]); X.kp[s].borrow(Y.kp[s]); X.bv[s].borrow(Y.bv[s]); X.pc[s].borrow(Y.pc[s]); }
-            for (uint32_t t = next++; t < n_mine && rc == 0 && rc_all.load() == 0; t = next++) {
-                const uint32_t i = order[t];
-                const uint32_t n = (uint32_t)(sub_off[i + 1] - sub_off[i]);
-                rc = cluster_driver(k, P, n ? ids + sub_off[i] : &none, n, &outs[i]);
-            }
-        }
-        if (rc != 0) {
-            std::lock_guard<std::mutex> g(err_mu);
-            if (rc_all.load() == 0) { rc_all = rc; err_msg = rattle_hip_last_error(); }
-        }
-        delete k;                                                // borrowed index buffers stay with the parent
-    };
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < T; ++t) th.emplace_back(worker);
-    for (auto &x : th) x.join();
-    int rc = rc_all.load();
-    if (rc != 0) set_error(err_msg);
+    (void)n_workers;                                              // round 1 ran one host thread per worker; the subsets now advance in lockstep
+    int rc = cluster_driver_many(c, P, ids, sub_off, order.data(), (uint32_t)order.size(), outs);
+    std::string err_msg = rc != 0 ? rattle_hip_last_error() : "";
+    if (rc != 0) for (uint32_t i : order) { rattle_hip_cluster_set_free(outs[i]); outs[i] = nullptr; }
     if (R > 1) {
         // all ranks take part in the exchange even after a local failure (an empty payload marks it)
         std::vector<uint8_t> mine;

@@ -17,12 +17,16 @@ namespace rattle {
 #define BVF_TS 32
 #define BVF_TC 256
 
+// One launch covers a LIST of rectangles (seeds [s_base, s_base+ns) x candidates [c_base, c_base+nc) of the uploaded
+// seed / candidate arrays): the greedy rounds of many independent clusterings (the gene clusters of `--iso`,
+// main.cpp:281-318) advance in lockstep and share the launch.  Rectangle j owns tiles [tile_base_j, tile_base_{j+1});
+// a workgroup finds its rectangle by bisection.  first_cand[] is in the index space of the candidate array.
 template <bool BOTH>
 __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restrict__ bvf, const uint64_t *__restrict__ bvr,
                                                         const uint32_t *__restrict__ pcf, const uint32_t *__restrict__ seed_ids,
-                                                        uint32_t n_seeds, const uint32_t *__restrict__ cand_ids, uint32_t n_cands,
-                                                        const uint32_t *__restrict__ first_cand, const uint16_t *__restrict__ lut,
-                                                        int fwd_bypass, uint8_t *__restrict__ dense, uint32_t *__restrict__ list,
+                                                        const uint32_t *__restrict__ cand_ids, const bvf_rect *__restrict__ rects, uint32_t n_rects,
+                                                        const uint32_t *__restrict__ first_cand, const uint16_t *__restrict__ luts,
+                                                        uint8_t *__restrict__ dense, uint32_t *__restrict__ list,
                                                         uint32_t list_cap, uint32_t *__restrict__ list_count) {
     __shared__ __attribute__((aligned(16))) uint64_t s_bv[BVF_TS][64];
     __shared__ uint32_t s_pc[BVF_TS];
@@ -30,10 +34,20 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
     __shared__ uint32_t s_minfirst;
     __shared__ uint16_t s_cf[BOTH ? BVF_TS : 1][BVF_TC];     // forward counts parked while the reverse vector is in registers
 
-    const uint32_t s0 = blockIdx.y * BVF_TS;
-    const uint32_t ns = min((uint32_t)BVF_TS, n_seeds - s0);
-    const uint32_t c0 = blockIdx.x * BVF_TC;
+    uint32_t lo = 0, hi = n_rects;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rects[mid].tile_base <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const bvf_rect J = rects[lo];
+    const uint32_t tile = blockIdx.x - J.tile_base, cand_tiles = (J.nc + BVF_TC - 1) / BVF_TC;
+    const uint32_t s0 = J.s_base + (tile / cand_tiles) * BVF_TS;
+    const uint32_t ns = min((uint32_t)BVF_TS, J.s_base + J.ns - s0);
+    const uint32_t c0 = J.c_base + (tile % cand_tiles) * BVF_TC;
     const uint32_t c = c0 + threadIdx.x;
+    const uint32_t n_cands = J.c_base + J.nc;                 // end of this rectangle's candidates
+    const uint16_t *__restrict__ lut = luts + J.lut_off;
+    const int fwd_bypass = (int)J.fwd_bypass;
 
     if (threadIdx.x == 0) s_minfirst = 0xFFFFFFFFu;
     __syncthreads();
@@ -47,7 +61,7 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
     // whole candidate tile lies before every seed's first candidate: nothing to do
     if (c0 + BVF_TC <= s_minfirst) {
         if (dense && c < n_cands)
-            for (uint32_t s = 0; s < ns; ++s) dense[(uint64_t)(s0 + s) * n_cands + c] = 0;
+            for (uint32_t s = 0; s < ns; ++s) dense[(uint64_t)(s0 - J.s_base + s) * J.nc + (c - J.c_base)] = 0;
         return;
     }
     for (uint32_t t = threadIdx.x; t < ns * 64; t += blockDim.x) {
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
             if (fwd_bypass || common_f >= need) res |= 1u;     // cluster.cpp:19
             if (BOTH && common_r >= need) res |= 2u;           // cluster.cpp:43
         }
-        if (dense) dense[(uint64_t)(s0 + s) * n_cands + c] = (uint8_t)res;
+        if (dense) dense[(uint64_t)(s0 - J.s_base + s) * J.nc + (c - J.c_base)] = (uint8_t)res;
         if (list && res) {
             uint32_t cnt = (res & 1u) + ((res >> 1) & 1u);
             uint32_t at = atomicAdd(list_count, cnt);
@@ -118,25 +132,34 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
     }
 }
 
-int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fwd_bypass, bool dense, bool list,
-                     uint32_t list_cap) {
-    if (n_seeds == 0 || n_cands == 0) return 0;
+// rectangles already uploaded (d_rect), tile_base filled by the caller; n_tiles = their total
+int launch_bv_filter_rects(rattle_ctx *ctx, uint32_t n_rects, uint32_t n_tiles, uint64_t pairs, bool dense, bool list, uint32_t list_cap) {
+    if (n_rects == 0 || n_tiles == 0) return 0;
     read_index &X = ctx->idx;
-    dim3 grid((n_cands + BVF_TC - 1) / BVF_TC, (n_seeds + BVF_TS - 1) / BVF_TS);
-    uint64_t pairs = (uint64_t)n_seeds * n_cands;
     ktimer T(ctx, K_FILTER, pairs * (512ull * (1 + X.both) + 2));
     if (X.both)
-        hipLaunchKernelGGL(bv_filter_kernel<true>, grid, dim3(256), 0, ctx->stream, X.bv[0].p, X.bv[1].p, X.pc[0].p,
-                           ctx->d_seed.p, n_seeds, ctx->d_cand.p, n_cands, ctx->d_first.p, ctx->d_lut.p, fwd_bypass,
+        hipLaunchKernelGGL(bv_filter_kernel<true>, dim3(n_tiles), dim3(256), 0, ctx->stream, X.bv[0].p, X.bv[1].p, X.pc[0].p,
+                           ctx->d_seed.p, ctx->d_cand.p, ctx->d_rect.p, n_rects, ctx->d_first.p, ctx->d_lut.p,
                            dense ? ctx->d_pass.p : nullptr, list ? ctx->d_surv.p : nullptr, list_cap, ctx->d_counter.p);
     else
-        hipLaunchKernelGGL(bv_filter_kernel<false>, grid, dim3(256), 0, ctx->stream, X.bv[0].p, (const uint64_t *)nullptr,
-                           X.pc[0].p, ctx->d_seed.p, n_seeds, ctx->d_cand.p, n_cands, ctx->d_first.p, ctx->d_lut.p,
-                           fwd_bypass, dense ? ctx->d_pass.p : nullptr, list ? ctx->d_surv.p : nullptr, list_cap,
-                           ctx->d_counter.p);
+        hipLaunchKernelGGL(bv_filter_kernel<false>, dim3(n_tiles), dim3(256), 0, ctx->stream, X.bv[0].p, (const uint64_t *)nullptr,
+                           X.pc[0].p, ctx->d_seed.p, ctx->d_cand.p, ctx->d_rect.p, n_rects, ctx->d_first.p, ctx->d_lut.p,
+                           dense ? ctx->d_pass.p : nullptr, list ? ctx->d_surv.p : nullptr, list_cap, ctx->d_counter.p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("bv_filter launch: ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
     return 0;
+}
+
+// one rectangle: all seeds x all candidates of ctx->d_seed / d_cand, look-up table at d_lut[0..4096]
+int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fwd_bypass, bool dense, bool list,
+                     uint32_t list_cap) {
+    if (n_seeds == 0 || n_cands == 0) return 0;
+    const bvf_rect one = {0u, n_seeds, 0u, n_cands, 0u, 0u, (uint32_t)fwd_bypass, 0u};
+    RT_TRY(ctx->d_rect.reserve(1));
+    RT_HIP(hipMemcpyAsync(ctx->d_rect.p, &one, sizeof one, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));                 // `one` lives on this frame
+    const uint32_t tiles = ((n_cands + BVF_TC - 1) / BVF_TC) * ((n_seeds + BVF_TS - 1) / BVF_TS);
+    return launch_bv_filter_rects(ctx, 1, tiles, (uint64_t)n_seeds * n_cands, dense, list, list_cap);
 }
 
 }  // namespace rattle

@@ -14,6 +14,12 @@
 // (cluster.cpp:138-158: thread t takes candidates t, t+T, ...).  Here rank r of R scores the candidates at
 // positions r, r+R, ... of every level-2 evaluation (level 1, 256 x 256, is replicated), the accepted
 // (seed, candidate, strand) triples are all-gathered and every rank resolves them identically.
+//
+// Many independent clusterings at once (`--iso`: one per gene cluster, main.cpp:281-318, which the reference
+// runs one after another): every clustering is a small state machine (`job`) that stops whenever it needs a
+// rectangle of cluster_together verdicts; the rectangles of all jobs that are waiting go to the device in ONE
+// evaluation (kernel A over the rectangle list, kernel B over the union of the surviving pairs), the verdicts
+// are dealt back and the jobs advance.  A round costs a handful of launches whatever the number of genes.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -37,26 +43,43 @@ __global__ void expand_pairs_kernel(const uint32_t *__restrict__ surv, uint32_t 
     ps[t] = (uint8_t)(a & 1u);
 }
 
+namespace {
+
 struct hit_t { uint32_t seed, cand; uint8_t rev; };
 
 struct cseq { int32_t id; uint8_t rev; };
 
-struct driver {
+// one rectangle of cluster_together(i, j) evaluations a job waits for
+struct request {
+    std::vector<uint32_t> seeds, cands;       // loaded-read ids; triangular: candidates = the seeds, pairs (s, c > s) only
+    bool triangular = false;
+    double thr = 0.0;                         // bit-vector threshold of the pass (cluster.cpp:19,43)
+    uint64_t *counters = nullptr;             // the job's work counters
+    std::vector<hit_t> hits;                  // out: accepted (seed index, candidate index, strand), sorted
+    uint32_t n_cands() const { return (uint32_t)(triangular ? seeds.size() : cands.size()); }
+    uint64_t n_pairs() const {
+        const uint64_t s = seeds.size();
+        return triangular ? s * (s - 1) / 2 : s * (uint64_t)cands.size();
+    }
+};
+
+// ---- device evaluation of a set of rectangles -------------------------------------------------------------
+struct evaluator {
     rattle_ctx *ctx;
     const rattle_cluster_params *P;
-    const uint32_t *subset;          // local id -> loaded read id (nullptr = identity)
-    uint32_t n;
-    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint16_t lut[4097];
-    double lut_thr = -1.0;
-    std::vector<uint32_t> tmp_seed, tmp_cand, tmp_first;
-
-    uint32_t rid(uint32_t local) const { return subset ? subset[local] : local; }
-    uint32_t rlen(uint32_t local) const { return ctx->idx.h_len[rid(local)]; }
+    uint64_t launches = 0;
+    std::vector<double> lut_thr;              // row r of the device table belongs to threshold lut_thr[r]
+    std::vector<uint16_t> luts;
+    std::vector<uint32_t> h_seed, h_cand, h_first, seed_req;
+    std::vector<bvf_rect> rects;
 
     // min_common_lut[m] = smallest c with double(c)/double(m) >= thr  (cluster.cpp:19,43)
-    int set_threshold(double thr) {
-        if (thr == lut_thr) return 0;
+    int lut_row(double thr, uint32_t &row) {
+        for (size_t r = 0; r < lut_thr.size(); ++r) if (lut_thr[r] == thr) { row = (uint32_t)r; return 0; }
+        row = (uint32_t)lut_thr.size();
+        lut_thr.push_back(thr);
+        luts.resize((size_t)(row + 1) * 4097);
+        uint16_t *lut = luts.data() + (size_t)row * 4097;
         for (int m = 0; m <= 4096; ++m) {
             double mmax = (double)m;
             int need = 0xFFFF;
@@ -70,74 +93,121 @@ struct driver {
             }
             lut[m] = (uint16_t)need;
         }
-        lut_thr = thr;
-        RT_TRY(ctx->d_lut.reserve(4097));
-        RT_HIP(hipMemcpyAsync(ctx->d_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice, ctx->stream));
-        RT_HIP(hipStreamSynchronize(ctx->stream));   // lut[] may be rewritten by the next call
+        RT_TRY(ctx->d_lut.reserve(luts.size()));
+        RT_HIP(hipMemcpyAsync(ctx->d_lut.p, luts.data(), luts.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(hipStreamSynchronize(ctx->stream));   // luts may move on the next push
         return 0;
     }
 
-    // Evaluate cluster_together for every (seed s, cand c >= first[s]); seeds/cands are LOCAL ids.
-    // shard: this rank scores the candidates at positions rank, rank + nranks, ... and the hits of all ranks
-    // are all-gathered (every rank ends up with the same list; the callers sort it).
-    std::vector<uint32_t> sh_cands, sh_first;
-    int eval(const std::vector<uint32_t> &seeds, const uint32_t *cands, uint32_t n_cands, const std::vector<uint32_t> &first,
-             double thr, std::vector<hit_t> &hits, bool shard = false) {
+    // All requests of one greedy step.  shard: this rank scores the candidates at positions rank, rank + nranks, ...
+    // of the (single, rectangular) request and the hits of all ranks are all-gathered.
+    int run(std::vector<request *> &reqs, bool shard) {
         const int R = ctx->xchg.nranks, r = ctx->xchg.rank;
-        if (!shard || R <= 1) return eval_local(seeds, cands, n_cands, first, thr, hits);
-        sh_cands.clear();
-        for (uint32_t c = (uint32_t)r; c < n_cands; c += (uint32_t)R) sh_cands.push_back(cands[c]);
-        sh_first.resize(first.size());
-        for (size_t i = 0; i < first.size(); ++i) sh_first[i] = first[i] <= (uint32_t)r ? 0u : (first[i] - (uint32_t)r + (uint32_t)R - 1u) / (uint32_t)R;
-        uint64_t before[3] = {counters[0], counters[1], counters[2]};
-        RT_TRY(eval_local(seeds, sh_cands.data(), (uint32_t)sh_cands.size(), sh_first, thr, hits));
-        // payload: three counter deltas, then (seed, global candidate position, strand) triples
-        std::vector<uint8_t> mine(24 + hits.size() * 12);
-        for (int i = 0; i < 3; ++i) { const uint64_t d = counters[i] - before[i]; memcpy(mine.data() + 8 * i, &d, 8); counters[i] = before[i]; }
-        for (size_t i = 0; i < hits.size(); ++i) {
-            const uint32_t t[3] = {hits[i].seed, hits[i].cand * (uint32_t)R + (uint32_t)r, hits[i].rev};
-            memcpy(mine.data() + 24 + 12 * i, t, 12);
-        }
-        std::vector<std::vector<uint8_t>> all;
-        RT_TRY(xchg_allgatherv(ctx, mine, all));
-        hits.clear();
-        for (const std::vector<uint8_t> &b : all) {
-            if (b.size() < 24 || (b.size() - 24) % 12) { set_error("cluster exchange: malformed hit list"); return RATTLE_ERR_HIP; }
-            for (int i = 0; i < 3; ++i) { uint64_t d; memcpy(&d, b.data() + 8 * i, 8); counters[i] += d; }
-            for (size_t at = 24; at < b.size(); at += 12) {
-                uint32_t t[3];
-                memcpy(t, b.data() + at, 12);
-                hits.push_back(hit_t{t[0], t[1], (uint8_t)t[2]});
+        if (shard && R > 1) {
+            if (reqs.size() != 1 || reqs[0]->triangular) { set_error("sharded evaluation takes one rectangular request"); return RATTLE_ERR_STATE; }
+            request &q = *reqs[0];
+            request mine;
+            mine.seeds = q.seeds; mine.thr = q.thr; mine.counters = q.counters;
+            for (uint32_t c = (uint32_t)r; c < q.cands.size(); c += (uint32_t)R) mine.cands.push_back(q.cands[c]);
+            uint64_t before[3] = {q.counters[0], q.counters[1], q.counters[2]};
+            std::vector<request *> one{&mine};
+            RT_TRY(run_chunks(one));
+            // payload: three counter deltas, then (seed, global candidate position, strand) triples
+            std::vector<uint8_t> pay(24 + mine.hits.size() * 12);
+            for (int i = 0; i < 3; ++i) { const uint64_t d = q.counters[i] - before[i]; memcpy(pay.data() + 8 * i, &d, 8); q.counters[i] = before[i]; }
+            for (size_t i = 0; i < mine.hits.size(); ++i) {
+                const uint32_t t[3] = {mine.hits[i].seed, mine.hits[i].cand * (uint32_t)R + (uint32_t)r, mine.hits[i].rev};
+                memcpy(pay.data() + 24 + 12 * i, t, 12);
             }
+            std::vector<std::vector<uint8_t>> all;
+            RT_TRY(xchg_allgatherv(ctx, pay, all));
+            q.hits.clear();
+            for (const std::vector<uint8_t> &b : all) {
+                if (b.size() < 24 || (b.size() - 24) % 12) { set_error("cluster exchange: malformed hit list"); return RATTLE_ERR_HIP; }
+                for (int i = 0; i < 3; ++i) { uint64_t d; memcpy(&d, b.data() + 8 * i, 8); q.counters[i] += d; }
+                for (size_t at = 24; at < b.size(); at += 12) {
+                    uint32_t t[3];
+                    memcpy(t, b.data() + at, 12);
+                    q.hits.push_back(hit_t{t[0], t[1], (uint8_t)t[2]});
+                }
+            }
+            sort_hits(q.hits);
+            return 0;
+        }
+        return run_chunks(reqs);
+    }
+
+    static void sort_hits(std::vector<hit_t> &hits) {
+        std::sort(hits.begin(), hits.end(), [](const hit_t &a, const hit_t &b) {
+            return a.seed != b.seed ? a.seed < b.seed : (a.cand != b.cand ? a.cand < b.cand : a.rev < b.rev);
+        });
+    }
+
+    // Every pair can survive the filter, and in the thr == 0 pass every pair does (cluster.cpp:19,43): one launch
+    // keeps its pairs x strands below the 32-bit survivor counter, and below 64 M where all of them survive.
+    int run_chunks(std::vector<request *> &reqs) {
+        const uint64_t strands = ctx->idx.both ? 2u : 1u;
+        size_t a = 0;
+        while (a < reqs.size()) {
+            uint64_t all_pairs = 0, sure = 0;
+            size_t b = a;
+            while (b < reqs.size()) {
+                const uint64_t p = reqs[b]->n_pairs() * strands;
+                const uint64_t s = reqs[b]->thr == 0.0 ? p : 0;
+                if (b > a && (all_pairs + p > (1ull << 31) || sure + s > (64ull << 20))) break;
+                all_pairs += p; sure += s;
+                ++b;
+            }
+            RT_TRY(run_local(reqs.data() + a, b - a));
+            a = b;
         }
         return 0;
     }
 
-    int eval_local(const std::vector<uint32_t> &seeds, const uint32_t *cands, uint32_t n_cands, const std::vector<uint32_t> &first,
-                   double thr, std::vector<hit_t> &hits) {
-        hits.clear();
-        uint32_t ns = (uint32_t)seeds.size();
-        if (ns == 0 || n_cands == 0) return 0;
+    int run_local(request **reqs, size_t nreq) {
         hipStream_t st = ctx->stream;
-        tmp_seed.resize(ns);
-        for (uint32_t i = 0; i < ns; ++i) tmp_seed[i] = rid(seeds[i]);
-        const uint32_t *cand_rids = cands;
-        if (subset) {
-            tmp_cand.resize(n_cands);
-            for (uint32_t i = 0; i < n_cands; ++i) tmp_cand[i] = subset[cands[i]];
-            cand_rids = tmp_cand.data();
+        const read_index &X = ctx->idx;
+        // ---- the rectangles side by side in one seed array and one candidate array
+        uint64_t ns = 0, nc = 0, npairs = 0;
+        for (size_t q = 0; q < nreq; ++q) {
+            reqs[q]->hits.clear();
+            if (reqs[q]->seeds.empty() || reqs[q]->n_cands() == 0) continue;
+            ns += reqs[q]->seeds.size(); nc += reqs[q]->n_cands();
         }
-        RT_TRY(ctx->d_seed.reserve(ns));
-        RT_TRY(ctx->d_first.reserve(ns));
-        RT_TRY(ctx->d_cand.reserve(n_cands));
-        RT_TRY(ctx->d_counter.reserve(4));
-        RT_TRY(ctx->h_counter.reserve(4));
-        RT_HIP(hipMemcpyAsync(ctx->d_seed.p, tmp_seed.data(), ns * 4, hipMemcpyHostToDevice, st));
-        RT_HIP(hipMemcpyAsync(ctx->d_first.p, first.data(), ns * 4, hipMemcpyHostToDevice, st));
-        RT_HIP(hipMemcpyAsync(ctx->d_cand.p, cand_rids, (size_t)n_cands * 4, hipMemcpyHostToDevice, st));
-        uint64_t npairs = 0;
-        for (uint32_t i = 0; i < ns; ++i) npairs += n_cands > first[i] ? n_cands - first[i] : 0;
-        counters[0] += npairs;
+        if (ns == 0 || nc == 0) return 0;
+        if (ns >= (1u << 31) || nc >= 0xFFFFFFF0ull) { set_error("cluster evaluation: too many seeds or candidates in one step"); return RATTLE_ERR_ARG; }
+        h_seed.resize(ns); h_first.resize(ns); h_cand.resize(nc);
+        rects.clear();
+        const bool many = nreq > 1;
+        if (many) seed_req.resize(ns);
+        std::vector<uint32_t> rect_req;
+        uint32_t sb = 0, cb = 0, tiles = 0;
+        for (size_t q = 0; q < nreq; ++q) {
+            request &Q = *reqs[q];
+            const uint32_t qs = (uint32_t)Q.seeds.size(), qc = Q.n_cands();
+            if (qs == 0 || qc == 0) continue;
+            uint32_t row = 0;
+            RT_TRY(lut_row(Q.thr, row));
+            memcpy(h_seed.data() + sb, Q.seeds.data(), (size_t)qs * 4);
+            memcpy(h_cand.data() + cb, Q.triangular ? Q.seeds.data() : Q.cands.data(), (size_t)qc * 4);
+            for (uint32_t s = 0; s < qs; ++s) h_first[sb + s] = cb + (Q.triangular ? s + 1 : 0u);
+            if (many) for (uint32_t s = 0; s < qs; ++s) seed_req[sb + s] = (uint32_t)rects.size();
+            rects.push_back(bvf_rect{sb, qs, cb, qc, tiles, row * 4097u, Q.thr == 0.0 ? 1u : 0u, 0u});
+            rect_req.push_back((uint32_t)q);
+            tiles += ((qc + 255u) / 256u) * ((qs + 31u) / 32u);
+            const uint64_t p = Q.n_pairs();
+            Q.counters[0] += p;
+            npairs += p;
+            sb += qs; cb += qc;
+        }
+        const uint32_t nrect = (uint32_t)rects.size();
+        RT_TRY(ctx->d_seed.reserve(ns)); RT_TRY(ctx->d_first.reserve(ns)); RT_TRY(ctx->d_cand.reserve(nc));
+        RT_TRY(ctx->d_rect.reserve(nrect));
+        RT_TRY(ctx->d_counter.reserve(4)); RT_TRY(ctx->h_counter.reserve(4));
+        RT_HIP(hipMemcpyAsync(ctx->d_seed.p, h_seed.data(), ns * 4, hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(ctx->d_first.p, h_first.data(), ns * 4, hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(ctx->d_cand.p, h_cand.data(), nc * 4, hipMemcpyHostToDevice, st));
+        RT_HIP(hipMemcpyAsync(ctx->d_rect.p, rects.data(), (size_t)nrect * sizeof(bvf_rect), hipMemcpyHostToDevice, st));
 
         // survivor capacity: grow and retry on overflow (count is exact even when truncated)
         size_t cap = std::max<size_t>(ctx->d_surv.cap / 2, 1u << 20);
@@ -146,8 +216,8 @@ struct driver {
             RT_TRY(ctx->d_surv.reserve(cap * 2));
             cap = ctx->d_surv.cap / 2;
             RT_HIP(hipMemsetAsync(ctx->d_counter.p, 0, 16, st));
-            RT_TRY(launch_bv_filter(ctx, ns, n_cands, thr == 0.0 ? 1 : 0, false, true, (uint32_t)std::min<size_t>(cap, 0xFFFFFFF0u)));
-            counters[4]++;
+            RT_TRY(launch_bv_filter_rects(ctx, nrect, tiles, npairs, false, true, (uint32_t)std::min<size_t>(cap, 0xFFFFFFF0u)));
+            ++launches;
             RT_HIP(hipMemcpyAsync(ctx->h_counter.p, ctx->d_counter.p, 4, hipMemcpyDeviceToHost, st));
             RT_HIP(hipStreamSynchronize(st));
             nsurv = ctx->h_counter.p[0];
@@ -156,7 +226,6 @@ struct driver {
             cap = (size_t)nsurv + nsurv / 8;
         }
         if (nsurv == 0) return 0;
-        counters[1] += nsurv;
 
         RT_TRY(ctx->d_pi.reserve(nsurv));
         RT_TRY(ctx->d_pj.reserve(nsurv));
@@ -171,25 +240,27 @@ struct driver {
         // with double(k * |common|) / min_len < t_s cannot pass cluster.cpp:23-27 whatever its chain looks like: exact
         // rejection without the patience search.  In the low-threshold merge passes that is nearly every pair.
         RT_TRY(launch_pair_count(ctx, nsurv));
-        counters[4] += 2;
+        launches += 2;
         RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 4, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
         const double t_s = P->t_s, t_v = P->t_v;
-        const uint32_t kk = (uint32_t)ctx->idx.k;
-        uint64_t alg_bytes = 0;
+        const uint32_t kk = (uint32_t)X.k;
         // tens of millions of survivors per level-2 round: chunks in parallel, results concatenated in pair order
         const uint32_t chunk = 1u << 16;
         const uint32_t n_chunks = (nsurv + chunk - 1) / chunk;
         std::vector<std::vector<uint32_t>> part(n_chunks);
         std::vector<uint64_t> part_matches(n_chunks, 0), part_bytes(n_chunks, 0);
+        std::vector<std::vector<uint64_t>> part_req(many ? n_chunks : 0);       // per rectangle: survivors, matches
         parallel_for(n_chunks, n_chunks > 1 ? 0 : 1, [&](size_t ch) {
             uint64_t mt = 0, ab = 0;
+            if (many) part_req[ch].assign((size_t)nrect * 2, 0);
             const uint32_t p1 = std::min<uint32_t>(nsurv, (uint32_t)(ch + 1) * chunk);
             for (uint32_t p = (uint32_t)ch * chunk; p < p1; ++p) {
                 const uint32_t a = ctx->h_surv.p[2 * (size_t)p], c = ctx->h_surv.p[2 * (size_t)p + 1];
                 const uint64_t M = (uint32_t)ctx->h_res.p[p];
                 mt += M;
-                const uint32_t li = rlen(seeds[a >> 1]), lj = rlen(cands[c]);
+                if (many) { uint64_t *pr = part_req[ch].data() + 2 * (size_t)seed_req[a >> 1]; pr[0] += 1; pr[1] += M; }
+                const uint32_t li = X.h_len[h_seed[a >> 1]], lj = X.h_len[h_cand[c]];
                 ab += 8ull * ((li > kk ? li - kk : 0) + (lj > kk ? lj - kk : 0));
                 const double mn = (double)std::min<size_t>(li, lj);
                 if (double(M * kk) / mn >= t_s) part[ch].push_back(p);
@@ -197,14 +268,16 @@ struct driver {
             part_matches[ch] = mt; part_bytes[ch] = ab;
         });
         std::vector<uint32_t> todo;
+        uint64_t alg_bytes = 0, matches = 0;
         for (uint32_t ch = 0; ch < n_chunks; ++ch) {
             todo.insert(todo.end(), part[ch].begin(), part[ch].end());
-            counters[2] += part_matches[ch];
+            matches += part_matches[ch];
             alg_bytes += part_bytes[ch];
+            if (many) for (uint32_t j = 0; j < nrect; ++j) { uint64_t *cn = reqs[rect_req[j]]->counters; cn[1] += part_req[ch][2 * (size_t)j]; cn[2] += part_req[ch][2 * (size_t)j + 1]; }
         }
+        if (!many) { reqs[rect_req[0]]->counters[1] += nsurv; reqs[rect_req[0]]->counters[2] += matches; }
         ctx->stats[K_SCORE].bytes += alg_bytes;
         const uint32_t n2 = (uint32_t)todo.size();
-        counters[5] += n2;
         if (n2 == 0) return 0;
         // ---- pass 2: the reference's full comparison for the pairs that can still be accepted
         {
@@ -212,7 +285,8 @@ struct driver {
             std::vector<uint8_t> ps2(n2);
             for (uint32_t q = 0; q < n2; ++q) {
                 const uint32_t a = ctx->h_surv.p[2 * (size_t)todo[q]], c = ctx->h_surv.p[2 * (size_t)todo[q] + 1];
-                pi2[q] = rid(seeds[a >> 1]); pj2[q] = rid(cands[c]); ps2[q] = (uint8_t)(a & 1u);
+                pi2[q] = h_seed[a >> 1]; pj2[q] = h_cand[c]; ps2[q] = (uint8_t)(a & 1u);
+                reqs[rect_req[many ? seed_req[a >> 1] : 0]]->counters[5] += 1;
             }
             RT_TRY(ctx->d_var.reserve(n2));
             RT_TRY(ctx->h_var.reserve(n2));
@@ -220,7 +294,7 @@ struct driver {
             RT_HIP(hipMemcpyAsync(ctx->d_pj.p, pj2.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
             RT_HIP(hipMemcpyAsync(ctx->d_ps.p, ps2.data(), (size_t)n2, hipMemcpyHostToDevice, st));
             RT_TRY(launch_pair_score(ctx, n2));
-            counters[4]++;
+            ++launches;
             RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
             RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
             RT_HIP(hipStreamSynchronize(st));             // also: pi2 / pj2 / ps2 may go out of scope
@@ -235,22 +309,53 @@ struct driver {
             }
         if (!big.empty()) {
             RT_TRY(launch_pair_score_oversize(ctx, big, big_m));
-            counters[4]++;
+            ++launches;
             RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
             RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
             RT_HIP(hipStreamSynchronize(st));
         }
-        // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic
+        // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic; verdicts back to their rectangle
         for (uint32_t q = 0; q < n2; ++q) {
             const uint32_t a = ctx->h_surv.p[2 * (size_t)todo[q]], c = ctx->h_surv.p[2 * (size_t)todo[q] + 1];
-            const int32_t *r = ctx->h_res.p + 4 * (size_t)q;
-            const uint32_t li = rlen(seeds[a >> 1]), lj = rlen(cands[c]);
+            const int32_t *res = ctx->h_res.p + 4 * (size_t)q;
+            const uint32_t li = X.h_len[h_seed[a >> 1]], lj = X.h_len[h_cand[c]];
             const double mn = (double)std::min<size_t>(li, lj);
-            const double score = P->use_hc ? double(r[1]) / mn : double(r[0]) / mn;
-            if (score >= t_s && ctx->h_var.p[q] < t_v) hits.push_back(hit_t{a >> 1, c, (uint8_t)(a & 1u)});
+            const double score = P->use_hc ? double(res[1]) / mn : double(res[0]) / mn;
+            if (score >= t_s && ctx->h_var.p[q] < t_v) {
+                const bvf_rect &J = rects[many ? seed_req[a >> 1] : 0];
+                reqs[rect_req[many ? seed_req[a >> 1] : 0]]->hits.push_back(hit_t{(a >> 1) - J.s_base, c - J.c_base, (uint8_t)(a & 1u)});
+            }
         }
+        for (uint32_t j = 0; j < nrect; ++j) sort_hits(reqs[rect_req[j]]->hits);
         return 0;
     }
+};
+
+// ---- one clustering (cluster.cpp:93-259) as a state machine ------------------------------------------------
+struct job {
+    const read_index *X = nullptr;
+    const rattle_cluster_params *P = nullptr;
+    const uint32_t *subset = nullptr;     // local id -> loaded read id (nullptr = identity)
+    uint32_t n = 0;
+    bool inner_parallel = true;           // a lone job spreads its representative choice over the host threads
+    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    struct cl { cseq main; std::vector<cseq> seqs; };
+    std::vector<cl> clusters;
+    enum { INITIAL, MERGE, DONE } stage = INITIAL;
+    double thr = 0.0;
+    bool last = false;
+
+    // the greedy pass in flight: owner[i] = index of the founder item that absorbed i (owner[i] == i for founders),
+    // rev[i] = strand of the match
+    enum { ROUND, WAIT_L1, FOUNDERS, WAIT_L2 } phase = ROUND;
+    std::vector<uint32_t> items, owner, remaining, next, seeds_local, founders;
+    std::vector<uint8_t> rev, taken;
+    uint32_t B = 0;
+    request rq;
+
+    uint32_t rid(uint32_t local) const { return subset ? subset[local] : local; }
+    uint32_t rlen(uint32_t local) const { return X->h_len[rid(local)]; }
 
     // cluster.cpp:67-91
     cseq get_main_seq(std::vector<cseq> &seqs, double repr_percentile) const {
@@ -264,41 +369,104 @@ struct driver {
         return ns;
     }
 
-    // One greedy pass over `items` (local read id compared for each item).  owner[i] = index of
-    // the founder item that absorbed i (owner[i]==i for founders); rev[i] = strand of the match.
-    int greedy_pass(const std::vector<uint32_t> &items, double thr, std::vector<uint32_t> &owner, std::vector<uint8_t> &rev) {
-        RT_TRY(set_threshold(thr));
-        uint32_t m = (uint32_t)items.size();
+    void begin_pass(double t) {
+        thr = t;
+        const uint32_t m = (uint32_t)items.size();
         owner.resize(m);
         rev.assign(m, 0);
-        for (uint32_t i = 0; i < m; ++i) owner[i] = i;
-        static const uint32_t batch = getenv("RATTLE_SEED_BATCH") ? (uint32_t)atoi(getenv("RATTLE_SEED_BATCH")) : 256;
-        std::vector<uint32_t> remaining(m), next, seeds_local, first, cands_local, founders, ffirst;
-        for (uint32_t i = 0; i < m; ++i) remaining[i] = i;
-        std::vector<uint8_t> taken;
-        std::vector<hit_t> hits;
-        while (!remaining.empty()) {
-            counters[3]++;
-            uint32_t B = (uint32_t)std::min<size_t>(batch, remaining.size());
-            {
-                // every pair can survive the filter (the thr == 0 pass lets all of them through, cluster.cpp:19,43): keep
-                // seeds x candidates x strands below the 32-bit survivor counter, and below 64 M where all of them DO survive
-                const uint64_t per_seed = (uint64_t)remaining.size() * (ctx->idx.both ? 2u : 1u);
-                const uint64_t cap = thr == 0.0 ? (64ull << 20) : (1ull << 31);
-                B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, cap / std::max<uint64_t>(per_seed, 1)));
+        remaining.resize(m);
+        for (uint32_t i = 0; i < m; ++i) { owner[i] = i; remaining[i] = i; }
+        phase = ROUND;
+    }
+
+    void start() {
+        rq.counters = counters;
+        items.resize(n);
+        for (uint32_t i = 0; i < n; ++i) items[i] = i;
+        stage = INITIAL;
+        begin_pass(P->bv_threshold);
+    }
+
+    void choose_mains() {
+        if (inner_parallel) parallel_for(clusters.size(), 0, [&](size_t i) { clusters[i].main = get_main_seq(clusters[i].seqs, P->repr_percentile); });
+        else for (cl &c : clusters) c.main = get_main_seq(c.seqs, P->repr_percentile);
+    }
+
+    // the merge loop's head, cluster.cpp:171: `while (thr >= min_bv_threshold || last)`
+    void next_merge(double t) {
+        if (!(t >= P->min_bv_threshold || last)) { stage = DONE; return; }
+        stage = MERGE;
+        const uint32_t nc = (uint32_t)clusters.size();
+        items.resize(nc);
+        for (uint32_t i = 0; i < nc; ++i) items[i] = (uint32_t)clusters[i].main.id;     // main_seq.rev ignored (:197)
+        begin_pass(t);
+    }
+
+    void end_pass() {
+        if (stage == INITIAL) {                                   // cluster.cpp:124-166
+            std::vector<int32_t> slot(n, -1);
+            for (uint32_t i = 0; i < n; ++i)
+                if (owner[i] == i) { slot[i] = (int32_t)clusters.size(); clusters.push_back(cl{{(int32_t)i, 0}, {cseq{(int32_t)i, 0}}}); }
+            for (uint32_t i = 0; i < n; ++i)
+                if (owner[i] != i) clusters[slot[owner[i]]].seqs.push_back(cseq{(int32_t)i, rev[i]});
+            choose_mains();
+            next_merge(P->bv_threshold - P->bv_falloff);
+            return;
+        }
+        const uint32_t nc = (uint32_t)clusters.size();            // cluster.cpp:171-256
+        std::vector<cl> merged;
+        std::vector<int32_t> slot(nc, -1);
+        for (uint32_t i = 0; i < nc; ++i)
+            if (owner[i] == i) { slot[i] = (int32_t)merged.size(); merged.push_back(cl{{0, 0}, {}}); merged.back().seqs = std::move(clusters[i].seqs); }
+        for (uint32_t i = 0; i < nc; ++i) {
+            if (owner[i] == i) continue;
+            cl &dst = merged[slot[owner[i]]];
+            for (cseq s : clusters[i].seqs) {                     // :227-238
+                if (rev[i]) s.rev = !s.rev;
+                dst.seqs.push_back(s);
             }
-            // ---- level 1: seeds x seeds
-            seeds_local.resize(B);
-            first.resize(B);
-            for (uint32_t s = 0; s < B; ++s) { seeds_local[s] = items[remaining[s]]; first[s] = s + 1; }
-            founders.clear();
-            taken.assign(B, 0);
-            if (B > 1) {
-                RT_TRY(eval(seeds_local, seeds_local.data(), B, first, thr, hits));
-                // group hits by seed; forward verdict wins over reverse (cluster.cpp:19-40 before :43)
-                std::sort(hits.begin(), hits.end(), [](const hit_t &a, const hit_t &b) {
-                    return a.seed != b.seed ? a.seed < b.seed : (a.cand != b.cand ? a.cand < b.cand : a.rev < b.rev);
-                });
+        }
+        clusters.swap(merged);
+        choose_mains();
+        if (last) { stage = DONE; return; }
+        double t = thr - P->bv_falloff;                           // :251-255
+        if (t < P->min_bv_threshold && !last) { last = true; t = 0.0; }
+        next_merge(t);
+    }
+
+    // advance until the job needs a rectangle evaluated (true, *out) or is finished (false)
+    bool step(request **out) {
+        static const uint32_t batch = getenv("RATTLE_SEED_BATCH") ? (uint32_t)atoi(getenv("RATTLE_SEED_BATCH")) : 256;
+        while (stage != DONE) {
+            switch (phase) {
+            case ROUND: {
+                if (remaining.empty()) { end_pass(); break; }
+                counters[3]++;
+                B = (uint32_t)std::min<size_t>(batch, remaining.size());
+                {
+                    // seeds x candidates x strands below the evaluator's per-launch bounds even if every pair survives
+                    const uint64_t per_seed = (uint64_t)remaining.size() * (X->both ? 2u : 1u);
+                    const uint64_t cap = thr == 0.0 ? (64ull << 20) : (1ull << 31);
+                    B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, cap / std::max<uint64_t>(per_seed, 1)));
+                }
+                seeds_local.resize(B);
+                for (uint32_t s = 0; s < B; ++s) seeds_local[s] = items[remaining[s]];
+                taken.assign(B, 0);
+                if (B > 1) {                                      // ---- level 1: seeds x seeds
+                    rq.seeds.resize(B);
+                    for (uint32_t s = 0; s < B; ++s) rq.seeds[s] = rid(seeds_local[s]);
+                    rq.cands.clear();
+                    rq.triangular = true; rq.thr = thr;
+                    phase = WAIT_L1;
+                    *out = &rq;
+                    return true;
+                }
+                phase = FOUNDERS;
+                break;
+            }
+            case WAIT_L1: {
+                // hits grouped by seed; forward verdict wins over reverse (cluster.cpp:19-40 before :43)
+                const std::vector<hit_t> &hits = rq.hits;
                 size_t h = 0;
                 for (uint32_t s = 0; s < B; ++s) {
                     while (h < hits.size() && hits[h].seed < s) ++h;
@@ -311,106 +479,118 @@ struct driver {
                         rev[remaining[c]] = hits[q].rev;
                     }
                 }
+                phase = FOUNDERS;
+                break;
             }
-            for (uint32_t s = 0; s < B; ++s) if (!taken[s]) founders.push_back(s);
-            // ---- level 2: founders x rest
-            uint32_t nrest = (uint32_t)remaining.size() - B;
-            next.clear();
-            if (nrest > 0) {
-                cands_local.resize(nrest);
-                for (uint32_t c = 0; c < nrest; ++c) cands_local[c] = items[remaining[B + c]];
-                std::vector<uint32_t> fl(founders.size());
-                ffirst.assign(founders.size(), 0);
-                for (size_t f = 0; f < founders.size(); ++f) fl[f] = seeds_local[founders[f]];
-                RT_TRY(eval(fl, cands_local.data(), nrest, ffirst, thr, hits, true));
-                std::sort(hits.begin(), hits.end(), [](const hit_t &a, const hit_t &b) {
-                    return a.seed != b.seed ? a.seed < b.seed : (a.cand != b.cand ? a.cand < b.cand : a.rev < b.rev);
-                });
+            case FOUNDERS: {
+                founders.clear();
+                for (uint32_t s = 0; s < B; ++s) if (!taken[s]) founders.push_back(s);
+                const uint32_t nrest = (uint32_t)remaining.size() - B;
+                next.clear();
+                if (nrest > 0) {                                  // ---- level 2: founders x rest
+                    rq.seeds.resize(founders.size());
+                    for (size_t f = 0; f < founders.size(); ++f) rq.seeds[f] = rid(seeds_local[founders[f]]);
+                    rq.cands.resize(nrest);
+                    for (uint32_t c = 0; c < nrest; ++c) rq.cands[c] = rid(items[remaining[B + c]]);
+                    rq.triangular = false; rq.thr = thr;
+                    phase = WAIT_L2;
+                    *out = &rq;
+                    return true;
+                }
+                remaining.swap(next);
+                phase = ROUND;
+                break;
+            }
+            case WAIT_L2: {
+                const uint32_t nrest = (uint32_t)remaining.size() - B;
                 taken.assign(nrest, 0);
-                for (const hit_t &q : hits) {          // founders in order; first accepting founder wins
+                for (const hit_t &q : rq.hits) {                  // founders in order; first accepting founder wins
                     if (taken[q.cand]) continue;
                     taken[q.cand] = 1;
                     owner[remaining[B + q.cand]] = remaining[founders[q.seed]];
                     rev[remaining[B + q.cand]] = q.rev;
                 }
                 for (uint32_t c = 0; c < nrest; ++c) if (!taken[c]) next.push_back(remaining[B + c]);
+                remaining.swap(next);
+                phase = ROUND;
+                break;
             }
-            remaining.swap(next);
+            }
         }
-        return 0;
+        return false;
+    }
+
+    rattle_cluster_set *flatten() const {
+        rattle_cluster_set *R = (rattle_cluster_set *)calloc(1, sizeof(rattle_cluster_set));
+        size_t nm = 0;
+        for (auto &c : clusters) nm += c.seqs.size();
+        R->n_clusters = (uint32_t)clusters.size();
+        R->main_id = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, clusters.size()));
+        R->main_rev = (uint8_t *)malloc(std::max<size_t>(1, clusters.size()));
+        R->offsets = (uint32_t *)malloc(sizeof(uint32_t) * (clusters.size() + 1));
+        R->member_id = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, nm));
+        R->member_rev = (uint8_t *)malloc(std::max<size_t>(1, nm));
+        uint32_t p = 0;
+        for (size_t c = 0; c < clusters.size(); ++c) {
+            R->main_id[c] = clusters[c].main.id;
+            R->main_rev[c] = clusters[c].main.rev;
+            R->offsets[c] = p;
+            for (auto &s : clusters[c].seqs) { R->member_id[p] = s.id; R->member_rev[p] = s.rev; ++p; }
+        }
+        R->offsets[clusters.size()] = p;
+        memcpy(R->counters, counters, sizeof(counters));
+        return R;
     }
 };
 
+// all jobs in lockstep: every turn, the rectangles the unfinished jobs wait for are evaluated together
+int run_jobs(rattle_ctx *ctx, const rattle_cluster_params *P, std::vector<job> &jobs, bool shard_level2) {
+    evaluator E{ctx, P};
+    std::vector<uint32_t> active(jobs.size());
+    for (uint32_t i = 0; i < jobs.size(); ++i) { active[i] = i; jobs[i].inner_parallel = jobs.size() == 1; jobs[i].start(); }
+    std::vector<request *> want, reqs;
+    while (!active.empty()) {
+        want.assign(active.size(), nullptr);
+        parallel_for(active.size(), active.size() > 64 ? 16 : 1, [&](size_t i) {        // a step is microseconds of host work
+            request *q = nullptr;
+            if (jobs[active[i]].step(&q)) want[i] = q;
+        });
+        reqs.clear();
+        std::vector<uint32_t> still;
+        for (size_t i = 0; i < active.size(); ++i) if (want[i]) { reqs.push_back(want[i]); still.push_back(active[i]); }
+        active.swap(still);
+        if (reqs.empty()) break;
+        RT_TRY(E.run(reqs, shard_level2 && jobs.size() == 1 && !reqs[0]->triangular));
+    }
+    if (!jobs.empty()) jobs[0].counters[4] += E.launches;
+    return 0;
+}
+
+}  // namespace
+
 int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32_t *subset, uint32_t n_subset,
                    rattle_cluster_set **out) {
-    driver D;
-    D.ctx = ctx; D.P = P; D.subset = subset;
-    D.n = subset ? n_subset : ctx->idx.n;
-    const uint32_t n = D.n;
-    struct cl { cseq main; std::vector<cseq> seqs; };
-    std::vector<cl> clusters;
-    std::vector<uint32_t> owner;
-    std::vector<uint8_t> rev;
+    std::vector<job> jobs(1);
+    jobs[0].X = &ctx->idx; jobs[0].P = P; jobs[0].subset = subset;
+    jobs[0].n = subset ? n_subset : ctx->idx.n;
+    RT_TRY(run_jobs(ctx, P, jobs, true));
+    *out = jobs[0].flatten();
+    return 0;
+}
 
-    // ---- initial pass, cluster.cpp:124-166
-    {
-        std::vector<uint32_t> items(n);
-        for (uint32_t i = 0; i < n; ++i) items[i] = i;
-        RT_TRY(D.greedy_pass(items, P->bv_threshold, owner, rev));
-        std::vector<int32_t> slot(n, -1);
-        for (uint32_t i = 0; i < n; ++i)
-            if (owner[i] == i) { slot[i] = (int32_t)clusters.size(); clusters.push_back(cl{{(int32_t)i, 0}, {cseq{(int32_t)i, 0}}}); }
-        for (uint32_t i = 0; i < n; ++i)
-            if (owner[i] != i) clusters[slot[owner[i]]].seqs.push_back(cseq{(int32_t)i, rev[i]});
-        parallel_for(clusters.size(), 0, [&](size_t i) { clusters[i].main = D.get_main_seq(clusters[i].seqs, P->repr_percentile); });
+// subsets which[0..n_which) of (ids, sub_off), clustered independently and in lockstep; outs[which[i]] receives the result
+int cluster_driver_many(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32_t *ids, const uint64_t *sub_off,
+                        const uint32_t *which, uint32_t n_which, rattle_cluster_set **outs) {
+    static const uint32_t none = 0;
+    std::vector<job> jobs(n_which);
+    for (uint32_t i = 0; i < n_which; ++i) {
+        const uint32_t g = which[i];
+        jobs[i].X = &ctx->idx; jobs[i].P = P;
+        jobs[i].n = (uint32_t)(sub_off[g + 1] - sub_off[g]);
+        jobs[i].subset = jobs[i].n ? ids + sub_off[g] : &none;
     }
-    // ---- merge passes, cluster.cpp:171-256
-    double thr = P->bv_threshold - P->bv_falloff;
-    bool last = false;
-    while (thr >= P->min_bv_threshold || last) {
-        uint32_t nc = (uint32_t)clusters.size();
-        std::vector<uint32_t> items(nc);
-        for (uint32_t i = 0; i < nc; ++i) items[i] = (uint32_t)clusters[i].main.id;     // main_seq.rev ignored (:197)
-        RT_TRY(D.greedy_pass(items, thr, owner, rev));
-        std::vector<cl> merged;
-        std::vector<int32_t> slot(nc, -1);
-        for (uint32_t i = 0; i < nc; ++i)
-            if (owner[i] == i) { slot[i] = (int32_t)merged.size(); merged.push_back(cl{{0, 0}, {}}); merged.back().seqs = std::move(clusters[i].seqs); }
-        for (uint32_t i = 0; i < nc; ++i) {
-            if (owner[i] == i) continue;
-            cl &dst = merged[slot[owner[i]]];
-            for (cseq s : clusters[i].seqs) {            // :227-238
-                if (rev[i]) s.rev = !s.rev;
-                dst.seqs.push_back(s);
-            }
-        }
-        parallel_for(merged.size(), 0, [&](size_t i) { merged[i].main = D.get_main_seq(merged[i].seqs, P->repr_percentile); });
-        clusters.swap(merged);
-        if (last) break;
-        thr -= P->bv_falloff;                             // :251-255
-        if (thr < P->min_bv_threshold && !last) { last = true; thr = 0.0; }
-    }
-
-    // ---- flatten
-    rattle_cluster_set *R = (rattle_cluster_set *)calloc(1, sizeof(rattle_cluster_set));
-    size_t nm = 0;
-    for (auto &c : clusters) nm += c.seqs.size();
-    R->n_clusters = (uint32_t)clusters.size();
-    R->main_id = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, clusters.size()));
-    R->main_rev = (uint8_t *)malloc(std::max<size_t>(1, clusters.size()));
-    R->offsets = (uint32_t *)malloc(sizeof(uint32_t) * (clusters.size() + 1));
-    R->member_id = (int32_t *)malloc(sizeof(int32_t) * std::max<size_t>(1, nm));
-    R->member_rev = (uint8_t *)malloc(std::max<size_t>(1, nm));
-    uint32_t p = 0;
-    for (size_t c = 0; c < clusters.size(); ++c) {
-        R->main_id[c] = clusters[c].main.id;
-        R->main_rev[c] = clusters[c].main.rev;
-        R->offsets[c] = p;
-        for (auto &s : clusters[c].seqs) { R->member_id[p] = s.id; R->member_rev[p] = s.rev; ++p; }
-    }
-    R->offsets[clusters.size()] = p;
-    memcpy(R->counters, D.counters, sizeof(D.counters));
-    *out = R;
+    RT_TRY(run_jobs(ctx, P, jobs, false));
+    for (uint32_t i = 0; i < n_which; ++i) outs[which[i]] = jobs[i].flatten();
     return 0;
 }
 

@@ -196,6 +196,12 @@ void lpt_assign(const std::vector<uint64_t> &cost, int nranks, std::vector<uint3
 // all-gather of one byte string per rank (sizes first, then the payload)
 int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all);
 
+// one rectangle of kernel A's launch: seeds [s_base, s_base+ns) x candidates [c_base, c_base+nc) of the uploaded
+// arrays, tiles [tile_base, ...), look-up table row at d_lut + lut_off
+struct bvf_rect {
+    uint32_t s_base, ns, c_base, nc, tile_base, lut_off, fwd_bypass, pad;
+};
+
 // copy descriptor of the gather kernel: flags bit 0 = reverse complement (qualities reversed)
 struct gather_desc {
     uint64_t src, dst;
@@ -239,6 +245,7 @@ struct rattle_ctx {
     rattle::read_index idx;
     // scratch for the filter / score kernels
     rattle::dbuf<uint32_t> d_seed, d_cand, d_first;
+    rattle::dbuf<rattle::bvf_rect> d_rect;
     rattle::dbuf<uint16_t> d_lut;
     rattle::dbuf<uint8_t> d_pass;
     rattle::dbuf<uint32_t> d_surv;          // survivor list (2 words per entry)
@@ -317,6 +324,8 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
 // Writes dense pass bytes (if dense) and/or appends survivors (seed_slot<<1|strand, cand_slot).
 int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fwd_bypass, bool dense, bool list,
                      uint32_t list_cap);
+// the same over a list of rectangles already uploaded to ctx->d_rect (look-up table rows in ctx->d_lut)
+int launch_bv_filter_rects(rattle_ctx *ctx, uint32_t n_rects, uint32_t n_tiles, uint64_t pairs, bool dense, bool list, uint32_t list_cap);
 // pair_score.hip : pairs in ctx->d_pi/d_pj/d_ps; results in ctx->d_res (4 ints per pair) + ctx->d_var.
 int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs);
 // the same pairs, |common| only (d_res[pair]); see pair_score.hip
@@ -330,6 +339,8 @@ int launch_gather(rattle_ctx *ctx, const gather_desc *d_desc, uint32_t n, const 
                   uint8_t *dqual);
 int launch_post_msa(rattle_ctx *ctx, const post_args &A, uint32_t n_packs, int mode);
 // cluster_driver.cpp
+int cluster_driver_many(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32_t *ids, const uint64_t *sub_off,
+                        const uint32_t *which, uint32_t n_which, rattle_cluster_set **outs);
 int cluster_driver(rattle_ctx *ctx, const rattle_cluster_params *P, const uint32_t *subset, uint32_t n_subset,
                    rattle_cluster_set **out);
 
