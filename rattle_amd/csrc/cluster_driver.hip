@@ -351,7 +351,7 @@ struct job {
     enum { ROUND, WAIT_L1, FOUNDERS, WAIT_L2 } phase = ROUND;
     std::vector<uint32_t> items, owner, remaining, next, seeds_local, founders;
     std::vector<uint8_t> rev, taken;
-    uint32_t B = 0;
+    uint32_t B = 0, batch_now = 0;
     request rq;
 
     uint32_t rid(uint32_t local) const { return subset ? subset[local] : local; }
@@ -377,6 +377,15 @@ struct job {
         remaining.resize(m);
         for (uint32_t i = 0; i < m; ++i) { owner[i] = i; remaining[i] = i; }
         phase = ROUND;
+        // The outcome does not depend on the batch size (level 1 resolves the seeds exactly), the work does: level 1
+        // costs B^2/2 comparisons, which is wasted where a few founders absorb everything (a gene's reads falling into
+        // its few isoforms).  Start small on small problems and follow the number of founders the last round produced.
+        batch_now = m > 4096 ? max_batch() : std::min<uint32_t>(max_batch(), 16);
+    }
+
+    static uint32_t max_batch() {
+        static const uint32_t batch = getenv("RATTLE_SEED_BATCH") ? (uint32_t)std::max(1, atoi(getenv("RATTLE_SEED_BATCH"))) : 256;
+        return batch;
     }
 
     void start() {
@@ -436,13 +445,12 @@ struct job {
 
     // advance until the job needs a rectangle evaluated (true, *out) or is finished (false)
     bool step(request **out) {
-        static const uint32_t batch = getenv("RATTLE_SEED_BATCH") ? (uint32_t)atoi(getenv("RATTLE_SEED_BATCH")) : 256;
         while (stage != DONE) {
             switch (phase) {
             case ROUND: {
                 if (remaining.empty()) { end_pass(); break; }
                 counters[3]++;
-                B = (uint32_t)std::min<size_t>(batch, remaining.size());
+                B = (uint32_t)std::min<size_t>(batch_now, remaining.size());
                 {
                     // seeds x candidates x strands below the evaluator's per-launch bounds even if every pair survives
                     const uint64_t per_seed = (uint64_t)remaining.size() * (X->both ? 2u : 1u);
@@ -485,6 +493,11 @@ struct job {
             case FOUNDERS: {
                 founders.clear();
                 for (uint32_t s = 0; s < B; ++s) if (!taken[s]) founders.push_back(s);
+                {
+                    uint32_t want = 8;
+                    while (want < 4 * founders.size() && want < max_batch()) want *= 2;
+                    batch_now = std::min(want, max_batch());
+                }
                 const uint32_t nrest = (uint32_t)remaining.size() - B;
                 next.clear();
                 if (nrest > 0) {                                  // ---- level 2: founders x rest
