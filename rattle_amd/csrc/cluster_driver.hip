@@ -21,6 +21,7 @@
 // evaluation (kernel A over the rectangle list, kernel B over the union of the surviving pairs), the verdicts
 // are dealt back and the jobs advance.  A round costs a handful of launches whatever the number of genes.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -55,7 +56,7 @@ struct request {
     bool triangular = false;
     double thr = 0.0;                         // bit-vector threshold of the pass (cluster.cpp:19,43)
     uint64_t *counters = nullptr;             // the job's work counters
-    std::vector<hit_t> hits;                  // out: accepted (seed index, candidate index, strand), sorted
+    std::vector<hit_t> hits;                  // out: accepted (seed index, candidate index, strand); sorted if triangular
     uint32_t n_cands() const { return (uint32_t)(triangular ? seeds.size() : cands.size()); }
     uint64_t n_pairs() const {
         const uint64_t s = seeds.size();
@@ -68,6 +69,11 @@ struct evaluator {
     rattle_ctx *ctx;
     const rattle_cluster_params *P;
     uint64_t launches = 0;
+    // RATTLE_TIMING: where the host's wall time of a clustering goes
+    double t_split[6] = {0, 0, 0, 0, 0, 0};
+    std::chrono::steady_clock::time_point t_mark;
+    void mark() { t_mark = std::chrono::steady_clock::now(); }
+    void lap(int i) { const auto now = std::chrono::steady_clock::now(); t_split[i] += std::chrono::duration<double, std::milli>(now - t_mark).count(); t_mark = now; }
     std::vector<double> lut_thr;              // row r of the device table belongs to threshold lut_thr[r]
     std::vector<uint16_t> luts;
     std::vector<uint32_t> h_seed, h_cand, h_first, seed_req;
@@ -131,7 +137,6 @@ struct evaluator {
                     q.hits.push_back(hit_t{t[0], t[1], (uint8_t)t[2]});
                 }
             }
-            sort_hits(q.hits);
             return 0;
         }
         return run_chunks(reqs);
@@ -167,6 +172,7 @@ struct evaluator {
     int run_local(request **reqs, size_t nreq) {
         hipStream_t st = ctx->stream;
         const read_index &X = ctx->idx;
+        mark();
         // ---- the rectangles side by side in one seed array and one candidate array
         uint64_t ns = 0, nc = 0, npairs = 0;
         for (size_t q = 0; q < nreq; ++q) {
@@ -209,6 +215,7 @@ struct evaluator {
         RT_HIP(hipMemcpyAsync(ctx->d_cand.p, h_cand.data(), nc * 4, hipMemcpyHostToDevice, st));
         RT_HIP(hipMemcpyAsync(ctx->d_rect.p, rects.data(), (size_t)nrect * sizeof(bvf_rect), hipMemcpyHostToDevice, st));
 
+        lap(0);
         // survivor capacity: grow and retry on overflow (count is exact even when truncated)
         size_t cap = std::max<size_t>(ctx->d_surv.cap / 2, 1u << 20);
         uint32_t nsurv = 0;
@@ -225,6 +232,7 @@ struct evaluator {
             if (nsurv <= cap) break;
             cap = (size_t)nsurv + nsurv / 8;
         }
+        lap(1);
         if (nsurv == 0) return 0;
 
         RT_TRY(ctx->d_pi.reserve(nsurv));
@@ -243,6 +251,7 @@ struct evaluator {
         launches += 2;
         RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 4, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
+        lap(2);
         const double t_s = P->t_s, t_v = P->t_v;
         const uint32_t kk = (uint32_t)X.k;
         // tens of millions of survivors per level-2 round: chunks in parallel, results concatenated in pair order
@@ -278,6 +287,7 @@ struct evaluator {
         if (!many) { reqs[rect_req[0]]->counters[1] += nsurv; reqs[rect_req[0]]->counters[2] += matches; }
         ctx->stats[K_SCORE].bytes += alg_bytes;
         const uint32_t n2 = (uint32_t)todo.size();
+        lap(3);
         if (n2 == 0) return 0;
         // ---- pass 2: the reference's full comparison for the pairs that can still be accepted
         {
@@ -326,7 +336,8 @@ struct evaluator {
                 reqs[rect_req[many ? seed_req[a >> 1] : 0]]->hits.push_back(hit_t{(a >> 1) - J.s_base, c - J.c_base, (uint8_t)(a & 1u)});
             }
         }
-        for (uint32_t j = 0; j < nrect; ++j) sort_hits(reqs[rect_req[j]]->hits);
+        for (uint32_t j = 0; j < nrect; ++j) if (reqs[rect_req[j]]->triangular) sort_hits(reqs[rect_req[j]]->hits);      // level 2 takes them in any order
+        lap(4);
         return 0;
     }
 };
@@ -349,7 +360,7 @@ struct job {
     // the greedy pass in flight: owner[i] = index of the founder item that absorbed i (owner[i] == i for founders),
     // rev[i] = strand of the match
     enum { ROUND, WAIT_L1, FOUNDERS, WAIT_L2 } phase = ROUND;
-    std::vector<uint32_t> items, owner, remaining, next, seeds_local, founders;
+    std::vector<uint32_t> items, owner, remaining, next, seeds_local, founders, best;
     std::vector<uint8_t> rev, taken;
     uint32_t B = 0, batch_now = 0;
     request rq;
@@ -357,11 +368,20 @@ struct job {
     uint32_t rid(uint32_t local) const { return subset ? subset[local] : local; }
     uint32_t rlen(uint32_t local) const { return X->h_len[rid(local)]; }
 
-    // cluster.cpp:67-91
+    // cluster.cpp:67-91.  The reference's two stable sorts (by id descending, then by length descending) leave the
+    // sequences ordered by (length desc, id desc); ids are unique in a cluster, so one sort on that key gives the
+    // same order, and a cluster no merge touched is still in it.
     cseq get_main_seq(std::vector<cseq> &seqs, double repr_percentile) const {
         cseq old = seqs[0];
-        std::stable_sort(seqs.begin(), seqs.end(), [](const cseq &a, const cseq &b) { return a.id > b.id; });
-        std::stable_sort(seqs.begin(), seqs.end(), [this](const cseq &a, const cseq &b) { return rlen(a.id) > rlen(b.id); });
+        auto key = [this](const cseq &a) { return ((uint64_t)rlen((uint32_t)a.id) << 32) | (uint32_t)a.id; };
+        bool sorted = true;
+        for (size_t i = 1; i < seqs.size() && sorted; ++i) sorted = key(seqs[i - 1]) > key(seqs[i]);
+        if (!sorted) {
+            std::vector<std::pair<uint64_t, uint8_t>> tmp(seqs.size());
+            for (size_t i = 0; i < seqs.size(); ++i) tmp[i] = {key(seqs[i]), seqs[i].rev};
+            std::sort(tmp.begin(), tmp.end(), [](const std::pair<uint64_t, uint8_t> &a, const std::pair<uint64_t, uint8_t> &b) { return a.first > b.first; });
+            for (size_t i = 0; i < seqs.size(); ++i) seqs[i] = cseq{(int32_t)(uint32_t)tmp[i].first, tmp[i].second};
+        }
         int nsid = seqs.size() * repr_percentile;
         cseq ns = seqs[nsid];
         while (ns.rev != old.rev && (size_t)nsid < seqs.size() - 1) { nsid++; ns = seqs[nsid]; }
@@ -384,7 +404,7 @@ struct job {
     }
 
     static uint32_t max_batch() {
-        static const uint32_t batch = getenv("RATTLE_SEED_BATCH") ? (uint32_t)std::max(1, atoi(getenv("RATTLE_SEED_BATCH"))) : 256;
+        static const uint32_t batch = getenv("RATTLE_SEED_BATCH") ? (uint32_t)std::max(1, atoi(getenv("RATTLE_SEED_BATCH"))) : 512;
         return batch;
     }
 
@@ -516,14 +536,15 @@ struct job {
             }
             case WAIT_L2: {
                 const uint32_t nrest = (uint32_t)remaining.size() - B;
-                taken.assign(nrest, 0);
-                for (const hit_t &q : rq.hits) {                  // founders in order; first accepting founder wins
-                    if (taken[q.cand]) continue;
-                    taken[q.cand] = 1;
-                    owner[remaining[B + q.cand]] = remaining[founders[q.seed]];
-                    rev[remaining[B + q.cand]] = q.rev;
+                // founders in order, the first accepting founder wins, forward before reverse: the smallest (founder, strand)
+                // key per candidate, whatever order the hits arrive in
+                best.assign(nrest, 0xFFFFFFFFu);
+                for (const hit_t &q : rq.hits) best[q.cand] = std::min(best[q.cand], (q.seed << 1) | q.rev);
+                for (uint32_t c = 0; c < nrest; ++c) {
+                    if (best[c] == 0xFFFFFFFFu) { next.push_back(remaining[B + c]); continue; }
+                    owner[remaining[B + c]] = remaining[founders[best[c] >> 1]];
+                    rev[remaining[B + c]] = (uint8_t)(best[c] & 1u);
                 }
-                for (uint32_t c = 0; c < nrest; ++c) if (!taken[c]) next.push_back(remaining[B + c]);
                 remaining.swap(next);
                 phase = ROUND;
                 break;
@@ -562,7 +583,10 @@ int run_jobs(rattle_ctx *ctx, const rattle_cluster_params *P, std::vector<job> &
     std::vector<uint32_t> active(jobs.size());
     for (uint32_t i = 0; i < jobs.size(); ++i) { active[i] = i; jobs[i].inner_parallel = jobs.size() == 1; jobs[i].start(); }
     std::vector<request *> want, reqs;
+    static const bool timing = getenv("RATTLE_TIMING") != nullptr;
+    double t_steps = 0;
     while (!active.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
         want.assign(active.size(), nullptr);
         parallel_for(active.size(), active.size() > 64 ? 16 : 1, [&](size_t i) {        // a step is microseconds of host work
             request *q = nullptr;
@@ -572,10 +596,14 @@ int run_jobs(rattle_ctx *ctx, const rattle_cluster_params *P, std::vector<job> &
         std::vector<uint32_t> still;
         for (size_t i = 0; i < active.size(); ++i) if (want[i]) { reqs.push_back(want[i]); still.push_back(active[i]); }
         active.swap(still);
+        t_steps += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (reqs.empty()) break;
         RT_TRY(E.run(reqs, shard_level2 && jobs.size() == 1 && !reqs[0]->triangular));
     }
     if (!jobs.empty()) jobs[0].counters[4] += E.launches;
+    if (timing)
+        fprintf(stderr, "[rattle]   %zu job(s): host steps %.1f ms | build+upload %.1f, filter %.1f, count pass %.1f, host bound test %.1f, full pass + verdicts %.1f ms\n",
+                jobs.size(), t_steps, E.t_split[0], E.t_split[1], E.t_split[2], E.t_split[3], E.t_split[4]);
     return 0;
 }
 
