@@ -44,6 +44,55 @@ __global__ void expand_pairs_kernel(const uint32_t *__restrict__ surv, uint32_t 
     ps[t] = (uint8_t)(a & 1u);
 }
 
+// cluster.cpp:23-27 turned into an exact rejection on |common| (see run_local): pairs that can still reach t_s are compacted
+// for the full comparison; survivors / matches per rectangle and the algorithmic bytes are summed on the way.
+// stats: [0] pairs kept, [1] algorithmic bytes, then per rectangle (survivors, matches)
+__global__ __launch_bounds__(256) void count_bound_kernel(const uint32_t *__restrict__ surv, const int32_t *__restrict__ common, uint32_t n,
+                                                          const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj, const uint8_t *__restrict__ ps,
+                                                          const uint32_t *__restrict__ len, uint32_t kk, double t_s,
+                                                          const uint32_t *__restrict__ seed_rect, unsigned long long *__restrict__ stats,
+                                                          uint32_t *__restrict__ pi2, uint32_t *__restrict__ pj2, uint8_t *__restrict__ ps2,
+                                                          uint32_t *__restrict__ slot2) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < n;
+    uint32_t a = 0, c = 0, ri = 0, rj = 0, rect = 0;
+    unsigned long long M = 0, bytes = 0;
+    bool keep = false;
+    if (live) {
+        a = surv[2 * (uint64_t)p]; c = surv[2 * (uint64_t)p + 1];
+        M = (uint32_t)common[p];
+        ri = pi[p]; rj = pj[p];
+        const uint32_t li = len[ri], lj = len[rj];
+        bytes = 8ull * ((li > kk ? li - kk : 0) + (lj > kk ? lj - kk : 0));
+        const double mn = (double)(li < lj ? li : lj);
+        keep = (double)(M * kk) / mn >= t_s;
+        rect = seed_rect ? seed_rect[a >> 1] : 0u;
+    }
+    // one atomic per wavefront where its lanes agree on the rectangle (always, with a single rectangle)
+    const uint32_t rect0 = __shfl(rect, 0, 64);
+    const bool uniform = __all(!live || rect == rect0);
+    unsigned long long mm = M, bb = bytes, one = live ? 1ull : 0ull;
+    for (int d = 32; d; d >>= 1) { bb += __shfl_down(bb, d, 64); if (uniform) { mm += __shfl_down(mm, d, 64); one += __shfl_down(one, d, 64); } }
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) atomicAdd(&stats[1], bb);
+    if (uniform) {
+        if (lane == 0 && one) { atomicAdd(&stats[2 + 2 * (size_t)rect0], one); atomicAdd(&stats[3 + 2 * (size_t)rect0], mm); }
+    } else if (live) {
+        atomicAdd(&stats[2 + 2 * (size_t)rect], 1ull); atomicAdd(&stats[3 + 2 * (size_t)rect], M);
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&stats[0], (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (keep) {
+            const uint64_t at = base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
+            pi2[at] = ri; pj2[at] = rj; ps2[at] = ps[p];
+            slot2[2 * at] = a; slot2[2 * at + 1] = c;
+        }
+    }
+}
+
 namespace {
 
 struct hit_t { uint32_t seed, cand; uint8_t rev; };
@@ -239,76 +288,49 @@ struct evaluator {
         RT_TRY(ctx->d_pj.reserve(nsurv));
         RT_TRY(ctx->d_ps.reserve(nsurv));
         RT_TRY(ctx->d_res.reserve((size_t)nsurv * 4));
-        RT_TRY(ctx->h_surv.reserve((size_t)nsurv * 2));
-        RT_TRY(ctx->h_res.reserve((size_t)nsurv * 4));
+        RT_TRY(ctx->d_pi2.reserve(nsurv)); RT_TRY(ctx->d_pj2.reserve(nsurv)); RT_TRY(ctx->d_ps2.reserve(nsurv)); RT_TRY(ctx->d_slot2.reserve((size_t)nsurv * 2));
+        RT_TRY(ctx->d_bound_stats.reserve(2 + 2 * (size_t)nrect)); RT_TRY(ctx->h_bound_stats.reserve(2 + 2 * (size_t)nrect));
+        if (many) {
+            RT_TRY(ctx->d_seed_rect.reserve(ns));
+            RT_HIP(hipMemcpyAsync(ctx->d_seed_rect.p, seed_req.data(), ns * 4, hipMemcpyHostToDevice, st));
+        }
+        RT_HIP(hipMemsetAsync(ctx->d_bound_stats.p, 0, (2 + 2 * (size_t)nrect) * 8, st));
         hipLaunchKernelGGL(expand_pairs_kernel, dim3((nsurv + 255) / 256), dim3(256), 0, st, ctx->d_surv.p, nsurv,
                            ctx->d_seed.p, ctx->d_cand.p, ctx->d_pi.p, ctx->d_pj.p, ctx->d_ps.p);
-        RT_HIP(hipMemcpyAsync(ctx->h_surv.p, ctx->d_surv.p, (size_t)nsurv * 8, hipMemcpyDeviceToHost, st));
         // ---- pass 1: |common| of every surviving pair.  bases <= k * |LIS| <= k * |common| (similarity.cpp:52-85), so a pair
         // with double(k * |common|) / min_len < t_s cannot pass cluster.cpp:23-27 whatever its chain looks like: exact
-        // rejection without the patience search.  In the low-threshold merge passes that is nearly every pair.
+        // rejection without the patience search.  In the low-threshold merge passes that is nearly every pair.  The test
+        // (same double expression) and the compaction of the pairs that pass run on the device.
         RT_TRY(launch_pair_count(ctx, nsurv));
-        launches += 2;
-        RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)nsurv * 4, hipMemcpyDeviceToHost, st));
-        RT_HIP(hipStreamSynchronize(st));
-        lap(2);
         const double t_s = P->t_s, t_v = P->t_v;
         const uint32_t kk = (uint32_t)X.k;
-        // tens of millions of survivors per level-2 round: chunks in parallel, results concatenated in pair order
-        const uint32_t chunk = 1u << 16;
-        const uint32_t n_chunks = (nsurv + chunk - 1) / chunk;
-        std::vector<std::vector<uint32_t>> part(n_chunks);
-        std::vector<uint64_t> part_matches(n_chunks, 0), part_bytes(n_chunks, 0);
-        std::vector<std::vector<uint64_t>> part_req(many ? n_chunks : 0);       // per rectangle: survivors, matches
-        parallel_for(n_chunks, n_chunks > 1 ? 0 : 1, [&](size_t ch) {
-            uint64_t mt = 0, ab = 0;
-            if (many) part_req[ch].assign((size_t)nrect * 2, 0);
-            const uint32_t p1 = std::min<uint32_t>(nsurv, (uint32_t)(ch + 1) * chunk);
-            for (uint32_t p = (uint32_t)ch * chunk; p < p1; ++p) {
-                const uint32_t a = ctx->h_surv.p[2 * (size_t)p], c = ctx->h_surv.p[2 * (size_t)p + 1];
-                const uint64_t M = (uint32_t)ctx->h_res.p[p];
-                mt += M;
-                if (many) { uint64_t *pr = part_req[ch].data() + 2 * (size_t)seed_req[a >> 1]; pr[0] += 1; pr[1] += M; }
-                const uint32_t li = X.h_len[h_seed[a >> 1]], lj = X.h_len[h_cand[c]];
-                ab += 8ull * ((li > kk ? li - kk : 0) + (lj > kk ? lj - kk : 0));
-                const double mn = (double)std::min<size_t>(li, lj);
-                if (double(M * kk) / mn >= t_s) part[ch].push_back(p);
-            }
-            part_matches[ch] = mt; part_bytes[ch] = ab;
-        });
-        std::vector<uint32_t> todo;
-        uint64_t alg_bytes = 0, matches = 0;
-        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-            todo.insert(todo.end(), part[ch].begin(), part[ch].end());
-            matches += part_matches[ch];
-            alg_bytes += part_bytes[ch];
-            if (many) for (uint32_t j = 0; j < nrect; ++j) { uint64_t *cn = reqs[rect_req[j]]->counters; cn[1] += part_req[ch][2 * (size_t)j]; cn[2] += part_req[ch][2 * (size_t)j + 1]; }
+        hipLaunchKernelGGL(count_bound_kernel, dim3((nsurv + 255) / 256), dim3(256), 0, st, ctx->d_surv.p, ctx->d_res.p, nsurv,
+                           ctx->d_pi.p, ctx->d_pj.p, ctx->d_ps.p, X.len.p, kk, t_s, many ? ctx->d_seed_rect.p : (const uint32_t *)nullptr,
+                           ctx->d_bound_stats.p, ctx->d_pi2.p, ctx->d_pj2.p, ctx->d_ps2.p, ctx->d_slot2.p);
+        launches += 3;
+        RT_HIP(hipMemcpyAsync(ctx->h_bound_stats.p, ctx->d_bound_stats.p, (2 + 2 * (size_t)nrect) * 8, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        lap(2);
+        const uint32_t n2 = (uint32_t)ctx->h_bound_stats.p[0];
+        ctx->stats[K_SCORE].bytes += ctx->h_bound_stats.p[1];
+        for (uint32_t j = 0; j < nrect; ++j) {
+            uint64_t *cn = reqs[rect_req[j]]->counters;
+            cn[1] += ctx->h_bound_stats.p[2 + 2 * (size_t)j]; cn[2] += ctx->h_bound_stats.p[3 + 2 * (size_t)j];
         }
-        if (!many) { reqs[rect_req[0]]->counters[1] += nsurv; reqs[rect_req[0]]->counters[2] += matches; }
-        ctx->stats[K_SCORE].bytes += alg_bytes;
-        const uint32_t n2 = (uint32_t)todo.size();
         lap(3);
         if (n2 == 0) return 0;
         // ---- pass 2: the reference's full comparison for the pairs that can still be accepted
-        {
-            std::vector<uint32_t> pi2(n2), pj2(n2);
-            std::vector<uint8_t> ps2(n2);
-            for (uint32_t q = 0; q < n2; ++q) {
-                const uint32_t a = ctx->h_surv.p[2 * (size_t)todo[q]], c = ctx->h_surv.p[2 * (size_t)todo[q] + 1];
-                pi2[q] = h_seed[a >> 1]; pj2[q] = h_cand[c]; ps2[q] = (uint8_t)(a & 1u);
-                reqs[rect_req[many ? seed_req[a >> 1] : 0]]->counters[5] += 1;
-            }
-            RT_TRY(ctx->d_var.reserve(n2));
-            RT_TRY(ctx->h_var.reserve(n2));
-            RT_HIP(hipMemcpyAsync(ctx->d_pi.p, pi2.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
-            RT_HIP(hipMemcpyAsync(ctx->d_pj.p, pj2.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, st));
-            RT_HIP(hipMemcpyAsync(ctx->d_ps.p, ps2.data(), (size_t)n2, hipMemcpyHostToDevice, st));
-            RT_TRY(launch_pair_score(ctx, n2));
-            ++launches;
-            RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipStreamSynchronize(st));             // also: pi2 / pj2 / ps2 may go out of scope
-        }
+        RT_TRY(ctx->h_surv.reserve((size_t)n2 * 2));
+        RT_TRY(ctx->d_res.reserve((size_t)n2 * 4)); RT_TRY(ctx->h_res.reserve((size_t)n2 * 4));
+        RT_TRY(ctx->d_var.reserve(n2)); RT_TRY(ctx->h_var.reserve(n2));
+        RT_HIP(hipMemcpyAsync(ctx->h_surv.p, ctx->d_slot2.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+        ctx->d_pi.swap(ctx->d_pi2); ctx->d_pj.swap(ctx->d_pj2); ctx->d_ps.swap(ctx->d_ps2);       // the launchers read d_pi / d_pj / d_ps
+        struct unswap { rattle_ctx *c; ~unswap() { c->d_pi.swap(c->d_pi2); c->d_pj.swap(c->d_pj2); c->d_ps.swap(c->d_ps2); } } back{ctx};
+        RT_TRY(launch_pair_score(ctx, n2));
+        ++launches;
+        RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
         // pairs whose match list did not fit LDS: rerun through the global-scratch variant
         std::vector<uint32_t> big;
         uint32_t big_m = 0;
@@ -326,8 +348,9 @@ struct evaluator {
         }
         // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic; verdicts back to their rectangle
         for (uint32_t q = 0; q < n2; ++q) {
-            const uint32_t a = ctx->h_surv.p[2 * (size_t)todo[q]], c = ctx->h_surv.p[2 * (size_t)todo[q] + 1];
+            const uint32_t a = ctx->h_surv.p[2 * (size_t)q], c = ctx->h_surv.p[2 * (size_t)q + 1];
             const int32_t *res = ctx->h_res.p + 4 * (size_t)q;
+            reqs[rect_req[many ? seed_req[a >> 1] : 0]]->counters[5] += 1;
             const uint32_t li = X.h_len[h_seed[a >> 1]], lj = X.h_len[h_cand[c]];
             const double mn = (double)std::min<size_t>(li, lj);
             const double score = P->use_hc ? double(res[1]) / mn : double(res[0]) / mn;
@@ -515,7 +538,7 @@ struct job {
                 for (uint32_t s = 0; s < B; ++s) if (!taken[s]) founders.push_back(s);
                 {
                     uint32_t want = 8;
-                    while (want < 4 * founders.size() && want < max_batch()) want *= 2;
+                    while (want < 2 * founders.size() && want < max_batch()) want *= 2;
                     batch_now = std::min(want, max_batch());
                 }
                 const uint32_t nrest = (uint32_t)remaining.size() - B;

@@ -90,6 +90,7 @@ struct dbuf {
         release();
         p = o.p; cap = o.cap; owned = false;
     }
+    void swap(dbuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(owned, o.owned); }
     void release() {
         if (p && owned) (void)hipFree(p);
         p = nullptr;
@@ -246,6 +247,10 @@ struct rattle_ctx {
     // scratch for the filter / score kernels
     rattle::dbuf<uint32_t> d_seed, d_cand, d_first;
     rattle::dbuf<rattle::bvf_rect> d_rect;
+    rattle::dbuf<uint32_t> d_pi2, d_pj2, d_slot2, d_seed_rect;      // pairs past the count bound, compacted on the device
+    rattle::dbuf<uint8_t> d_ps2;
+    rattle::dbuf<unsigned long long> d_bound_stats;
+    rattle::hbuf<unsigned long long> h_bound_stats;
     rattle::dbuf<uint16_t> d_lut;
     rattle::dbuf<uint8_t> d_pass;
     rattle::dbuf<uint32_t> d_surv;          // survivor list (2 words per entry)

@@ -104,3 +104,18 @@ def test_cli_one_job_over_several_ranks(built, tmp_path):
     for f in ("clusters.out", "corrected.fq", "uncorrected.fq", "consensi.fq"):
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
     assert (a / "corrected.fq").stat().st_size > 100000
+
+
+@pytest.mark.parametrize("batch", ["1", "7", "64"])
+def test_clusters_do_not_depend_on_the_seed_batch(built, tmp_path, batch):
+    """The greedy driver evaluates the next B un-clustered seeds together and resolves them in index order; B (RATTLE_SEED_BATCH,
+    default 512, adapted per round) must not show in the result.  B = 1 is the reference's own seed-at-a-time loop."""
+    seqs, quals, _, _ = synth.reads(1200, 8, 3, True, seed=23)
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(synth.fastq_text(seqs, quals))
+    a = tmp_path / "default"; b = tmp_path / "small"
+    a.mkdir(); b.mkdir()
+    for out, env in ((a, {}), (b, {"RATTLE_SEED_BATCH": batch})):
+        subprocess.run([RATTLE, "cluster", "-i", str(fq), "-o", str(out), "--iso"], check=True, capture_output=True, env=dict(os.environ, **env))
+    assert (a / "clusters.out").read_bytes() == (b / "clusters.out").read_bytes()
+    assert (a / "clusters.out").stat().st_size > 1000
