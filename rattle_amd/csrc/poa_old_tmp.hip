@@ -1448,8 +1448,6 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         };
                         int32_t Hij = best;
                         while (!err && Hij != 0) {                      // H != 0 implies i != 0 and j != 0
-                            uint4 fpl = make_uint4(0, 0, 0, 0), fplb = make_uint4(0, 0, 0, 0);
-                            int pf_lane = -1;                              // lane holding the plan of row i, or -1
                             if (fast_tb) {
                                 constexpr uint32_t K = 16;
                                 uint32_t my_i = 0, my_next = 0, cur = i;
@@ -1462,9 +1460,6 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                                 const bool in = lane < K && j > lane;       // column of my step: j - lane >= 1
                                 const uint32_t my_j = in ? j - lane : 1u;
                                 int32_t c = 0;
-                                // the row plan of my step travels with the cell: the step that fails is replayed by the general
-                                // code below, which then has its plan in lane m's registers instead of a second round trip
-                                if (in && my_i != 0) { fpl = S.plan[my_i - 1]; fplb = S.planb[my_i - 1]; }
                                 if (in && my_next != 0 && my_j > 1) { c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2]; if (PK == 1) c &= 0x3FFF; }
                                 const int32_t hcur = wave_shr1(c, Hij);     // H of my step's own cell = the cell lane-1 fetched
                                 const int32_t mc = tlet[my_i] == (PK == 2 ? s[my_j - 1] : S.sq[my_j - 1]) ? POA_M : POA_N;
@@ -1480,19 +1475,12 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                                     j -= m;
                                     if (m == K || Hij == 0) continue;
                                 }
-                                pf_lane = (int)m;                          // lane m < K walked to row i at column j >= 1 (H != 0): its plan is loaded
                             }
                             // general step
                             bool found = false, ext_left = false, ext_up = false;
                             uint32_t pi = 0, pj = 0;
                             int32_t Hn = 0;
-                            uint4 pl, plb;
-                            if (pf_lane >= 0) {
-                                pl.x = (uint32_t)__builtin_amdgcn_readlane((int)fpl.x, pf_lane); pl.y = (uint32_t)__builtin_amdgcn_readlane((int)fpl.y, pf_lane);
-                                pl.z = (uint32_t)__builtin_amdgcn_readlane((int)fpl.z, pf_lane); pl.w = (uint32_t)__builtin_amdgcn_readlane((int)fpl.w, pf_lane);
-                                plb.x = (uint32_t)__builtin_amdgcn_readlane((int)fplb.x, pf_lane); plb.y = (uint32_t)__builtin_amdgcn_readlane((int)fplb.y, pf_lane);
-                                plb.z = (uint32_t)__builtin_amdgcn_readlane((int)fplb.z, pf_lane); plb.w = (uint32_t)__builtin_amdgcn_readlane((int)fplb.w, pf_lane);
-                            } else { pl = S.plan[i - 1]; plb = S.planb[i - 1]; }
+                            const uint4 pl = S.plan[i - 1], plb = S.planb[i - 1];
                             const uint32_t n_in = rd_nin(pl.x);
                             const uint32_t npred = n_in ? n_in : 1u;
                             {
@@ -2022,9 +2010,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (ctx->poa_arena_bytes < want_bytes) {
             if (ctx->poa_arena) (void)hipFree(ctx->poa_arena);
             ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
-            // allocating (and freeing) tens of GB costs seconds (the driver clears the memory, ~20 ms per GB): take a tenth
-            // more so that the next stage, whose packs differ a little, does not trigger another round of it
-            uint64_t take_bytes = std::min<uint64_t>(budget, want_bytes + want_bytes / 10);
+            // allocating (and freeing) tens of GB costs seconds: take half as much again so that the next stage,
+            // whose packs differ a little, does not trigger another round of it
+            uint64_t take_bytes = std::min<uint64_t>(budget, want_bytes + want_bytes / 2);
             if (hipMalloc((void **)&ctx->poa_arena, take_bytes) != hipSuccess) {
                 take_bytes = want_bytes;
                 if (hipMalloc((void **)&ctx->poa_arena, take_bytes) != hipSuccess) { set_error("poa: arena allocation failed"); rc = RATTLE_ERR_HIP; break; }

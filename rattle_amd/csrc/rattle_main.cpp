@@ -25,7 +25,59 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+
 #include "../../include/rattle_hip.h"
+
+// RATTLE_TIMING=1: wall time of the CLI's own phases on stderr (the library prints its phases the same way)
+struct cli_timer {
+    const char *name;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit cli_timer(const char *n) : name(n) {}
+    ~cli_timer() {
+        static const bool on = getenv("RATTLE_TIMING") != nullptr;
+        if (on) fprintf(stderr, "[rattle cli] %-26s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+// An output file of known size: the text is laid out by record offsets, formatted by all threads into an UNinitialised
+// buffer (the page faults spread over the threads; a zero-filled std::vector would touch the 2 GB once more, alone), and
+// written with one pwrite stream per thread.
+struct sized_output {
+    std::string path;
+    char *p = nullptr;
+    size_t size = 0;
+    sized_output(const std::string &path_, size_t n) : path(path_), size(n) {
+        p = (char *)malloc(n ? n : 1);
+        if (!p) { fprintf(stderr, "Error: out of memory for %s\n", path.c_str()); exit(EXIT_FAILURE); }
+    }
+    ~sized_output() { free(p); }
+    bool finish() {
+        const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return false;
+        std::atomic<bool> ok(true);
+        const size_t piece = 32u << 20;
+        const size_t n_pieces = (size + piece - 1) / piece;
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (size_t i = next++; i < n_pieces && ok; i = next++) {
+                size_t at = i * piece;
+                const size_t end = std::min(size, at + piece);
+                while (at < end) {
+                    const ssize_t w = pwrite(fd, p + at, end - at, (off_t)at);
+                    if (w <= 0) { ok = false; break; }
+                    at += (size_t)w;
+                }
+            }
+        };
+        const size_t T = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), n_pieces}));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        return (close(fd) == 0) && ok;
+    }
+};
 
 namespace {
 
@@ -561,7 +613,8 @@ int mode_cluster(int argc, char **argv) {
     // main.cpp:16-64 + fasta.cpp:272-370: ann = running record index over ALL records, length filter unless --raw, reads that
     // contain 'N' skipped; then sort_read_set (fasta.cpp:458-464): stable, longest first (a counting sort over the lengths)
     read_table T;
-    read_table_inputs(T, split_string(a.str("input", ""), ','), split_string(a.str("label", ""), ','), a.has("write-unzipped"));
+    { cli_timer t("read input"); read_table_inputs(T, split_string(a.str("input", ""), ','), split_string(a.str("label", ""), ','), a.has("write-unzipped")); }
+    std::unique_ptr<cli_timer> t_sort(new cli_timer("filter + sort + gather"));
     std::vector<uint32_t> order;                  // processing position -> record index (= the reference's `ann`)
     {
         const bool raw = a.has("raw");
@@ -595,7 +648,9 @@ int mode_cluster(int argc, char **argv) {
     std::cerr << "Done" << std::endl;
     const uint32_t n_reads = (uint32_t)order.size();
 
-    opener.wait();
+    t_sort.reset();
+    { cli_timer t("wait for device"); opener.wait(); }
+    std::unique_ptr<cli_timer> t_lib(new cli_timer("library: load + cluster"));
     rattle_cluster_params P;
     P.t_s = a.d("t_s", 0.2); P.t_v = a.d("t_v", 1000000); P.bv_threshold = a.d("bv_threshold", 0.4);
     P.min_bv_threshold = a.d("bv_min_threshold", 0.2); P.bv_falloff = a.d("bv_falloff", 0.05);
@@ -608,6 +663,8 @@ int mode_cluster(int argc, char **argv) {
         chk(rattle_hip_cluster_reads(ctx, &P, &mine));
         if (r == 0) raw = mine; else rattle_hip_cluster_set_free(mine);
     });
+    t_lib.reset();
+    cli_timer t_out("to clusters.out");
     cluster_set_t gene = to_set(raw);
     std::cerr << "Gene clustering done" << std::endl;
     std::cerr << gene.size() << " gene clusters found" << std::endl;
@@ -680,12 +737,16 @@ int mode_correct(int argc, char **argv) {
     std::vector<std::string> labels = split_string(a.str("label", ""), ',');
     const std::vector<std::string> files = split_string(a.str("input", ""), ',');
     device_team team;
-    // arena hint: ~440 kB of FASTQ per pack of 200 one-kb reads, at most a device full of resident packs, ~30 MB each
+    // arena hint: ~440 kB of FASTQ per pack of 200 one-kb reads, at most a device full of resident packs in each of two
+    // column classes, ~28 MB each on average (the library asks for 80 GB at 1e6 one-kb reads; a hint that falls short
+    // costs a second allocation, not the result).  The driver clears what it hands out at ~20 ms per GB, so a generous
+    // hint is seconds of start-up.
     const uint64_t packs_hint = std::min<uint64_t>(input_bytes(files) / 440000 + 1, 3072);
-    team_opener opener(team, a, packs_hint * (45ull << 20));
+    team_opener opener(team, a, packs_hint * (29ull << 20));
     read_table T;
-    read_table_inputs(T, files, labels, a.has("write-unzipped"));
+    { cli_timer t("read input"); read_table_inputs(T, files, labels, a.has("write-unzipped")); }
     std::cerr << "Done" << std::endl;
+    std::unique_ptr<cli_timer> t_cl(new cli_timer("read clusters + gather"));
     cluster_set_t clusters = read_clusters(a.str("clusters", ""));
     if (clusters.empty()) die("\nError: empty clusters file\n");
     const bool gene_mode = clusters[0].main_seq.gene_id == -1;                   // correct.cpp:322
@@ -712,8 +773,10 @@ int mode_correct(int argc, char **argv) {
     std::string vo = a.str("vote-order", "");
     if (vo.size() == 6) memcpy(P.vote_order, vo.data(), 6);
     if (a.has("max-pack-cells")) P.max_pack_cells = std::stoull(a.str("max-pack-cells", "0"));
-    opener.wait();
+    t_cl.reset();
+    { cli_timer t("wait for device + arena"); opener.wait(); }
     rattle_correction *R = nullptr;
+    std::unique_ptr<cli_timer> t_lib(new cli_timer("library: correct_reads"));
     team.run([&](int r, rattle_ctx *ctx) {                                      // packs sharded over the ranks, result reassembled on rank 0
         rattle_correction *mine = nullptr, *merged = nullptr;
         chk(rattle_hip_correct_reads(ctx, cat.data(), qcat.data(), off.data(), n_reads, (uint32_t)clusters.size(), coff.data(), mid.data(),
@@ -723,6 +786,8 @@ int mode_correct(int argc, char **argv) {
         rattle_hip_correction_free(mine);
         if (r == 0) R = merged;
     });
+    t_lib.reset();
+    cli_timer t_out("format + write outputs");
     auto tag = [&](int cid) {                                                    // correct.cpp:348-353
         int gid = clusters[cid].main_seq.gene_id;
         if (gid == -1) return ",gene_cluster_" + std::to_string(cid);
@@ -741,11 +806,11 @@ int mode_correct(int argc, char **argv) {
             at[i + 1] = at[i] + T.header[rid].n + (T.label[rid] ? T.labels[T.label[rid] - 1].size() : 0) + tg.size() + 1 + len + 1 +
                         (corrected ? 1 : T.ann[rid].n) + 1 + len + 1;
         }
-        std::vector<char> text(at[S.n]);
+        sized_output text(path, at[S.n]);
         parallel_chunks(S.n, [&](size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 const uint32_t rid = (uint32_t)S.read_id[i];
-                char *o = text.data() + at[i];
+                char *o = text.p + at[i];
                 auto put = [&o](const char *p, size_t n) { memcpy(o, p, n); o += n; };
                 put(T.header[rid].p, T.header[rid].n);
                 if (T.label[rid]) put(T.labels[T.label[rid] - 1].data(), T.labels[T.label[rid] - 1].size());
@@ -756,10 +821,7 @@ int mode_correct(int argc, char **argv) {
                 put(S.qual + S.off[i], S.off[i + 1] - S.off[i]); *o++ = '\n';
             }
         });
-        FILE *f = fopen(path.c_str(), "wb");
-        if (!f) die("Error: cannot write " + path);
-        fwrite(text.data(), 1, text.size(), f);
-        fclose(f);
+        if (!text.finish()) die("Error: cannot write " + path);
     };
     read_set_t consensi;
     // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's packs

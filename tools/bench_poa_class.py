@@ -31,7 +31,7 @@ flat = [s for p in range(PACKS) for s in distinct[p % 16]]
 cat, off = pack_reads(flat)
 first = (np.arange(PACKS + 1) * DEPTH).astype(np.uint32)
 ctx = Context(0)
-for it in range(2):
+for it in range(int(sys.argv[5]) if len(sys.argv) > 5 else 2):
     ctx.reset_stats()
     out = C.POINTER(MsaSet)()
     t = time.time()

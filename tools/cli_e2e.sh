@@ -14,7 +14,7 @@ with open(d + "/reads.fq", "wb") as f:
         f.write(b"@r%d\n" % i); f.write(cat[int(off[i]):int(off[i + 1])].tobytes()); f.write(b"\n+\n"); f.write(qcat[int(off[i]):int(off[i + 1])].tobytes()); f.write(b"\n")
 PY
 ls -la $D/reads.fq
-s=$(date +%s%N); ./rattle_amd/csrc/rattle cluster -i $D/reads.fq -o $D -t 32 2>/dev/null; e=$(date +%s%N); echo "rattle cluster: $(( (e - s) / 1000000 )) ms"
-s=$(date +%s%N); ./rattle_amd/csrc/rattle correct -i $D/reads.fq -c $D/clusters.out -o $D -t 32 2>$D/err.txt; grep -E "rattle\]" $D/err.txt | grep -vE "poa class|stage: " | head -20; e=$(date +%s%N); echo "rattle correct: $(( (e - s) / 1000000 )) ms"
+s=$(date +%s%N); ./rattle_amd/csrc/rattle cluster -i $D/reads.fq -o $D -t 32 2>$D/err0.txt; (grep -E "rattle cli\]" $D/err0.txt || true); e=$(date +%s%N); echo "rattle cluster: $(( (e - s) / 1000000 )) ms"
+s=$(date +%s%N); ./rattle_amd/csrc/rattle correct -i $D/reads.fq -c $D/clusters.out -o $D -t 32 2>$D/err.txt; grep -E "rattle( cli)?\]" $D/err.txt | grep -vE "poa class|stage: |poa pass" | head -40 || true; e=$(date +%s%N); echo "rattle correct: $(( (e - s) / 1000000 )) ms"
 ls -la $D | tail -5
 rm -rf $D
