@@ -129,8 +129,9 @@ int rattle_hip_cluster_subset(rattle_ctx *ctx, const rattle_cluster_params *para
                               uint32_t n_subset, rattle_cluster_set **out);
 /* Several subsets in one call (all gene clusters of the --iso level): subset i is
  * subset_ids[subset_offsets[i] .. subset_offsets[i+1]); outs[i] receives its clusters.  The subsets
- * are independent, so they run concurrently on n_workers host threads (0: default) with one stream
- * each.  Results are identical to n_subsets calls of rattle_hip_cluster_subset. */
+ * are independent: their greedy rounds advance in lockstep and every round is one evaluation on the
+ * device (n_workers is kept for ABI compatibility and ignored).  Results are identical to n_subsets
+ * calls of rattle_hip_cluster_subset. */
 int rattle_hip_cluster_subsets(rattle_ctx *ctx, const rattle_cluster_params *params, const uint32_t *subset_ids,
                                const uint64_t *subset_offsets, uint32_t n_subsets, rattle_cluster_set **outs, int n_workers);
 /* The `rattle cluster` flow around cluster_reads for reads in FILE order (main.cpp:254-277):
