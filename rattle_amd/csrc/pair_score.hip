@@ -170,59 +170,97 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     const int M = (int)total;
     const int k = A.k;
     int l = 0;
+    // Matches of two reads of one gene come in co-linear runs, so nearly every element is larger than the last tail and
+    // simply extends the longest chain: that case needs no search and no LDS read (the last tail and its element index
+    // are carried in scalars, the elements are fetched 64 at a time and handed out by readlane).
+    uint32_t tail_last = 0, m_last = 0;                  // tv[l], m[l]
     if (lane == 0) m[0] = 0;
-    for (int i = 0; i < M; ++i) {
-        const uint32_t x = pos2[i];
-        int lt = 0;
-        for (int base = 0; base < l; base += 64) {
-            const int idx = base + (int)lane + 1;
-            const bool f = idx <= l && tv[idx] < x;
-            lt += (int)__popcll(__ballot(f));
+    for (int base = 0; base < M; base += 64) {
+        const uint32_t xv = base + lane < M ? pos2[base + lane] : 0u;
+        const int nb = min(64, M - base);
+        for (int t = 0; t < nb; ++t) {
+            const int i = base + t;
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xv, t);
+            if (l == 0 || tail_last < x) {
+                ++l;
+                if (lane == 0) { pp[i] = m_last; m[l] = (uint32_t)i; tv[l] = x; }
+                tail_last = x; m_last = (uint32_t)i;
+                continue;
+            }
+            __syncthreads();                               // lane 0's tails and elements, before the wave reads them
+            int lt = 0;
+            for (int b2 = 0; b2 < l; b2 += 64) {
+                const int idx = b2 + (int)lane + 1;
+                const bool f = idx <= l && tv[idx] < x;
+                lt += (int)__popcll(__ballot(f));
+            }
+            const int lo = lt + 1;                         // <= l here
+            if (lane == 0) { pp[i] = m[lo - 1]; m[lo] = (uint32_t)i; tv[lo] = x; }
+            if (lo == l) { tail_last = x; m_last = (uint32_t)i; }
         }
-        const int lo = lt + 1;
-        if (lane == 0) { pp[i] = m[lo - 1]; m[lo] = (uint32_t)i; tv[lo] = x; }
-        if (lo > l) l = lo;
-        __syncthreads();
     }
-    if (lane != 0) return;
+    __syncthreads();
     int bases = 0, hc = 0, nd = 0;
     double variance = 0.0;
     if (l > 0) {
         // :37-44 chain reconstruction; chain indices overwrite m[0..l-1] (m[l] is read first)
-        uint32_t cur = m[l];
-        for (int i = l - 1; i >= 0; --i) { uint32_t nx = pp[cur]; m[i] = cur; cur = nx; }
-        // :52-85 walk; distances go to tv[] (free now)
+        if (lane == 0) {
+            uint32_t cur = m[l];
+            for (int i = l - 1; i >= 0; --i) { uint32_t nx = pp[cur]; m[i] = cur; cur = nx; }
+        }
+        __syncthreads();
+        // :52-85 walk; distances go to tv[] (free now).  The state (last KEPT element, previous chain element) is
+        // sequential, the chain's positions are not: 64 of them are gathered per step and handed out by readlane.
+        // The reference's double sum of the distances is a sum of small integers, exact in any order: kept as int64.
         int kf = (int)pos1[m[0]], ks = (int)pos2[m[0]];          // last KEPT element
         int prev_s = ks;                                         // previous CHAIN element (.second)
         bases = k; hc = k;
-        double sum = 0.0;
-        for (int i = 1; i < l; ++i) {
-            int f = (int)pos1[m[i]], s = (int)pos2[m[i]];
-            int d1 = f - kf, d2 = s - ks;
-            if ((d1 < k && d2 < k) || (d1 >= k && d2 >= k)) {
-                bases += k;
-                int ex = k - (s - prev_s);
-                if (ex > 0) bases -= ex;
-                int dist = d2 - d1;
-                tv[nd++] = (uint32_t)dist;
-                sum += (double)dist;
-                if (dist < 10) { hc += k; if (ex > 0) hc -= ex; }
-                kf = f; ks = s;
+        long long isum = 0;
+        for (int base = 1; base < l; base += 64) {
+            const int idx = base + (int)lane;
+            int fv = 0, sv = 0;
+            if (idx < l) { const uint32_t e = m[idx]; fv = (int)pos1[e]; sv = (int)pos2[e]; }
+            const int nb = min(64, l - base);
+            for (int t = 0; t < nb; ++t) {
+                const int f = __builtin_amdgcn_readlane(fv, t), s2 = __builtin_amdgcn_readlane(sv, t);
+                const int d1 = f - kf, d2 = s2 - ks;
+                if ((d1 < k && d2 < k) || (d1 >= k && d2 >= k)) {
+                    bases += k;
+                    const int ex = k - (s2 - prev_s);
+                    if (ex > 0) bases -= ex;
+                    const int dist = d2 - d1;
+                    if (lane == 0) tv[nd] = (uint32_t)dist;
+                    ++nd;
+                    isum += dist;
+                    if (dist < 10) { hc += k; if (ex > 0) hc -= ex; }
+                    kf = f; ks = s2;
+                }
+                prev_s = s2;
             }
-            prev_s = s;
         }
-        // utils.cpp:36-55
+        __syncthreads();
+        // utils.cpp:36-55: the two sums over the deviations keep the reference's order
         if (nd > 0) {
-            double mean = sum / (double)nd;
+            const double sum = (double)isum;
+            const double mean = sum / (double)nd;
             double ss = 0.0, comp = 0.0;
-            for (int i = 0; i < nd; ++i) {
-                double d = (double)(int)tv[i] - mean;
-                ss += d * d;
-                comp += d;
+            for (int base = 0; base < nd; base += 64) {
+                const int idx = base + (int)lane;
+                const double dv = idx < nd ? (double)(int)tv[idx] - mean : 0.0;
+                const int dlo = (int)(uint32_t)__double_as_longlong(dv), dhi = (int)(uint32_t)((unsigned long long)__double_as_longlong(dv) >> 32);
+                const int nb = min(64, nd - base);
+                for (int t = 0; t < nb; ++t) {
+                    const unsigned long long bits = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dlo, t) |
+                                                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dhi, t) << 32);
+                    const double d = __longlong_as_double((long long)bits);
+                    ss += d * d;
+                    comp += d;
+                }
             }
             variance = (ss - comp * comp / (double)nd) / (double)(nd - 1);
         }
     }
+    if (lane != 0) return;
     out[0] = bases; out[1] = hc; out[2] = nd; out[3] = M;
     A.var[pr] = variance;
 }
