@@ -295,13 +295,20 @@ struct evaluator {
             RT_HIP(hipMemcpyAsync(ctx->d_seed_rect.p, seed_req.data(), ns * 4, hipMemcpyHostToDevice, st));
         }
         RT_HIP(hipMemsetAsync(ctx->d_bound_stats.p, 0, (2 + 2 * (size_t)nrect) * 8, st));
+        // Two count passes.  "seed": survivors sorted by seed, the seed's k-mer set as a bit set in LDS, its candidates' lists
+        // streamed past it (pair_count.hip) -- pays where a seed has many surviving candidates (gene level: hundreds).
+        // "search": one wavefront per pair, binary searches in the candidate's list (pair_score.hip) -- better for the short
+        // runs of the --iso level.  RATTLE_PAIR_COUNT=seed|search forces one of them.
+        static const char *force = getenv("RATTLE_PAIR_COUNT");
+        const bool seed_major = force ? !strcmp(force, "seed") : (uint64_t)nsurv >= 64ull * ns;
+        if (seed_major) RT_TRY(sort_survivors_by_seed(ctx, nsurv, ns));
         hipLaunchKernelGGL(expand_pairs_kernel, dim3((nsurv + 255) / 256), dim3(256), 0, st, ctx->d_surv.p, nsurv,
                            ctx->d_seed.p, ctx->d_cand.p, ctx->d_pi.p, ctx->d_pj.p, ctx->d_ps.p);
         // ---- pass 1: |common| of every surviving pair.  bases <= k * |LIS| <= k * |common| (similarity.cpp:52-85), so a pair
         // with double(k * |common|) / min_len < t_s cannot pass cluster.cpp:23-27 whatever its chain looks like: exact
         // rejection without the patience search.  In the low-threshold merge passes that is nearly every pair.  The test
         // (same double expression) and the compaction of the pairs that pass run on the device.
-        RT_TRY(launch_pair_count(ctx, nsurv));
+        if (seed_major) RT_TRY(launch_pair_count_seed(ctx, nsurv)); else RT_TRY(launch_pair_count(ctx, nsurv));
         const double t_s = P->t_s, t_v = P->t_v;
         const uint32_t kk = (uint32_t)X.k;
         hipLaunchKernelGGL(count_bound_kernel, dim3((nsurv + 255) / 256), dim3(256), 0, st, ctx->d_surv.p, ctx->d_res.p, nsurv,

@@ -254,6 +254,8 @@ struct rattle_ctx {
     rattle::dbuf<uint16_t> d_lut;
     rattle::dbuf<uint8_t> d_pass;
     rattle::dbuf<uint32_t> d_surv;          // survivor list (2 words per entry)
+    rattle::dbuf<uint32_t> d_surv2;         // ... sorted by seed (double buffer of the device sort)
+    rattle::dbuf<uint8_t> d_sort_tmp;
     rattle::dbuf<uint32_t> d_counter;
     rattle::dbuf<uint32_t> d_pi, d_pj;
     rattle::dbuf<uint8_t> d_ps;
@@ -333,6 +335,9 @@ int launch_bv_filter(rattle_ctx *ctx, uint32_t n_seeds, uint32_t n_cands, int fw
 int launch_bv_filter_rects(rattle_ctx *ctx, uint32_t n_rects, uint32_t n_tiles, uint64_t pairs, bool dense, bool list, uint32_t list_cap);
 // pair_score.hip : pairs in ctx->d_pi/d_pj/d_ps; results in ctx->d_res (4 ints per pair) + ctx->d_var.
 int launch_pair_score(rattle_ctx *ctx, uint32_t n_pairs);
+// pair_count.hip : the count pass, seed-major (survivors sorted by seed, the seed's k-mer set as an LDS bit set)
+int sort_survivors_by_seed(rattle_ctx *ctx, uint32_t n, uint64_t n_seeds);
+int launch_pair_count_seed(rattle_ctx *ctx, uint32_t n_pairs);
 // the same pairs, |common| only (d_res[pair]); see pair_score.hip
 int launch_pair_count(rattle_ctx *ctx, uint32_t n_pairs);
 // poa.hip : device-resident POA over packs (sequences, offsets, column output in HBM)

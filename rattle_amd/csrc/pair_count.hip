@@ -1,0 +1,152 @@
+// Kernel B, count pass, seed-major: |common| of every pair that passed the bit-vector filter.
+//
+// |common| (kmer.cpp:45-67: the full cross product on repeated hashes) = sum over the candidate's k-mers b of the
+// number of times hash(b) occurs in the seed.  The pairs are sorted by seed first; a workgroup then turns the seed's
+// k-mer set into a direct-address bit set in LDS (4^k <= 2^20 bits = 128 KB for k <= 10), and each of its 16 wavefronts
+// streams the hash lists of that seed's candidates past it: one coalesced load and one LDS bit test per k-mer, no
+// search.  Hashes that occur more than once in the seed are kept, once per extra occurrence, in a short list that is
+// consulted only on a hit, so the count is exact.  For k > 10 the hash is folded to 20 bits: the count becomes an
+// UPPER bound of |common|, which is all the caller's exact rejection test needs (cluster_driver.hip: pairs that pass
+// it go through the reference's full comparison).  The same holds when the repeat list overflows (low-complexity
+// seeds): every hit is charged the whole list.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace rattle {
+
+#define PC_THREADS 1024
+#define PC_CHUNK 512            // pairs per workgroup (one or a few seeds' runs)
+#define PC_REP 2048             // repeat list entries
+
+struct pc_args {
+    const uint32_t *surv;        // [n][2] (seed_slot << 1 | strand, cand_slot), sorted by seed slot
+    uint32_t n;
+    const uint32_t *seed_ids, *cand_ids;
+    const uint32_t *uh;          // forward hashes of every read, position order
+    const uint32_t *kh[2];       // per strand: hash lists
+    const uint64_t *koff;
+    int k;
+    int32_t *res;                // [n] count per pair
+};
+
+__global__ __launch_bounds__(PC_THREADS) void pair_count_seed_kernel(pc_args A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t s_nrep, s_run_end;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int bits = 2 * A.k < 20 ? 2 * A.k : 20;
+    const uint32_t nwords = bits > 5 ? 1u << (bits - 5) : 1u;
+    const bool folded = 2 * A.k > 20;
+    uint32_t *set = lds, *rep = lds + nwords;
+    auto fold = [&](uint32_t h) { return folded ? (h ^ (h >> 20)) & 0xFFFFFu : h; };
+    const uint32_t p0 = blockIdx.x * PC_CHUNK, p1 = min(A.n, p0 + PC_CHUNK);
+    uint32_t p = p0;
+    while (p < p1) {                                          // one run of equal seed per turn
+        const uint32_t seed_slot = A.surv[2 * (uint64_t)p] >> 1;
+        if (tid == 0) { s_run_end = p1; s_nrep = 0; }
+        for (uint32_t w = tid * 4; w < nwords; w += PC_THREADS * 4) *(uint4 *)(set + w) = make_uint4(0, 0, 0, 0);
+        if (nwords < 4 && tid < nwords) set[tid] = 0;
+        __syncthreads();
+        for (uint32_t q = p + 1 + tid; q < p1; q += PC_THREADS)
+            if ((A.surv[2 * (uint64_t)q] >> 1) != seed_slot && (A.surv[2 * (uint64_t)(q - 1)] >> 1) == seed_slot) atomicMin(&s_run_end, q);
+        const uint32_t ri = A.seed_ids[seed_slot];
+        const uint32_t nA = (uint32_t)(A.koff[ri + 1] - A.koff[ri]);
+        const uint32_t *__restrict__ ah = A.uh + A.koff[ri];
+        for (uint32_t t = tid; t < nA; t += PC_THREADS) {
+            const uint32_t f = fold(ah[t]), bit = 1u << (f & 31u);
+            if (atomicOr(&set[f >> 5], bit) & bit) {          // one more occurrence of a value already in the set
+                const uint32_t at = atomicAdd(&s_nrep, 1u);
+                if (at < PC_REP) rep[at] = f;
+            }
+        }
+        __syncthreads();
+        const uint32_t nrep = s_nrep, run_end = s_run_end;
+        const bool overflow = nrep > PC_REP;
+        // wave w takes pairs p + w, p + w + 16, ...; the lanes fetch the descriptors of 64 of them at once (pair -> candidate ->
+        // list offsets is three dependent loads: paid once per batch instead of once per pair) and hand them out by readlane
+        constexpr uint32_t NWV = PC_THREADS / 64;
+        for (uint32_t qb = p + wave; qb < run_end; qb += NWV * 64) {
+            const uint32_t myq = qb + NWV * lane;
+            uint32_t m_strand = 0, m_n = 0, m_lo = 0, m_hi = 0;
+            if (myq < run_end) {
+                const uint32_t a = A.surv[2 * (uint64_t)myq], c = A.surv[2 * (uint64_t)myq + 1];
+                const uint32_t rj = A.cand_ids[c];
+                const uint64_t o0 = A.koff[rj], o1 = A.koff[rj + 1];
+                m_strand = a & 1u; m_n = (uint32_t)(o1 - o0); m_lo = (uint32_t)o0; m_hi = (uint32_t)(o0 >> 32);
+            }
+            const uint32_t nb = min(64u, (run_end - qb + NWV - 1) / NWV);
+            for (uint32_t i = 0; i < nb; ++i) {
+                const uint32_t strand = (uint32_t)__builtin_amdgcn_readlane((int)m_strand, (int)i);
+                const uint32_t nB = (uint32_t)__builtin_amdgcn_readlane((int)m_n, (int)i);
+                const uint64_t o0 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_lo, (int)i) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m_hi, (int)i) << 32);
+                const uint32_t *__restrict__ bh = A.kh[strand] + o0;
+                uint32_t cnt = 0;
+                auto test = [&](uint32_t h) {
+                    const uint32_t f = fold(h);
+                    if ((set[f >> 5] >> (f & 31u)) & 1u) {
+                        ++cnt;
+                        if (overflow) cnt += nrep;
+                        else for (uint32_t r = 0; r < nrep; ++r) cnt += rep[r] == f ? 1u : 0u;
+                    }
+                };
+                uint32_t t = lane;
+                for (; t + 448 < nB; t += 512) {                  // eight loads in flight per lane
+                    const uint32_t h0 = bh[t], h1 = bh[t + 64], h2 = bh[t + 128], h3 = bh[t + 192], h4 = bh[t + 256], h5 = bh[t + 320], h6 = bh[t + 384], h7 = bh[t + 448];
+                    test(h0); test(h1); test(h2); test(h3); test(h4); test(h5); test(h6); test(h7);
+                }
+                for (; t + 192 < nB; t += 256) {
+                    const uint32_t h0 = bh[t], h1 = bh[t + 64], h2 = bh[t + 128], h3 = bh[t + 192];
+                    test(h0); test(h1); test(h2); test(h3);
+                }
+                for (; t < nB; t += 64) test(bh[t]);
+                for (int d = 32; d; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+                if (lane == 0) A.res[qb + NWV * i] = (int32_t)min(cnt, 0x7FFFFFFFu);
+            }
+        }
+        __syncthreads();                                      // the set is rebuilt for the next run
+        p = run_end;
+    }
+}
+
+// sort the survivor list (ctx->d_surv, n entries of two words) by seed slot; n_seeds bounds the slot
+int sort_survivors_by_seed(rattle_ctx *ctx, uint32_t n, uint64_t n_seeds) {
+    if (n < 2) return 0;
+    int sbits = 1;
+    while ((1ull << sbits) < n_seeds) ++sbits;
+    RT_TRY(ctx->d_surv2.reserve((size_t)n * 2));
+    unsigned long long *in = (unsigned long long *)ctx->d_surv.p, *out = (unsigned long long *)ctx->d_surv2.p;
+    size_t tmp = 0;
+    // an entry read as one 64-bit key has the seed word in its low half: bits [1, 1 + sbits) are the seed slot
+    if (rocprim::radix_sort_keys(nullptr, tmp, in, out, (size_t)n, 1u, (unsigned)(1 + sbits), ctx->stream) != hipSuccess) { set_error("survivor sort: size query failed"); return RATTLE_ERR_HIP; }
+    RT_TRY(ctx->d_sort_tmp.reserve(tmp + 16));
+    if (rocprim::radix_sort_keys((void *)ctx->d_sort_tmp.p, tmp, in, out, (size_t)n, 1u, (unsigned)(1 + sbits), ctx->stream) != hipSuccess) { set_error("survivor sort failed"); return RATTLE_ERR_HIP; }
+    ctx->d_surv.swap(ctx->d_surv2);
+    return 0;
+}
+
+// pairs in ctx->d_surv (sorted by seed), seeds / candidates in ctx->d_seed / d_cand; count (or its upper bound, see above) of
+// each pair into ctx->d_res[pair]
+int launch_pair_count_seed(rattle_ctx *ctx, uint32_t n_pairs) {
+    if (n_pairs == 0) return 0;
+    read_index &X = ctx->idx;
+    pc_args A;
+    A.surv = ctx->d_surv.p; A.n = n_pairs; A.seed_ids = ctx->d_seed.p; A.cand_ids = ctx->d_cand.p;
+    A.uh = X.uh.p; A.kh[0] = X.kh[0].p; A.kh[1] = X.kh[1].p; A.koff = X.koff.p; A.k = X.k;
+    A.res = ctx->d_res.p;
+    const int bits = 2 * X.k < 20 ? 2 * X.k : 20;
+    const size_t shm = ((bits > 5 ? (size_t)1 << (bits - 5) : 4) + PC_REP) * 4;
+    static size_t attr_shm = 0;
+    if (shm > attr_shm) {
+        RT_HIP(hipFuncSetAttribute((const void *)pair_count_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        attr_shm = shm;
+    }
+    ktimer T(ctx, K_SCORE, 0);
+    hipLaunchKernelGGL(pair_count_seed_kernel, dim3((n_pairs + PC_CHUNK - 1) / PC_CHUNK), dim3(PC_THREADS), shm, ctx->stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("pair_count_seed launch: ") + hipGetErrorString(e)); return RATTLE_ERR_HIP; }
+    return 0;
+}
+
+}  // namespace rattle

@@ -119,3 +119,21 @@ def test_clusters_do_not_depend_on_the_seed_batch(built, tmp_path, batch):
         subprocess.run([RATTLE, "cluster", "-i", str(fq), "-o", str(out), "--iso"], check=True, capture_output=True, env=dict(os.environ, **env))
     assert (a / "clusters.out").read_bytes() == (b / "clusters.out").read_bytes()
     assert (a / "clusters.out").stat().st_size > 1000
+
+
+@pytest.mark.parametrize("k", ["10", "12"])
+def test_both_count_passes_give_the_same_clusters(built, tmp_path, k):
+    """Kernel B's count pass exists twice (per pair with binary searches; per seed with an LDS bit set, which for k > 10
+    folds the hash and returns an upper bound of |common|): the exact rejection built on either must lead to the same
+    clusters at both levels of `--iso`."""
+    seqs, quals, _, _ = synth.reads(1500, 6, 3, True, seed=29)
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(synth.fastq_text(seqs, quals))
+    outs = {}
+    for mode in ("seed", "search"):
+        d = tmp_path / mode
+        d.mkdir()
+        subprocess.run([RATTLE, "cluster", "-i", str(fq), "-o", str(d), "--iso", "-k", k, "--iso-kmer-size", str(int(k) + 1)], check=True, capture_output=True,
+                       env=dict(os.environ, RATTLE_PAIR_COUNT=mode))
+        outs[mode] = (d / "clusters.out").read_bytes()
+    assert outs["seed"] == outs["search"] and len(outs["seed"]) > 1000
