@@ -96,9 +96,16 @@ def test_cluster_100k_bit_exact_with_oracle(gpu_ctx, oracle, big):
     order = sorted(range(N), key=lambda i: -len(seqs[i]))
     reads = [seqs[i] for i in order]
     gpu_ctx.load_reads(reads, 10, True)
-    got = gpu_ctx.cluster_reads(is_rna=False).as_list()
-    want, _ = oracle.cluster_reads(reads, k=10, is_rna=False)
+    res = gpu_ctx.cluster_reads(is_rna=False)
+    got = res.as_list()
+    want, ocnt = oracle.cluster_reads(reads, k=10, is_rna=False)
     assert got == want
+    # work profile beside the reference's seed-at-a-time loop (oracle counters: bit-vector tests, full comparisons): the batched
+    # driver tests more pairs against the bit vectors and counts |common| for every survivor, but runs the full comparison
+    # (patience search, variance) only for the pairs past the exact |common| bound
+    c = [int(x) for x in res.counters]
+    print(f"\n1e5 reads: bit-vector tests {c[0]} (oracle {int(ocnt[0])}), count pass {c[1]}, full comparisons {c[5]} (oracle {int(ocnt[1])})")
+    assert c[5] <= c[1] and int(ocnt[1]) <= c[1] and c[0] >= int(ocnt[0])
     # and the unsorted entry point translates the same clusters back to input ids
     tr = [((order[m[0]], m[1], -1), [(order[s[0]], s[1], -1) for s in mem]) for m, mem in want]
     assert cl.as_list() == tr
