@@ -394,6 +394,7 @@ struct job {
     std::vector<uint8_t> rev, taken;
     uint32_t B = 0, batch_now = 0;
     request rq;
+    double t_phase[5] = {0, 0, 0, 0, 0};                   // RATTLE_TIMING: round set-up, level-1 resolve, founders + request, level-2 resolve, end of pass
 
     uint32_t rid(uint32_t local) const { return subset ? subset[local] : local; }
     uint32_t rlen(uint32_t local) const { return X->h_len[rid(local)]; }
@@ -447,8 +448,15 @@ struct job {
     }
 
     void choose_mains() {
-        if (inner_parallel) parallel_for(clusters.size(), 0, [&](size_t i) { clusters[i].main = get_main_seq(clusters[i].seqs, P->repr_percentile); });
-        else for (cl &c : clusters) c.main = get_main_seq(c.seqs, P->repr_percentile);
+        // clusters no merge touched are still in order (one linear check); only the others are sorted, on a few host
+        // threads when there is enough of it (spawning a thread per core costs more than most passes' sorting)
+        std::vector<uint32_t> big;
+        size_t work = 0;
+        for (uint32_t i = 0; i < clusters.size(); ++i) {
+            if (inner_parallel && clusters[i].seqs.size() >= 4096) { big.push_back(i); work += clusters[i].seqs.size(); continue; }
+            clusters[i].main = get_main_seq(clusters[i].seqs, P->repr_percentile);
+        }
+        parallel_for(big.size(), work >= (1u << 18) ? 16 : 1, [&](size_t t) { cl &c = clusters[big[t]]; c.main = get_main_seq(c.seqs, P->repr_percentile); });
     }
 
     // the merge loop's head, cluster.cpp:171: `while (thr >= min_bv_threshold || last)`
@@ -464,8 +472,15 @@ struct job {
     void end_pass() {
         if (stage == INITIAL) {                                   // cluster.cpp:124-166
             std::vector<int32_t> slot(n, -1);
+            std::vector<uint32_t> size(n, 0);
+            for (uint32_t i = 0; i < n; ++i) ++size[owner[i]];
             for (uint32_t i = 0; i < n; ++i)
-                if (owner[i] == i) { slot[i] = (int32_t)clusters.size(); clusters.push_back(cl{{(int32_t)i, 0}, {cseq{(int32_t)i, 0}}}); }
+                if (owner[i] == i) {
+                    slot[i] = (int32_t)clusters.size();
+                    clusters.push_back(cl{{(int32_t)i, 0}, {}});
+                    clusters.back().seqs.reserve(size[i]);
+                    clusters.back().seqs.push_back(cseq{(int32_t)i, 0});
+                }
             for (uint32_t i = 0; i < n; ++i)
                 if (owner[i] != i) clusters[slot[owner[i]]].seqs.push_back(cseq{(int32_t)i, rev[i]});
             choose_mains();
@@ -496,6 +511,10 @@ struct job {
     // advance until the job needs a rectangle evaluated (true, *out) or is finished (false)
     bool step(request **out) {
         while (stage != DONE) {
+            struct lapse { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                           ~lapse() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
+            const bool ending = phase == ROUND && remaining.empty();
+            lapse L{t_phase[ending ? 4 : (int)phase]};
             switch (phase) {
             case ROUND: {
                 if (remaining.empty()) { end_pass(); break; }
@@ -631,6 +650,9 @@ int run_jobs(rattle_ctx *ctx, const rattle_cluster_params *P, std::vector<job> &
         RT_TRY(E.run(reqs, shard_level2 && jobs.size() == 1 && !reqs[0]->triangular));
     }
     if (!jobs.empty()) jobs[0].counters[4] += E.launches;
+    if (timing && jobs.size() == 1)
+        fprintf(stderr, "[rattle]   host steps: round set-up %.1f, level-1 resolve %.1f, founders + request %.1f, level-2 resolve %.1f, end of pass %.1f ms\n",
+                jobs[0].t_phase[0], jobs[0].t_phase[1], jobs[0].t_phase[2], jobs[0].t_phase[3], jobs[0].t_phase[4]);
     if (timing)
         fprintf(stderr, "[rattle]   %zu job(s): host steps %.1f ms | build+upload %.1f, filter %.1f, count pass %.1f, host bound test %.1f, full pass + verdicts %.1f ms\n",
                 jobs.size(), t_steps, E.t_split[0], E.t_split[1], E.t_split[2], E.t_split[3], E.t_split[4]);
