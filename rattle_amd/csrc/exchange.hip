@@ -125,17 +125,24 @@ int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vect
     return 0;
 }
 
-// gather of one byte string per rank on `root` (all[] stays empty elsewhere).  RCCL: send / recv pairs in a
-// group; host transport: the caller's all-gather-v.
-static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int root, std::vector<std::vector<uint8_t>> &all) {
+// gather of one byte string per rank on `root` (nothing elsewhere).  RCCL: send / recv pairs in a group, the root's pieces land
+// in ONE host buffer that is not zero-filled first (GBs of corrected reads); host transport: the caller's all-gather-v.
+struct gathered {
+    std::vector<std::vector<uint8_t>> owned;      // host transport: the all-gather's pieces
+    std::unique_ptr<uint8_t[]> flat;              // RCCL: the root's receive buffer
+    std::vector<const uint8_t *> p;               // piece r = p[r][0 .. n[r])
+    std::vector<size_t> n;
+};
+
+static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int root, gathered &G) {
     exchange &X = ctx->xchg;
+    G.p.assign((size_t)X.nranks, nullptr); G.n.assign((size_t)X.nranks, 0);
     if (X.nranks == 1 || !X.comm) {
-        RT_TRY(xchg_allgatherv(ctx, mine, all));
-        if (X.rank != root) all.assign((size_t)X.nranks, {});
+        RT_TRY(xchg_allgatherv(ctx, mine, G.owned));
+        if (X.rank == root) for (int r = 0; r < X.nranks; ++r) { G.p[r] = G.owned[r].data(); G.n[r] = G.owned[r].size(); }
         return 0;
     }
     ++X.calls;
-    all.assign((size_t)X.nranks, {});
     hipStream_t st = ctx->stream;
     std::vector<uint64_t> bytes((size_t)X.nranks, 0);
     const uint64_t my_bytes = mine.size();
@@ -168,14 +175,15 @@ static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int r
         at += bytes[r];
     }
     RT_NCCL(A.GroupEnd());
+    G.flat.reset(new uint8_t[total + 16]);
+    if (total) RT_HIP(hipMemcpyAsync(G.flat.get(), d_recv.p, total, hipMemcpyDeviceToHost, st));
+    RT_HIP(hipStreamSynchronize(st));
     at = 0;
     for (int r = 0; r < X.nranks; ++r) {
-        if (r == root) { all[r] = mine; continue; }
-        all[r].resize(bytes[r]);
-        if (bytes[r]) RT_HIP(hipMemcpyAsync(all[r].data(), d_recv.p + at, bytes[r], hipMemcpyDeviceToHost, st));
+        if (r == root) { G.p[r] = mine.data(); G.n[r] = mine.size(); continue; }
+        G.p[r] = G.flat.get() + at; G.n[r] = bytes[r];
         at += bytes[r];
     }
-    RT_HIP(hipStreamSynchronize(st));
     X.bytes += total;
     return 0;
 }
@@ -190,8 +198,8 @@ void put(std::vector<uint8_t> &b, const T *p, size_t n) {
     if (n) memcpy(b.data() + at, p, n * sizeof(T));
 }
 template <typename T>
-const T *take(const std::vector<uint8_t> &b, size_t &at, size_t n) {
-    const T *p = (const T *)(b.data() + at);
+const T *take(const uint8_t *b, size_t &at, size_t n) {
+    const T *p = (const T *)(b + at);
     at += n * sizeof(T);
     return p;
 }
@@ -209,6 +217,7 @@ struct piece_view {                      // one rank's serialised set
 
 void put_set(std::vector<uint8_t> &b, const rattle_read_set &S, const uint32_t *pack) {
     const uint64_t n = S.n;
+    b.reserve(b.size() + 16 + (n + 1) * 8 + n * 16 + 2 * S.off[n] + 8);      // one growth, not a doubling per array
     put(b, &n, 1);
     put(b, S.off, n + 1);                // 8-byte fields first: every array stays naturally aligned
     put(b, S.read_id, n); put(b, S.cluster_id, n); put(b, S.n_reads, n);
@@ -222,7 +231,7 @@ void put_set(std::vector<uint8_t> &b, const rattle_read_set &S, const uint32_t *
     put(b, z, pad);
 }
 
-piece_view take_set(const std::vector<uint8_t> &b, size_t &at) {
+piece_view take_set(const uint8_t *b, size_t &at) {
     piece_view V;
     const uint64_t n = *take<uint64_t>(b, at, 1);
     V.n = (uint32_t)n;
@@ -263,13 +272,20 @@ void merge_sets(const std::vector<piece_view> &V, rattle_read_set &S, uint32_t *
     for (size_t i = 0; i < refs.size(); ++i) {
         const piece_view &P = V[refs[i].piece];
         const uint32_t j = refs[i].idx;
-        const uint64_t len = P.off[j + 1] - P.off[j];
         S.read_id[i] = P.read_id[j]; S.cluster_id[i] = P.cluster_id[j]; S.n_reads[i] = P.n_reads[j];
         S.off[i] = at;
-        memcpy(S.seq + at, P.seq + P.off[j], len); memcpy(S.qual + at, P.qual + P.off[j], len);
         pk[i] = P.pack[j];
-        at += len;
+        at += P.off[j + 1] - P.off[j];
     }
+    const size_t chunk = 4096;
+    parallel_for((refs.size() + chunk - 1) / chunk, refs.size() > 8 * chunk ? 16 : 1, [&](size_t c) {
+        for (size_t i = c * chunk; i < std::min(refs.size(), (c + 1) * chunk); ++i) {
+            const piece_view &P = V[refs[i].piece];
+            const uint32_t j = refs[i].idx;
+            const uint64_t len = P.off[j + 1] - P.off[j];
+            memcpy(S.seq + S.off[i], P.seq + P.off[j], len); memcpy(S.qual + S.off[i], P.qual + P.off[j], len);
+        }
+    });
     S.off[refs.size()] = at;
     if (pack_out) *pack_out = pk; else free(pk);
 }
@@ -291,8 +307,8 @@ int correction_gather(rattle_ctx *ctx, const rattle_correction *L, int root, rat
         if ((3 * n + tot) & 1) { const uint32_t z = 0; put(mine, &z, 1); }
         put(mine, L->counters, 8);
     }
-    std::vector<std::vector<uint8_t>> all;
-    RT_TRY(xchg_gatherv(ctx, mine, root, all));
+    gathered G;
+    RT_TRY(xchg_gatherv(ctx, mine, root, G));
     if (X.rank != root) return 0;
     rattle_correction *R = (rattle_correction *)calloc(1, sizeof(rattle_correction));
     std::vector<piece_view> cor, unc;
@@ -301,16 +317,17 @@ int correction_gather(rattle_ctx *ctx, const rattle_correction *L, int root, rat
     uint64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < X.nranks; ++r) {
         size_t at = 0;
-        cor.push_back(take_set(all[r], at));
-        unc.push_back(take_set(all[r], at));
-        const uint64_t n = *take<uint64_t>(all[r], at, 1);
-        const uint64_t *ro = take<uint64_t>(all[r], at, n + 1);
-        const int32_t *cid = take<int32_t>(all[r], at, n);
-        const uint32_t *pk = take<uint32_t>(all[r], at, n), *stg = take<uint32_t>(all[r], at, n);
+        const uint8_t *b = G.p[r];
+        cor.push_back(take_set(b, at));
+        unc.push_back(take_set(b, at));
+        const uint64_t n = *take<uint64_t>(b, at, 1);
+        const uint64_t *ro = take<uint64_t>(b, at, n + 1);
+        const int32_t *cid = take<int32_t>(b, at, n);
+        const uint32_t *pk = take<uint32_t>(b, at, n), *stg = take<uint32_t>(b, at, n);
         const uint64_t tot = ro[n];
-        const int32_t *rid = take<int32_t>(all[r], at, tot);
-        if ((3 * n + tot) & 1) take<uint32_t>(all[r], at, 1);
-        const uint64_t *c8 = take<uint64_t>(all[r], at, 8);
+        const int32_t *rid = take<int32_t>(b, at, tot);
+        if ((3 * n + tot) & 1) take<uint32_t>(b, at, 1);
+        const uint64_t *c8 = take<uint64_t>(b, at, 8);
         for (uint64_t i = 0; i < n; ++i) sk.push_back(skip_ref{cid[i], pk[i], stg[i], rid + ro[i], ro[i + 1] - ro[i]});
         cnt[0] += c8[0]; cnt[1] += c8[1];                 // DP cells and alignments add up; the pack count is global already
         cnt[2] = c8[2];
@@ -407,18 +424,26 @@ int rattle_hip_comm_probe(rattle_ctx *c) {
     if (c->device >= 0) RT_HIP(hipSetDevice(c->device));
     // ragged pieces (one of them empty) through both exchange shapes the sharded paths use
     std::vector<uint8_t> mine((size_t)((X.rank * 1000 + 7) % 2501) * (X.rank % 3 != 1), (uint8_t)(X.rank + 1));
-    std::vector<std::vector<uint8_t>> all;
-    RT_TRY(xchg_allgatherv(c, mine, all));
-    for (int root = 0; root <= (X.nranks > 1); ++root) {
+    auto check = [&](const std::vector<const uint8_t *> &p, const std::vector<size_t> &n) -> int {
         for (int r = 0; r < X.nranks; ++r) {
             const size_t want = (size_t)((r * 1000 + 7) % 2501) * (r % 3 != 1);
-            bool ok = all[r].size() == want;
-            for (size_t i = 0; ok && i < want; ++i) ok = all[r][i] == (uint8_t)(r + 1);
+            bool ok = n[r] == want;
+            for (size_t i = 0; ok && i < want; ++i) ok = p[r][i] == (uint8_t)(r + 1);
             if (!ok) { set_error("exchange probe: the piece of rank " + std::to_string(r) + " arrived damaged on rank " + std::to_string(X.rank)); return RATTLE_ERR_HIP; }
         }
-        if (root == 1) break;
-        RT_TRY(xchg_gatherv(c, mine, X.nranks - 1, all));
-        if (X.rank != X.nranks - 1) break;
+        return 0;
+    };
+    std::vector<std::vector<uint8_t>> all;
+    RT_TRY(xchg_allgatherv(c, mine, all));
+    {
+        std::vector<const uint8_t *> p; std::vector<size_t> n;
+        for (const std::vector<uint8_t> &v : all) { p.push_back(v.data()); n.push_back(v.size()); }
+        RT_TRY(check(p, n));
+    }
+    if (X.nranks > 1) {
+        gathered G;
+        RT_TRY(xchg_gatherv(c, mine, X.nranks - 1, G));
+        if (X.rank == X.nranks - 1) RT_TRY(check(G.p, G.n));
     }
     return 0;
 }
