@@ -168,9 +168,22 @@ def main():
     ap.add_argument("--no-stage", action="store_true", help="hand the reads over as host buffers every step (PCIe-inclusive rate)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become N ranks (one per GPU) under torch.distributed.run.  The reference
+        # parallelises the same axes with in-process threads and needs no launcher (cluster.cpp:138-158, correct.cpp:377-392).
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); nothing was timed")
     # ranks of one node share the host cores for pack planning / result assembly
     os.environ.setdefault("RATTLE_HOST_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,6 +191,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     same_device = bool(os.environ.get("RATTLE_BENCH_ONE_DEVICE"))      # tests: several ranks on one GPU (gloo transport only)
+    if not same_device and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) on this node")
     if same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -336,7 +351,7 @@ def main():
         }
         if sharded:
             calls, xbytes = ctx.comm_stats()
-            out["exchange"] = {"transport": transport, "collectives": calls, "bytes_received": xbytes}
+            out["exchange"] = {"transport": transport, "ranks": world, "collectives": calls, "bytes_received": xbytes}
         if a.iso:
             out["config"] = {"workload": f"{n_reads} synthetic cDNA reads (mean 1 kb, 10% err, both strands, {genes} genes x 3 isoforms, Zipf abundance), "
                                          "`rattle cluster --iso` k=10 / iso k=11 (BASELINE configs[2])",

@@ -292,7 +292,6 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     *out = R;
     hipStream_t st = ctx->stream;
     phase_timer T_all("correct: total");
-    RT_TRY(ensure_post_constants(ctx));
     const int rank = ctx->xchg.rank, nranks = ctx->xchg.nranks;
 
     // ---- correct.cpp:328-370 pack building: ids and strands only, the bases stay where they are
@@ -330,6 +329,19 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     }
     const uint32_t n1 = (uint32_t)S1r.size();
 
+    // Several ranks: everything up to here depends on the arguments alone (the same on every rank).  From here on a rank
+    // works on its own packs, and a failure of its own (a bad base in one of ITS reads, a HIP error, an allocation) must not
+    // leave the other ranks blocked in the next all-gather: the rank remembers the error, keeps joining the exchanges with a
+    // failure record, and every rank returns an error after the exchange that carried it.
+    int local_rc = 0;
+    std::string local_msg;
+    auto local_step = [&](int r) -> bool {           // true: carry on with this rank's own work
+        if (r != 0 && local_rc == 0) { local_rc = r; local_msg = rattle_hip_last_error(); }
+        return local_rc == 0;
+    };
+#define LOCAL_TRY(call) do { if (local_rc == 0) { const int r_ = (call); if (r_ != 0) { if (nranks == 1) return r_; local_step(r_); } } } while (0)
+
+    LOCAL_TRY(ensure_post_constants(ctx));
     // only A, C, G, T, U are defined for the vote (an unordered_map key set in the reference)
     {
         bool ok[256] = {false};
@@ -341,7 +353,11 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
                 for (uint64_t b = off[S1r[q].rid]; b < off[S1r[q].rid + 1]; ++b)
                     if (!ok[seq[b]]) { bad = 1; return; }
         });
-        if (bad) { set_error("correct: read contains a base other than A, C, G, T, U"); return RATTLE_ERR_ARG; }
+        if (bad) {
+            set_error("correct: read contains a base other than A, C, G, T, U");
+            if (nranks == 1) return RATTLE_ERR_ARG;
+            local_step(RATTLE_ERR_ARG);
+        }
     }
 
     // skip list (this rank's share; unqueued entries on rank 0)
@@ -375,7 +391,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     struct joiner { std::thread &t; ~joiner() { if (t.joinable()) t.join(); } } d2h_join{d2h};      // also on error returns
     std::vector<uint32_t> cor_pack;
 
-    if (nm) {
+    auto stage1 = [&]() -> int {
         // ---- reads -> HBM, oriented pack members gathered into stage 1 (:343-346)
         const uint64_t total_in = off[n_reads];
         dbuf<uint8_t> d_rseq, d_rqual;
@@ -469,8 +485,14 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
                     uncorrected.push_back(oriented_read(seq, qual, off, S1r[q], tfront[q], tback[q]));
                     unc_cid.push_back(PL.pk_cid[mine[k]]); unc_pack.push_back(mine[k]);
                 }
-    } else {
+        return 0;
+    };
+    if (nm) LOCAL_TRY(stage1());
+    if (!nm || local_rc) {
+        if (d2h.joinable()) d2h.join();
+        if (R->corrected.off) { rattle_read_set &C = R->corrected; free(C.read_id); free(C.cluster_id); free(C.n_reads); free(C.off); free(C.seq); free(C.qual); C = rattle_read_set(); }
         fill_set(R->corrected, {}, {}, {});
+        cor_pack.clear();
     }
 
     // ---- POA #2 over the corrected reads of a pack, stably sorted by length desc (:427-445), + consensus vote;
@@ -514,8 +536,16 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     // exchange the results of one stage: pack consensi (kind 0) and cluster consensi (kind 1), dead flags included
     auto exchange_stage = [&](std::vector<uint8_t> &mine_bytes) -> int {
         std::vector<std::vector<uint8_t>> all;
-        if (nranks > 1) RT_TRY(xchg_allgatherv(ctx, mine_bytes, all));
-        else { all.resize(1); all[0].swap(mine_bytes); }
+        if (nranks > 1) {
+            if (local_rc) { mine_bytes.clear(); put_rec(mine_bytes, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr, 0); }      // failure record
+            RT_TRY(xchg_allgatherv(ctx, mine_bytes, all));
+            if (local_rc) { set_error(local_msg); return local_rc; }
+            for (int r = 0; r < nranks; ++r) {
+                uint32_t id = 0, flag = 0;
+                if (all[r].size() >= 12) { memcpy(&id, all[r].data(), 4); memcpy(&flag, all[r].data() + 4, 4); }
+                if (id == 0xFFFFFFFFu && flag == 0xFFFFFFFFu) { set_error("correct_reads failed on rank " + std::to_string(r)); return RATTLE_ERR_HIP; }
+            }
+        } else { all.resize(1); all[0].swap(mine_bytes); }
         for (const std::vector<uint8_t> &b : all) {
             size_t at = 0;
             while (at + 12 <= b.size()) {
@@ -583,7 +613,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         // stage 2a: my packs of the big clusters
         std::vector<uint32_t> s2a, s2b;
         for (uint32_t k = 0; k < nm; ++k) if (!pk_dead[mine[k]]) (big[PL.pk_cid[mine[k]]] ? s2a : s2b).push_back(k);
-        RT_TRY(cons_pass("correct: stage 2a", s2a, {}, bytes));
+        LOCAL_TRY(cons_pass("correct: stage 2a", s2a, {}, bytes));
         bool any_big = false;
         for (uint32_t c = 0; c < n_clusters; ++c) any_big |= big[c] != 0;
         if (any_big) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
@@ -599,9 +629,14 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
         lpt_assign(cost, nranks, own);
         for (size_t i = 0; i < g3a_all.size(); ++i) if ((int)own[i] == rank) g3a.push_back(g3a_all[i]);
-        RT_TRY(cons_pass("correct: stage 2b+3a", s2b, g3a, bytes));
+        LOCAL_TRY(cons_pass("correct: stage 2b+3a", s2b, g3a, bytes));
         RT_TRY(exchange_stage(bytes)); bytes.clear();
         if (d2h.joinable()) d2h.join();                  // S1.rowc is no longer needed once the download is done
+        if (d2h_err != hipSuccess) {
+            set_error(std::string("corrected reads download: ") + hipGetErrorString(d2h_err));
+            if (nranks == 1) return RATTLE_ERR_HIP;
+            local_step(RATTLE_ERR_HIP);
+        }
         S1.release();
         // stage 3b: POA #3 of the other clusters with more than one live pack
         std::vector<uint32_t> g3b_all, g3b;
@@ -614,12 +649,14 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
         lpt_assign(cost, nranks, own);
         for (size_t i = 0; i < g3b_all.size(); ++i) if ((int)own[i] == rank) g3b.push_back(g3b_all[i]);
-        RT_TRY(cons_pass("correct: stage 3b", {}, g3b, bytes));
-        if (!g3b_all.empty()) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
+        LOCAL_TRY(cons_pass("correct: stage 3b", {}, g3b, bytes));
+        // several ranks: this exchange always takes place, so that every rank leaves with the same verdict (the caller's
+        // next collective is the gather of the corrected reads)
+        if (!g3b_all.empty() || nranks > 1) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
     }
     if (d2h.joinable()) d2h.join();
     d_os.release(); d_oq.release();
-    if (d2h_err != hipSuccess) { set_error(std::string("corrected reads download: ") + hipGetErrorString(d2h_err)); return RATTLE_ERR_HIP; }
+#undef LOCAL_TRY
 
     std::vector<hread> consensi;
     std::vector<int32_t> con_cid, con_n;

@@ -115,3 +115,67 @@ def test_bench_sharded_on_one_device(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["checks"]["digest_equal_to_single_gpu"] and line["checks"]["digest_equal_across_steps"]
     assert line["checks"]["n_corrected"] + line["checks"]["n_uncorrected"] == 20000
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape) must become two ranks:
+    n_gpus == 2 in the line, the exchange reports two ranks, digest == the single-GPU digest."""
+    import json
+    env = dict(os.environ, RATTLE_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "20000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["exchange"]["ranks"] == 2 and line["exchange"]["collectives"] > 0
+    assert line["checks"]["digest_equal_to_single_gpu"] and line["checks"]["n_corrected"] + line["checks"]["n_uncorrected"] == 20000
+
+
+FAIL_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["RATTLE_ROOT"]); sys.path.insert(0, os.path.join(os.environ["RATTLE_ROOT"], "tests"))
+    import torch.distributed as dist
+    from rattle_amd import synth
+    from rattle_amd.api import Context
+    from test_dist_cpu import _plan
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cat, qcat, off, tid, _ = synth.reads_packed(1500, 6, 1, True, seed=5, exon=(50, 210))
+    ctx = Context(0)
+    ctx.set_exchange_gloo()
+    cl = ctx.cluster_unsorted_packed(cat, off)
+    plan = _plan(off, cl.offsets, cl.member_id, cl.member_rev, world, split=40)
+    victim = int(np.nonzero(plan["owner"] == world - 1)[0][0])          # a pack of the LAST rank only
+    bad = cat.copy()
+    bad[int(off[plan["member"][plan["first"][victim]]]) + 3] = ord("N")
+    try:
+        ctx.correct_packed(bad, qcat, off, cl, split=40, gather_root=0)
+        print("NO_ERROR", rank)
+    except RuntimeError as e:
+        msg = str(e)
+        assert ("base other than" in msg) == (rank == world - 1), msg
+        assert rank == world - 1 or "failed on rank %d" % (world - 1) in msg, msg
+        print("FAIL_OK", rank)
+    # the ranks are still in step: a good job right after the failed one
+    res = ctx.correct_packed(cat, qcat, off, cl, split=40, gather_root=0)
+    if rank == 0:
+        assert res[0] + res[1] == 1500
+        print("THEN_OK")
+    ctx.close()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_local_failure_reaches_every_rank_instead_of_hanging(tmp_path, world):
+    """A bad base in a read that only the last rank's packs hold: that rank must keep joining the exchanges
+    (correct_driver.hip: failure record) so that every rank returns an error -- none is left in an all-gather."""
+    script = tmp_path / "worker.py"
+    script.write_text(FAIL_WORKER)
+    env = dict(os.environ, RATTLE_ROOT=ROOT, MASTER_ADDR="127.0.0.1", RATTLE_HOST_THREADS="8")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29730 + world), str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("FAIL_OK") == world and "THEN_OK" in r.stdout and "NO_ERROR" not in r.stdout
