@@ -43,6 +43,21 @@ namespace rattle {
 #define POA_NEG (-(1 << 28))
 #define POA_STACK 512
 #define POA_NONE 0xFFFFFFFFu
+#ifndef POA_V3
+#define POA_V3 1                           // packed classes whose ring is a power of two take dp_rows_v3
+#endif
+#ifndef POA_MW_4x4
+#define POA_MW_4x4 6
+#endif
+#ifndef POA_MW_4x6
+#define POA_MW_4x6 5
+#endif
+#ifndef POA_RING_4x4
+#define POA_RING_4x4 8
+#endif
+#ifndef POA_RING_4x6
+#define POA_RING_4x6 8
+#endif
 #ifndef POA_MW_2x8
 #define POA_MW_2x8 4
 #endif
@@ -79,6 +94,7 @@ struct poa_args {
     uint32_t *out_width;           // per pack
     uint32_t *status;              // per pack: 0 ok, else error code
     unsigned long long *counters;  // [0] DP cells, [1] alignments, [2] final nodes, [3] rows, [4..7] phase ticks
+    unsigned long long *timeline;  // RATTLE_POA_TIMELINE: per pack {start, end} of its workgroup's work on it (100 MHz wall clock), else null
     unsigned long long *prof;      // POA_PROFILE builds: per class [0] plan [1] DP [2] ties [3] traceback [4] add_alignment [5] merge_order [6] final sort + columns [7] whole packs
 };
 
@@ -978,6 +994,262 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     multi = best > 0;
 }
 
+// ---- the packed row recurrence, third form (classes up to 2560 columns) ------------------------------
+// Same arithmetic, same record and ring words as dp_rows_pk; what changed is everything around the per-pair work, because the
+// kernel is bound by VALU issue and by the length of a row's instruction stream (profiles/README.md, round 3):
+//   * the row plan comes through the scalar cache: three s_load_dwordx4 per row (the plan arrays read as constant address
+//     space after an s_dcache_inv), prefetched one row ahead -- no v_readlane per plan word, no plan registers, no 64-row chunks;
+//   * every predecessor comes from the LDS ring (or, beyond RING rows, from the record): no register copy of the previous
+//     row, so the row body exists once per parity and the ring slot is `row & (RING - 1)`;
+//   * the record word is decoded with v_pk_lshrrev_b16 (4 instructions per pair and predecessor instead of 5);
+//   * the in-thread prefix of u: v = max(RUN, u) ; EX = alignbit(v, RUN) ; RUN = max(v, swap(v)) -- 3 instructions per pair
+//     instead of 5 (the half swap is an op_sel of v_pk_max_i16).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4 *cplan_t;      // wave-uniform loads from it are s_load_dwordx4
+
+template <int CPL, int RING, int NW>
+__device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
+    constexpr int NT = 64 * NW, NP = CPL / 2;
+    static_assert(RING > 0, "the rows of the last RING rows live in LDS");
+    static_assert(NT * CPL <= 2560 && NW <= 4, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t c0 = (uint32_t)tid * CPL;
+    const bool act = c0 < Lp;
+    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
+    {
+        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
+#pragma unroll
+        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
+#pragma unroll
+        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
+    }
+    uint32_t SEL[NP];                            // score table selectors (see dp_rows_pk)
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
+        const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
+        const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
+        SEL[u] = sa | (sb << 16);
+    }
+    const bool plain = S.plain != 0;
+    s16x2 JE[NP], UC[NP];                        // per column: j*e and g - (j+1)*e
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int j0 = (int)c0 + 2 * u + 1, j1 = j0 + 1;
+        const s16x2 je = {(short)(j0 * POA_E), (short)(j1 * POA_E)};
+        const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
+        JE[u] = je; UC[u] = uc;
+    }
+    s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
+    const bool wave_act = (uint32_t)wave * 64u * CPL < Lp;
+    uint32_t *const ring_thr = S.ring + (size_t)tid * NP;              // slot s of this thread: ring_thr + s * NT * NP
+    uint32_t *const lhr = (uint32_t *)S.lh_ring + wave;                // slot s of this wavefront: lhr[4 * s]
+    uint32_t *const Hrec = (uint32_t *)S.H;                            // the record, a dword per column pair
+
+    // the plan through the scalar cache: invalidate it first (the plan was just rewritten by vector stores, which are in L2
+    // once the barrier ahead of this function has been passed); the pointers depend on the invalidate so that no load moves above it
+    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc;
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc) : : "memory");
+    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
+
+    auto step = [&](auto par_tag, const uint32_t row, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
+        constexpr uint32_t par = decltype(par_tag)::value;
+        const uint32_t info = pa.x;
+        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+        s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
+        uint32_t raw[4][NP], rawl[4];
+        auto fetch = [&](const int k, const uint32_t prow) __attribute__((always_inline)) {
+            if (row - prow <= (uint32_t)RING) {
+                const uint32_t slot = prow % (uint32_t)RING;
+                const uint32_t *rp = ring_thr + slot * (uint32_t)(NT * NP);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) raw[k][u] = rp[u];
+                rawl[k] = lhr[4 * slot];
+            } else {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) raw[k][u] = 0x80008000u;          // H = 0, H - F = 2: what a column beyond the row decodes to
+                rawl[k] = 0;
+                if (act) {
+                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) raw[k][u] = hq[u];
+                    if (lane == 0 && wave > 0) rawl[k] = ((uint32_t)((const uint16_t *)S.H)[(uint64_t)prow * Lp + c0 - 1] & 0x3FFFu) << 16;
+                }
+                drain_vector_loads();            // rare path (1-2 % of the fetches): nothing stays pending past it
+            }
+        };
+        auto combine = [&](auto first_tag, const uint32_t (&w)[NP], const uint32_t wl) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            uint32_t hp[NP];
+            s16x2 FD[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                hp[u] = w[u] & 0x3FFF3FFFu;
+                u16x2 wu;
+                __builtin_memcpy(&wu, &w[u], 4);
+                const u16x2 d = __builtin_elementwise_min(wu >> (u16x2){14, 14}, (u16x2){2, 2});      // min(H - F, 2)
+                s16x2 ds;
+                __builtin_memcpy(&ds, &d, 4);
+                FD[u] = as_pk(hp[u]) - ds;                                                            // max(H + g - e, F)
+            }
+            const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const s16x2 HD = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
+                HM[u] = FIRST ? HD : pk_max(HM[u], HD);
+                FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
+            }
+        };
+        if (n_in == 0) {                         // virtual start row: H = 0, F = -inf
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
+        } else {
+            fetch(0, pb.x);
+            if (n_in > 1) fetch(1, pb.y);
+            if (n_in > 2) fetch(2, pb.z);
+            if (n_in > 3) fetch(3, pb.w);
+            combine(std::true_type{}, raw[0], rawl[0]);
+            if (n_in > 1) combine(std::false_type{}, raw[1], rawl[1]);
+            if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
+            if (n_in > 3) {
+                combine(std::false_type{}, raw[3], rawl[3]);
+                if (n_in > 4) {
+                    fetch(0, pc.x);
+                    if (n_in > 5) fetch(1, pc.y);
+                    if (n_in > 6) fetch(2, pc.z);
+                    if (n_in > 7) fetch(3, pc.w);
+                    combine(std::false_type{}, raw[0], rawl[0]);
+                    if (n_in > 5) combine(std::false_type{}, raw[1], rawl[1]);
+                    if (n_in > 6) combine(std::false_type{}, raw[2], rawl[2]);
+                    if (n_in > 7) combine(std::false_type{}, raw[3], rawl[3]);
+                    if (n_in > 8) {
+                        uint32_t e = pa.w;
+                        for (uint32_t k = 8; k < n_in; ++k) {
+                            const uint2 ed = S.edges[e]; e = ed.y;
+                            const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
+                            drain_vector_loads();
+                            fetch(0, prow);
+                            combine(std::false_type{}, raw[0], rawl[0]);
+                        }
+                    }
+                }
+            }
+        }
+        // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
+        s16x2 HNp[NP], EX[NP], SC[NP], FN[NP];
+        s16x2 RUN = pk_splat(-32768);
+        if (plain) {
+            const uint32_t li = (letter >> 1) & 3u;
+            const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));      // low / high bytes of {-4, -4, -4, -4} with 5 at li
+#pragma unroll
+            for (int u = 0; u < NP; ++u) SC[u] = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                SC[u] = as_pk(pack16(s0, s1));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            FN[u] = FM[u] + pk_splat(POA_E);
+            HNp[u] = pk_max(pk_max(HM[u] + SC[u], FN[u]), pk_splat(0));
+            const s16x2 v = pk_max(RUN, HNp[u] + UC[u]);                                   // (max(run, u_a), max(run, u_b))
+            EX[u] = as_pk(__builtin_amdgcn_alignbit(as_u(v), as_u(RUN), 16));              // (run, max(run, u_a)): both halves of RUN are equal
+            RUN = pk_max(v, __builtin_shufflevector(v, v, 1, 0));                          // max(run, u_a, u_b) in both halves
+        }
+        const int32_t run = (int32_t)(int16_t)(as_u(RUN) & 0xFFFFu);
+        const int32_t wincl = wave_scan_max_fused(act ? run : POA_NEG);
+        const int32_t texcl = wave_shr1(wincl, POA_NEG);
+        int32_t base = POA_G - POA_E;            // u_0
+        int32_t hl_new = 0;
+        if (NW > 1) {
+            if (lane == 63) {
+                const int32_t ex_last = (int32_t)as_u(EX[NP - 1]) >> 16, hn_last = (int32_t)as_u(HNp[NP - 1]) >> 16;
+                ((int32_t *)&X.T[par])[wave] = wincl;
+                if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex_last), hn_last);
+            }
+            row_barrier();
+            const int4 T = X.T[par];
+            const int32_t Tx = __builtin_amdgcn_readfirstlane(T.x), Ty = __builtin_amdgcn_readfirstlane(T.y), Tz = __builtin_amdgcn_readfirstlane(T.z);
+            const int32_t t0 = wave > 0 ? Tx : POA_NEG, t1 = wave > 1 ? Ty : POA_NEG, t2 = wave > 2 ? Tz : POA_NEG;
+            const int32_t b0 = wave > 1 ? Tx : POA_NEG, b1 = wave > 2 ? Ty : POA_NEG;
+            base = max(max(base, t0), max(t1, t2));
+            if (wave > 0) {
+                const int2 q = X.Q[par][wave];
+                const int32_t qx = __builtin_amdgcn_readfirstlane(q.x), qy = __builtin_amdgcn_readfirstlane(q.y);
+                const int32_t bp = max(max(POA_G - POA_E, b0), b1);
+                const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);
+                hl_new = max(qy, max(bp, qx) + c0w * POA_E);
+            }
+        }
+        base = max(base, texcl);
+        const s16x2 BASE = as_pk(pack16(base, base));
+        uint32_t W[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const s16x2 EV = pk_max(BASE, EX[u]) + JE[u];
+            const s16x2 HN = pk_max(HNp[u], EV);
+            MXA = pk_max(MXA, HN);
+            W[u] = as_u(HN) | (as_u(pk_min(HN - FN[u], pk_splat(3))) << 14);       // H (14 bits) | min(H - F, 3) << 14: ring, later rows, traceback
+        }
+        {
+            const uint32_t slot = row % (uint32_t)RING;
+            uint32_t *rp = ring_thr + slot * (uint32_t)(NT * NP);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) rp[u] = W[u];
+            if (lane == 0) lhr[4 * slot] = (uint32_t)hl_new << 16;
+            if (act) {
+                uint32_t *hq = Hrec + ((uint64_t)row * Lp >> 1) + (c0 >> 1);
+                if (NP % 2 == 0) {
+#pragma unroll
+                    for (int u = 0; u < NP / 2; ++u) ((uint2 *)hq)[u] = make_uint2(W[2 * u], W[2 * u + 1]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) hq[u] = W[u];
+                }
+            }
+        }
+    };
+
+    if (!wave_act) {
+        if (NW > 1) for (uint32_t r = 0; r < n; ++r) row_barrier();
+    } else {
+        u32x4 na = cpa[0], nb = cpb[0], nc = cpc[0];      // plan of the next row, one row ahead
+        for (uint32_t row = 1; row <= n; row += 2) {
+            {
+                const u32x4 pa = na, pb = nb, pc = nc;
+                if (row < n) { na = cpa[row]; nb = cpb[row]; nc = cpc[row]; }
+                step(std::integral_constant<uint32_t, 1>{}, row, pa, pb, pc);
+            }
+            if (row + 1 <= n) {
+                const u32x4 pa = na, pb = nb, pc = nc;
+                if (row + 1 < n) { na = cpa[row + 1]; nb = cpb[row + 1]; nc = cpc[row + 1]; }
+                step(std::integral_constant<uint32_t, 0>{}, row + 1, pa, pb, pc);
+            }
+        }
+    }
+    // block-wide best score and the threads whose columns reach it (the first row that reaches it comes from a rescan of
+    // those threads' columns in the record, kernel body)
+    const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wave] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
+    __syncthreads();
+    best = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
+    if (best > 0 && lbest == best) {
+        const uint32_t slot = atomicAdd(&X.ntl, 1u);
+        if (slot < 16) X.tl[slot] = (uint32_t)tid;
+    }
+    __syncthreads();
+    best_row = 0;
+    multi = best > 0;
+}
+
 // ---- rows longer than any register class (PK == 2): int32 cells, 1024-column segments ---------------
 // Reads beyond 6144 nt are rare (the tail of a cDNA run) but must not fail the call.  Same recurrence,
 // no register window and no ring: every predecessor row comes back from the int32 H / F matrices
@@ -1136,7 +1408,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
 constexpr int poa_min_waves(int CPL, int NW, int PK) {
-    return PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? 6 : 5) : NW == 4 && CPL == 6 ? (PK ? 5 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
+    return PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
            : PK == 1 && NW == 1 && CPL == 16 ? POA_MW_1x16 : 1;
 }
 template <int CPL, int RING, int NW, int PK>
@@ -1175,6 +1447,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         if (qi >= A.n_queue) break;
         const uint32_t pk = A.queue[qi];
         const uint32_t q0 = A.pack_first[pk], q1 = A.pack_first[pk + 1];
+        if (A.timeline && tid == 0) A.timeline[2 * pk] = (unsigned long long)wall_clock64();
         S.n_nodes = 0; S.n_edges = 0; S.err = 0; S.sp = 0; S.spilled = 0;
         if (tid == 0) s_alpha = 0;
         unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0, t_tie = 0, t_merge = 0;
@@ -1233,6 +1506,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                 int32_t best; uint32_t best_row;
                 bool multi = false;
                 if constexpr (PK == 2) dp_rows_long<NW>(S, X, s, n, L, Lp, best, best_row, multi);
+                else if constexpr (PK == 1 && POA_V3) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 cells += (unsigned long long)n * L;
@@ -1760,6 +2034,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         if (tid == 0) {
             A.out_width[pk] = width;
             A.status[pk] = S.err;
+            if (A.timeline) A.timeline[2 * pk + 1] = (unsigned long long)wall_clock64();
             atomicAdd(&A.counters[0], cells);
             atomicAdd(&A.counters[1], (unsigned long long)(q1 - q0));
 #ifdef POA_PROFILE
@@ -1809,7 +2084,7 @@ struct poa_variant {
 #define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, PK, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
 #define POA_CLASSES 8
 static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144, 8192};
-static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, 10, 4, 1), POA_VARIANT(6, 8, 4, 1), POA_VARIANT(8, 10, 4, 1), POA_VARIANT(10, 8, 4, 1),
+static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1),
                                                    POA_VARIANT(16, 4, 4, 0), POA_VARIANT(24, 5, 4, 0), POA_VARIANT(32, 3, 4, 0),
                                                    POA_VARIANT(4, 0, 4, 2) /* longer than 8192: int32 cells, segmented rows */};
 static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
@@ -1819,7 +2094,10 @@ static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIAN
 // per pack -- the per-row fixed cost (scan, exchange, scalar bookkeeping) is paid per wavefront
 // (measured round 2, profiles/README.md: 16 columns x 1 wavefront and 8 / 12 columns x 2 wavefronts are within noise of the
 // defaults in the full benchmark; two of them are kept selectable)
-static const poa_variant k_exp[] = {POA_VARIANT(16, 4, 1, 1), POA_VARIANT(8, 6, 2, 1), POA_VARIANT(12, 6, 2, 1)};
+#ifndef POA_EXP_RING
+#define POA_EXP_RING 8
+#endif
+static const poa_variant k_exp[] = {POA_VARIANT(16, 4, 1, 1), POA_VARIANT(8, POA_EXP_RING, 2, 1), POA_VARIANT(12, POA_EXP_RING, 2, 1)};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -1890,6 +2168,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     }
     dbuf<uint32_t> d_heads;
     RT_TRY(d_heads.reserve(8));
+    // RATTLE_POA_TIMELINE=<file>: when each pack's workgroup started and finished it (measurement aid: how full the device is over a pass)
+    const char *tl_path = getenv("RATTLE_POA_TIMELINE");
+    dbuf<unsigned long long> d_tl;
+    if (tl_path) { RT_TRY(d_tl.reserve(2 * (size_t)n_packs)); RT_HIP(hipMemsetAsync(d_tl.p, 0, 16 * (size_t)n_packs, st)); }
     struct cls_plan {
         std::vector<uint32_t> todo;
         uint32_t node_cap = getenv("RATTLE_POA_NODE_CAP") ? (uint32_t)std::max(64, atoi(getenv("RATTLE_POA_NODE_CAP"))) : 10240u;   // first-round capacity (tests lower it to force re-runs)
@@ -2042,6 +2324,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p + qoff; A.n_queue = (uint32_t)P.todo.size();
             A.queue_head = d_heads.p + c; A.arena = ctx->poa_arena + aoff; A.slot_stride = P.per_slot;
             A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p; A.prof = d_cnt.p + 32 + 8 * c;
+            A.timeline = tl_path ? d_tl.p : nullptr;
             aoff += P.per_slot * P.n_slots;
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
@@ -2107,6 +2390,20 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
 #endif
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
+    }
+    if (rc == 0 && tl_path) {
+        std::vector<unsigned long long> tl(2 * (size_t)n_packs);
+        if (hipMemcpy(tl.data(), d_tl.p, 16 * (size_t)n_packs, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(tl_path, "a")) {
+                fprintf(f, "# pass: pack class reads bases start end (ticks of 10 ns)\n");
+                for (uint32_t p = 0; p < n_packs; ++p) {
+                    int cls = 0;
+                    while (cls < POA_CLASSES - 1 && pmaxL[p] > k_class_cols[cls]) ++cls;
+                    fprintf(f, "%u %d %u %llu %llu %llu\n", p, cls, pack_first[p + 1] - pack_first[p], (unsigned long long)pbases[p], tl[2 * p], tl[2 * p + 1]);
+                }
+                fclose(f);
+            }
+        }
     }
     d_pf.release(); d_queue.release(); d_status.release(); d_cnt.release();
     if (rc) return rc;
