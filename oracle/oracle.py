@@ -130,6 +130,22 @@ class Oracle(_Lib):
         return out + (cnt,)
 
 
+    def fix_msa_ends(self, rows, seqs, quals):
+        """correct.cpp:32-92 on hand-built rows; returns (rows, seqs, quals) as the reference leaves them."""
+        n, width = len(rows), len(rows[0])
+        assert all(len(r) == width for r in rows)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        rb = C.create_string_buffer(b"".join(rows), n * width)
+        sb = C.create_string_buffer(b"".join(seqs) + b"\0"); qb = C.create_string_buffer(b"".join(quals) + b"\0")
+        ln = np.zeros(n, np.uint32)
+        self.lib.orc_fix_msa_ends(rb, C.c_uint32(n), C.c_uint32(width), sb, qb, _ptr(off, C.c_uint64), _ptr(ln, C.c_uint32))
+        out_rows = [rb.raw[i * width:(i + 1) * width] for i in range(n)]
+        out_s = [sb.raw[int(off[i]):int(off[i]) + int(ln[i])] for i in range(n)]
+        out_q = [qb.raw[int(off[i]):int(off[i]) + int(ln[i])] for i in range(n)]
+        return out_rows, out_s, out_q
+
+
 class Ref(_Lib):
     """The real reference TUs (oracle/_ref/libref.so), when built."""
 

@@ -119,6 +119,26 @@ int32_t orc_correct(const char *seqs, const char *quals, const uint64_t *off, ui
     return 0;
 }
 
+
+// fix_msa_ends (correct.cpp:32-92) on hand-built MSA rows: rows are `width` bytes each and are rewritten in place; the
+// reads' sequences / qualities (concatenated at off[]) are mutated the way the reference mutates them, and their new
+// lengths returned (the bytes themselves are moved to the front of each read's slot).
+void orc_fix_msa_ends(char *rows, uint32_t n, uint32_t width, char *seqs, char *quals, const uint64_t *off, uint32_t *len_out) {
+    read_set_t rs;
+    msa_t msa;
+    for (uint32_t i = 0; i < n; ++i) {
+        rs.push_back(read_t{"", std::string(seqs + off[i], seqs + off[i + 1]), "+", std::string(quals + off[i], quals + off[i + 1])});
+        msa.push_back(std::string(rows + (size_t)i * width, width));
+    }
+    fix_msa_ends(rs, msa);
+    for (uint32_t i = 0; i < n; ++i) {
+        memcpy(rows + (size_t)i * width, msa[i].data(), width);
+        memcpy(seqs + off[i], rs[i].seq.data(), rs[i].seq.size());
+        memcpy(quals + off[i], rs[i].quality.data(), rs[i].quality.size());
+        len_out[i] = (uint32_t)rs[i].seq.size();
+    }
+}
+
 void orc_free(void *p) { free(p); }
 
 // Column-vote tie-break order (6 symbols), see orc_correct.hpp.

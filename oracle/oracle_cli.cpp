@@ -39,8 +39,7 @@ int main(int argc, char **argv) {
         P.iso = flag(argc, argv, "--iso");
         int lower = atoi(opt(argc, argv, "--lower-length", "150")), upper = atoi(opt(argc, argv, "--upper-length", "100000"));
         bool raw = flag(argc, argv, "--raw");
-        int index = 0;
-        read_set_t reads = read_fastq_cluster(opt(argc, argv, "-i", ""), "", index, raw, lower, upper);
+        read_set_t reads = read_multiple_inputs_cluster(split_commas(opt(argc, argv, "-i", "")), split_commas(opt(argc, argv, "-l", "")), raw, lower, upper);
         std::cout << "Reads: " << reads.size() << std::endl;
         work_counters_t wc;
         cluster_set_t cs = cluster_command(reads, P, &wc);
@@ -54,11 +53,12 @@ int main(int argc, char **argv) {
     }
     if (mode == "correct") {
         if (strlen(opt(argc, argv, "--cv-order", "")) == 6) set_cv_order(opt(argc, argv, "--cv-order", ""));
-        read_set_t reads = read_fastq_plain(opt(argc, argv, "-i", ""), "");
+        const std::vector<std::string> labels = split_commas(opt(argc, argv, "-l", ""));
+        read_set_t reads = read_multiple_inputs(split_commas(opt(argc, argv, "-i", "")), labels);
         cluster_set_t cs = hps_read_file(opt(argc, argv, "-c", ""));
         correct_counters_t cc;
         correction_results_t R = correct_reads(cs, reads, atof(opt(argc, argv, "-m", "0.3")), atof(opt(argc, argv, "-g", "0.3")),
-                                               30.0, atoi(opt(argc, argv, "-s", "200")), atoi(opt(argc, argv, "-r", "5")), {}, &cc);
+                                               30.0, atoi(opt(argc, argv, "-s", "200")), atoi(opt(argc, argv, "-r", "5")), labels, &cc);
         std::string o = opt(argc, argv, "-o", ".");
         write_fastq(R.corrected, o + "/corrected.fq");
         write_fastq(R.uncorrected, o + "/uncorrected.fq");
@@ -99,6 +99,18 @@ int main(int argc, char **argv) {
             gid = -1;
         }
         write_fastq(R.consensi, std::string(opt(argc, argv, "-o", ".")) + "/transcriptome.fq");
+        return 0;
+    }
+    if (mode == "dump-reads") {                                   // tests: the restated readers against the real fasta.cpp (oracle/_ref)
+        int kind = atoi(opt(argc, argv, "--kind", "0")), index = atoi(opt(argc, argv, "--index", "0"));
+        const std::string path = opt(argc, argv, "-i", ""), label = opt(argc, argv, "-l", "");
+        bool raw = flag(argc, argv, "--raw");
+        int lower = atoi(opt(argc, argv, "--lower-length", "150")), upper = atoi(opt(argc, argv, "--upper-length", "100000"));
+        read_set_t rs = kind == 0 ? read_fastq_plain(path, label) : kind == 1 ? read_fastq_cluster(path, label, index, raw, lower, upper)
+                      : kind == 2 ? read_fasta_plain(path, label) : read_fasta_cluster(path, label, index, raw, lower, upper);
+        std::ofstream f(opt(argc, argv, "-o", "/dev/stdout"), std::ofstream::binary);
+        for (auto &r : rs) f << r.header << "\t" << r.seq << "\t" << r.ann << "\t" << r.quality << "\n";
+        std::cout << ((kind == 1 || kind == 3) ? index : 0) << std::endl;
         return 0;
     }
     std::cerr << "unknown mode\n";

@@ -7,8 +7,10 @@
 #pragma once
 #include <fstream>
 #include <iostream>
+#include <sstream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "orc_cluster.hpp"
 
@@ -62,6 +64,116 @@ inline read_set_t read_fastq_cluster(const std::string &file, const std::string 
         }
     }
     return out;
+}
+
+
+// fasta.cpp:33-96: FASTA, plain variant (`correct` / `polish` input): every record, sequence upper-cased (:131 / :57),
+// ann "+", quality '~' per base; a DOS file loses the last byte of every line.  The first header is taken as is,
+// whatever its first character.
+inline read_set_t read_fasta_plain(const std::string &file, const std::string &sample_id) {
+    read_set_t out;
+    std::ifstream in(file);
+    std::string line, header, seq;
+    if (!std::getline(in, line)) return out;
+    bool dos = !line.empty() && line[line.size() - 1] == '\r';
+    chomp_cr(line, dos);
+    header = line + sample_id;
+    auto flush = [&]() {
+        for (auto &c : seq) c = (char)::toupper((unsigned char)c);
+        out.push_back(read_t{header, seq, "+", std::string(seq.size(), '~')});
+    };
+    while (std::getline(in, line)) {
+        if (line.size() == 0) continue;
+        if (line[0] == '>') {
+            if (!header.empty()) flush();
+            seq.clear();
+            chomp_cr(line, dos);
+            header = line + sample_id;
+        } else {
+            chomp_cr(line, dos);
+            seq += line;
+        }
+    }
+    flush();
+    return out;
+}
+
+// fasta.cpp:98-205: FASTA, cluster variant: ann = running record index, upper-cased, length filter unless raw, reads with
+// 'N' skipped.  The Unix branch advances the index at EVERY header line (:146, outside the `!header.empty()` test),
+// the DOS branch only when the pending header is not empty (:176); the last record takes the index as it stands and
+// the next free index is one more (:203).
+inline read_set_t read_fasta_cluster(const std::string &file, const std::string &sample_id, int &index, bool raw, int lower_len, int upper_len) {
+    read_set_t out;
+    std::ifstream in(file);
+    std::string line, header, seq;
+    if (!std::getline(in, line)) return out;
+    bool dos = !line.empty() && line[line.size() - 1] == '\r';
+    chomp_cr(line, dos);
+    header = line + sample_id;
+    auto keep = [&]() {
+        for (auto &c : seq) c = (char)::toupper((unsigned char)c);
+        const bool len_ok = raw || ((int)seq.length() >= lower_len && (int)seq.length() <= upper_len);
+        if (len_ok && seq.find('N') == std::string::npos) out.push_back(read_t{header, seq, std::to_string(index), ""});
+    };
+    while (std::getline(in, line)) {
+        if (line.size() == 0) continue;
+        if (line[0] == '>') {
+            if (!header.empty()) { keep(); if (dos) ++index; }
+            if (!dos) ++index;
+            seq.clear();
+            chomp_cr(line, dos);
+            header = line + sample_id;
+        } else {
+            chomp_cr(line, dos);
+            seq += line;
+        }
+    }
+    if (!header.empty()) keep();
+    ++index;
+    return out;
+}
+
+inline std::vector<std::string> split_commas(const std::string &s) {          // utils.cpp splitString(str, ',')
+    std::vector<std::string> out;
+    std::stringstream ss(s);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) out.push_back(tok);
+    return out;
+}
+
+inline std::string file_extension(const std::string &f) { return f.substr(f.find_last_of(".") + 1); }
+
+// main.cpp:16-64: every input file in turn, header += "," + label, one running record index over all files
+inline read_set_t read_multiple_inputs_cluster(const std::vector<std::string> &files, const std::vector<std::string> &labels, bool raw, int lower_len, int upper_len) {
+    if (!labels.empty() && labels.size() != files.size()) throw std::runtime_error("Number of input files and number of label files do not match");
+    read_set_t reads;
+    int index = 0;
+    for (size_t i = 0; i < files.size(); ++i) {
+        const std::string lab = labels.empty() ? "" : "," + labels[i];
+        const std::string ext = file_extension(files[i]);
+        read_set_t part;
+        if (ext == "fq" || ext == "fastq") part = read_fastq_cluster(files[i], lab, index, raw, lower_len, upper_len);
+        else if (ext == "fasta" || ext == "fa") part = read_fasta_cluster(files[i], lab, index, raw, lower_len, upper_len);
+        else throw std::runtime_error("Input file format incorrect! Please use fasta/fastq file.");
+        reads.insert(reads.end(), part.begin(), part.end());
+    }
+    return reads;
+}
+
+// main.cpp:66-109
+inline read_set_t read_multiple_inputs(const std::vector<std::string> &files, const std::vector<std::string> &labels) {
+    if (!labels.empty() && labels.size() != files.size()) throw std::runtime_error("Number of input files and number of label files do not match");
+    read_set_t reads;
+    for (size_t i = 0; i < files.size(); ++i) {
+        const std::string lab = labels.empty() ? "" : "," + labels[i];
+        const std::string ext = file_extension(files[i]);
+        read_set_t part;
+        if (ext == "fq" || ext == "fastq") part = read_fastq_plain(files[i], lab);
+        else if (ext == "fasta" || ext == "fa") part = read_fasta_plain(files[i], lab);
+        else throw std::runtime_error("Input file format incorrect! Please use fasta/fastq file.");
+        reads.insert(reads.end(), part.begin(), part.end());
+    }
+    return reads;
 }
 
 inline void write_fastq(const read_set_t &reads, const std::string &file) {   // fasta.cpp:436-445

@@ -5,6 +5,7 @@
 // the restatement in orc_cluster.hpp (tests/test_oracle_vs_ref.py) and, on the GPU box
 // (where the prebuilt .so travels), as an extra checker.
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -63,6 +64,24 @@ int32_t ref_read_fastq_cluster(const char *path, int raw, int lower, int upper, 
     int32_t n = (int32_t)rs.size();
     for (int32_t i = 0; i < n && i < cap; ++i) { ann_out[i] = std::stoi(rs[i].ann); len_out[i] = (int32_t)rs[i].seq.size(); }
     return n;
+}
+
+
+// Any of the four readers of fasta.cpp dumped as text, one record per line: header \t seq \t ann \t quality.
+// kind: 0 FASTQ plain (:207-270), 1 FASTQ cluster (:272-370), 2 FASTA plain (:33-96), 3 FASTA cluster (:98-205).
+// Returns the next free record index of the cluster variants (smuggled through back().quality, main.cpp:47), else 0.
+int32_t ref_dump_reads(const char *path, const char *label, int kind, int index, int raw, int lower, int upper, const char *out_path) {
+    read_set_t rs;
+    int32_t next = 0;
+    if (kind == 0) rs = read_fastq_file(std::string(path), std::string(label));
+    else if (kind == 1) rs = read_fastq_file(std::string(path), std::string(label), index, raw != 0, lower, upper);
+    else if (kind == 2) rs = read_fasta_file(std::string(path), std::string(label));
+    else rs = read_fasta_file(std::string(path), std::string(label), index, raw != 0, lower, upper);
+    if ((kind == 1 || kind == 3) && !rs.empty()) { next = std::stoi(rs.back().quality); rs.back().quality = ""; }
+    FILE *f = fopen(out_path, "wb");
+    for (auto &r : rs) fprintf(f, "%s\t%s\t%s\t%s\n", r.header.c_str(), r.seq.c_str(), r.ann.c_str(), r.quality.c_str());
+    fclose(f);
+    return next;
 }
 
 }  // extern "C"

@@ -43,6 +43,9 @@ namespace rattle {
 #define POA_NEG (-(1 << 28))
 #define POA_STACK 512
 #define POA_NONE 0xFFFFFFFFu
+#ifndef POA_WIDE_RING
+#define POA_WIDE_RING 4                    // rows of the wide classes kept in LDS (a dword per cell: 32 KB per row at 8192 columns)
+#endif
 #ifndef POA_V3
 #define POA_V3 1                           // packed classes whose ring is a power of two take dp_rows_v3
 #endif
@@ -128,6 +131,8 @@ struct poa_ws {                    // per-block workspace: global pointers + LDS
     uint32_t plain;                        // the pack's letters so far are all in {A,C,G,T} or all in {A,C,G,U}: scores by table look-up
 };
 
+// words of one node bitmap in LDS: an even number, so that what follows the two bitmaps and the stack (the ring) is 16-byte aligned
+__host__ __device__ constexpr uint32_t poa_bit_words(uint32_t node_cap) { return ((node_cap + 63u) / 64u) * 2u; }
 __device__ __forceinline__ bool bit_get(const uint32_t *b, uint32_t i) { return (b[i >> 5] >> (i & 31)) & 1u; }
 __device__ __forceinline__ void bit_set(uint32_t *b, uint32_t i) { b[i >> 5] |= 1u << (i & 31); }
 __device__ __forceinline__ uint32_t rd_letter(uint32_t info) { return info & 0xFFu; }
@@ -413,7 +418,9 @@ template <int CPL> using ebits_t = typename ebits_sel<CPL>::type;
 struct dp_xchg {                 // LDS
     int4 T[2];                   // double-buffered by row parity: per wave, inclusive max of u
     int2 Q[2][4];                // for wave w: {max of u of wave w-1 without its last column, Hn of that column}
-    int32_t best[4];
+    int32_t best[16];
+    int32_t TW[2][16];           // blocks of more than four wavefronts (dp_rows_wide): inclusive max of u per wavefront ...
+    int2 QW[2][16];              // ... and {max of u of the wavefront to the left without its last column, Hn of that column}
     uint32_t brow;               // first row that reaches the best score
     uint32_t multi;              // 1: more than one row may reach it
     uint32_t ntl;                // number of threads whose columns reach it
@@ -1250,19 +1257,217 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     multi = best > 0;
 }
 
-// ---- rows longer than any register class (PK == 2): int32 cells, 1024-column segments ---------------
-// Reads beyond 6144 nt are rare (the tail of a cDNA run) but must not fail the call.  Same recurrence,
-// no register window and no ring: every predecessor row comes back from the int32 H / F matrices
-// (the column left of a thread's block too, so a full __syncthreads() orders the rows), a row is a
-// loop over segments of NT*4 columns, and the running prefix maximum of u is carried from segment to
-// segment.  Speed is not the point here.
-template <int NW>
+// ---- rows of 2561 .. 8192 columns (PK == 3): 32-bit cells, up to SIXTEEN wavefronts per pack ------------------
+// A pack of long reads used to be one workgroup of four wavefronts with 16-32 columns per lane in 250-410 registers: one
+// wavefront per SIMD, one pack per CU, tens of seconds per pack while most of the device idled (config 5).  Here the row is
+// spread over 8, 12 or 16 wavefronts of 8 columns per lane (<= 128 registers: four wavefronts per SIMD, the whole CU works on
+// one or two packs), built like dp_rows_v3: plan through the scalar cache, every predecessor from the LDS ring (a dword per
+// cell: H | min(H - F, 2) << 16) or, beyond RING rows, from the record.  Record as dp_rows: H as an unsigned 16-bit word
+// (exact up to 13107 columns) plus a nibble per column behind S.E.  The prefix of u over the wavefronts of the block is a
+// 16-lane scan of the exchanged totals.
+template <int CPL, int RING, int NW>
+__device__ void dp_rows_wide(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
+    constexpr int NT = 64 * NW;
+    constexpr int NWD = (CPL + 7) / 8;           // dwords of F/E nibbles per thread and row (traceback record)
+    static_assert(CPL % 4 == 0 && NW <= 16 && RING > 0 && NT * CPL <= 13056, "16-bit H record: 5 * columns < 65536");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t c0 = (uint32_t)tid * CPL;
+    const bool act = c0 < Lp;
+    uint32_t sw[CPL / 4];                        // this thread's CPL sequence bytes
+    {
+        const uint32_t *sp = (const uint32_t *)(S.sq + (act ? c0 : 0));
+#pragma unroll
+        for (int u = 0; u < CPL / 4; ++u) sw[u] = act ? sp[u] : 0u;
+    }
+    const bool wave_act = (uint32_t)wave * 64u * CPL < Lp;
+    uint32_t *const ring_thr = S.ring + (size_t)tid * CPL;             // slot s of this thread: ring_thr + s * NT * CPL
+    uint32_t *const lhr = (uint32_t *)S.lh_ring + wave;                // slot s of this wavefront: lhr[NW * s]
+    int32_t lbest = 0;
+    const int32_t je0 = ((int32_t)c0 + 1) * POA_E;                      // j * e of the thread's first column
+
+    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb;
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb) : : "memory");
+    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb;
+
+    auto step = [&](auto par_tag, const uint32_t row, const u32x4 pa, const u32x4 pb) __attribute__((always_inline)) {
+        constexpr uint32_t par = decltype(par_tag)::value;
+        const uint32_t info = pa.x;
+        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+        int32_t hm[CPL], fm[CPL];                // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
+        auto pred = [&](auto first_tag, const uint32_t prow) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            int32_t hp[CPL], fd[CPL];
+            int32_t hl;
+            if (row - prow <= (uint32_t)RING) {
+                const uint32_t slot = prow % (uint32_t)RING;
+                const uint4 *rp = (const uint4 *)(ring_thr + slot * (uint32_t)(NT * CPL));
+#pragma unroll
+                for (int u = 0; u < CPL / 4; ++u) {
+                    const uint4 a = rp[u];
+                    hp[4 * u] = (int32_t)(a.x & 0xFFFFu); fd[4 * u] = hp[4 * u] - (int32_t)(a.x >> 16);
+                    hp[4 * u + 1] = (int32_t)(a.y & 0xFFFFu); fd[4 * u + 1] = hp[4 * u + 1] - (int32_t)(a.y >> 16);
+                    hp[4 * u + 2] = (int32_t)(a.z & 0xFFFFu); fd[4 * u + 2] = hp[4 * u + 2] - (int32_t)(a.z >> 16);
+                    hp[4 * u + 3] = (int32_t)(a.w & 0xFFFFu); fd[4 * u + 3] = hp[4 * u + 3] - (int32_t)(a.w >> 16);
+                }
+                hl = (int32_t)lhr[(uint32_t)NW * slot];
+            } else {
+                hl = 0;
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) { hp[t] = 0; fd[t] = POA_G - POA_E; }
+                if (act) {
+                    load_block<CPL>(S.H + (uint64_t)prow * Lp + c0, hp);
+                    const uint32_t *np = (const uint32_t *)S.E + ((uint64_t)prow * NT + tid) * NWD;
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) fd[t] = hp[t] - min((int32_t)((np[t / 8] >> (4 * (t % 8))) & 3u), 2);   // H - min(H-F, 2)
+                    if (lane == 0 && wave > 0) hl = (int32_t)((const uint16_t *)S.H)[(uint64_t)prow * Lp + c0 - 1];
+                }
+                drain_vector_loads();            // rare path: nothing stays pending past it
+            }
+            const int32_t hleft = wave_shr1(hp[CPL - 1], hl);
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int32_t hd = t == 0 ? hleft : hp[t - 1];
+                hm[t] = FIRST ? hd : max(hm[t], hd);
+                fm[t] = FIRST ? fd[t] : max(fm[t], fd[t]);
+            }
+        };
+        if (n_in == 0) {                         // virtual start row: H = 0, F = -inf
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { hm[t] = 0; fm[t] = POA_G - POA_E; }
+        } else {
+            pred(std::true_type{}, pb.x);
+            if (n_in > 1) pred(std::false_type{}, pb.y);
+            if (n_in > 2) pred(std::false_type{}, pb.z);
+            if (n_in > 3) {
+                pred(std::false_type{}, pb.w);
+                uint32_t e = pa.z;
+                for (uint32_t k = 4; k < n_in; ++k) {
+                    const uint2 ed = S.edges[e]; e = ed.y;
+                    const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
+                    drain_vector_loads();
+                    pred(std::false_type{}, prow);
+                }
+            }
+        }
+        int32_t hn[CPL], fr[CPL], ex[CPL];
+        int32_t run = POA_NEG;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+            fr[t] = fm[t] + POA_E;
+            hn[t] = max(max(hm[t] + sc, fr[t]), 0);
+            ex[t] = run;
+            run = max(run, hn[t] + (POA_G - POA_E) - je0 - t * POA_E);            // u_j = Hn + g - (j+1) e
+        }
+        const int32_t wincl = wave_scan_max_fused(act ? run : POA_NEG);
+        const int32_t texcl = wave_shr1(wincl, POA_NEG);
+        int32_t base = POA_G - POA_E;            // u_0
+        int32_t hl_new = 0;
+        {
+            if (lane == 63) {
+                X.TW[par][wave] = wincl;
+                if (wave < NW - 1) X.QW[par][wave + 1] = make_int2(max(texcl, ex[CPL - 1]), hn[CPL - 1]);
+            }
+            row_barrier();
+            // inclusive prefix maximum of the wavefronts' totals, in lanes 0 .. NW-1 of every wavefront
+            int32_t tv = lane < NW ? X.TW[par][lane] : POA_NEG;
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x112 /*row_shr:2*/, 0xF, 0xF, false));
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x114 /*row_shr:4*/, 0xF, 0xF, false));
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x118 /*row_shr:8*/, 0xF, 0xF, false));
+            if (wave > 0) {
+                const int32_t pw = __builtin_amdgcn_readlane(tv, wave - 1);                     // waves 0 .. wave-1
+                const int32_t pw1 = wave > 1 ? __builtin_amdgcn_readlane(tv, wave - 2) : POA_NEG;      // waves 0 .. wave-2
+                const int2 q = X.QW[par][wave];
+                const int32_t qx = __builtin_amdgcn_readfirstlane(q.x), qy = __builtin_amdgcn_readfirstlane(q.y);
+                base = max(base, pw);
+                const int32_t bp = max(POA_G - POA_E, pw1);
+                const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);        // 1-based index of the column left of the wave
+                hl_new = max(qy, max(bp, qx) + c0w * POA_E);
+            }
+        }
+        base = max(base, texcl);
+        int32_t hN[CPL];
+        uint32_t nbw[NWD];
+#pragma unroll
+        for (int w = 0; w < NWD; ++w) nbw[w] = 0;
+        uint32_t rw[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int32_t ev = max(base, ex[t]) + je0 + t * POA_E;
+            hN[t] = max(hn[t], ev);
+            lbest = max(lbest, hN[t]);
+            const uint32_t df = (uint32_t)min(hN[t] - fr[t], 3);
+            nbw[t / 8] |= (df | ((uint32_t)min(hN[t] - ev, 3) << 2)) << (4 * (t % 8));
+            rw[t] = (uint32_t)hN[t] | (min(df, 2u) << 16);
+        }
+        {
+            const uint32_t slot = row % (uint32_t)RING;
+            uint4 *rp = (uint4 *)(ring_thr + slot * (uint32_t)(NT * CPL));
+#pragma unroll
+            for (int u = 0; u < CPL / 4; ++u) rp[u] = make_uint4(rw[4 * u], rw[4 * u + 1], rw[4 * u + 2], rw[4 * u + 3]);
+            if (lane == 0) lhr[(uint32_t)NW * slot] = (uint32_t)hl_new;
+            if (act) {
+                uint32_t pkH[CPL / 2];
+#pragma unroll
+                for (int u = 0; u < CPL / 2; ++u) pkH[u] = pack16(hN[2 * u], hN[2 * u + 1]);
+                store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, pkH);
+                uint32_t *np = (uint32_t *)S.E + ((uint64_t)row * NT + tid) * NWD;
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) np[w] = nbw[w];
+            }
+        }
+    };
+
+    if (!wave_act) {
+        for (uint32_t r = 0; r < n; ++r) row_barrier();
+    } else {
+        u32x4 na = cpa[0], nb = cpb[0];          // plan of the next row, one row ahead
+        for (uint32_t row = 1; row <= n; row += 2) {
+            {
+                const u32x4 pa = na, pb = nb;
+                if (row < n) { na = cpa[row]; nb = cpb[row]; }
+                step(std::integral_constant<uint32_t, 1>{}, row, pa, pb);
+            }
+            if (row + 1 <= n) {
+                const u32x4 pa = na, pb = nb;
+                if (row + 1 < n) { na = cpa[row + 1]; nb = cpb[row + 1]; }
+                step(std::integral_constant<uint32_t, 0>{}, row + 1, pa, pb);
+            }
+        }
+    }
+    // block-wide best score and the threads whose columns reach it (as dp_rows_pk: the rows come from a rescan)
+    if (!act) lbest = 0;
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wave] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
+    __syncthreads();
+    best = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
+    if (best > 0 && lbest == best) {
+        const uint32_t slot = atomicAdd(&X.ntl, 1u);
+        if (slot < 16) X.tl[slot] = (uint32_t)tid;
+    }
+    __syncthreads();
+    best_row = 0;
+    multi = best > 0;
+}
+
+// ---- rows longer than any register class (PK == 2): int32 cells, segments of NT * CPL columns ---------------
+// Reads beyond 8192 nt are the thin tail of a long-read run (config 5) but must not fail the call, and a pack of them is
+// billions of cells.  Same recurrence, no register window and no ring: every predecessor row comes back from the int32
+// H matrix and the nibble array (the column left of a thread's block too, so a full __syncthreads() orders the rows), a
+// row is a loop over segments of NT * CPL columns (16 wavefronts x 8 columns: 8192), and the running prefix maximum of u
+// is carried from segment to segment.  The wavefronts' totals are combined by a 16-lane scan, as in dp_rows_wide.
+template <int CPL, int NW>
 __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row,
                              bool &multi) {
-    constexpr int CPL = 4, NT = 64 * NW;
+    static_assert(CPL == 8 && NW <= 16, "two int4 per thread and row segment");
+    constexpr int NT = 64 * NW;
     constexpr uint32_t SEG = (uint32_t)NT * CPL;
     int32_t *H = (int32_t *)S.H;
-    uint16_t *NB = (uint16_t *)S.E;                  // per four columns: nibbles min(H-F,3) | min(H-E,3) << 2 (exact traceback record, see dp_rows_pk)
+    uint32_t *NB = (uint32_t *)S.E;                  // per eight columns: nibbles min(H-F,3) | min(H-E,3) << 2 (exact traceback record, see dp_rows_pk)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t lbest = 0;
     uint32_t lrow = 0, lcnt = 0, stepc = 0;
@@ -1292,19 +1497,27 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
                     else { const uint2 ed = S.edges[e]; e = ed.y; prow = (uint32_t)S.rank[ed.x] + 1; }
                     if (!act) continue;
                     const int32_t *hp = H + (uint64_t)prow * Lp + c0;
-                    const int4 h = *(const int4 *)hp;
-                    const uint32_t nb = NB[((uint64_t)prow * Lp + c0) >> 2];
+                    const int4 h0 = *(const int4 *)hp, h1 = *(const int4 *)(hp + 4);
+                    const uint32_t nbv = NB[((uint64_t)prow * Lp + c0) >> 3];
                     const int32_t hleft = c0 ? hp[-1] : 0;
-                    hm[0] = max(hm[0], hleft); hm[1] = max(hm[1], h.x); hm[2] = max(hm[2], h.y); hm[3] = max(hm[3], h.z);
-                    fm[0] = max(fm[0], h.x - min((int32_t)(nb & 3u), 2)); fm[1] = max(fm[1], h.y - min((int32_t)((nb >> 4) & 3u), 2));
-                    fm[2] = max(fm[2], h.z - min((int32_t)((nb >> 8) & 3u), 2)); fm[3] = max(fm[3], h.w - min((int32_t)((nb >> 12) & 3u), 2));
+                    const int32_t hv[CPL] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) {
+                        hm[t] = max(hm[t], t == 0 ? hleft : hv[t - 1]);
+                        fm[t] = max(fm[t], hv[t] - min((int32_t)((nbv >> (4 * t)) & 3u), 2));
+                    }
                 }
                 int32_t hn[CPL], fr[CPL], ex[CPL];
                 int32_t run = POA_NEG;
+                uint32_t sq[2] = {0, 0};
+                if (act) {
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { const uint32_t col = c0 + t; sq[t >> 2] |= (uint32_t)(col < L ? s[col] : 0) << (8 * (t & 3)); }
+                }
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) {
                     const uint32_t col = c0 + t;
-                    const int32_t sc = (col < L ? s[col] : 0) == letter ? POA_M : POA_N;
+                    const int32_t sc = ((sq[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
                     fr[t] = act ? fm[t] + POA_E : POA_G;
                     hn[t] = act ? max(max(hm[t] + sc, fr[t]), 0) : 0;
                     ex[t] = run;
@@ -1312,25 +1525,32 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
                 }
                 const int32_t wincl = wave_scan_max(act ? run : POA_NEG, POA_NEG);
                 const int32_t texcl = wave_shr1(wincl, POA_NEG);
-                if (lane == 63) ((int32_t *)&X.T[par])[wave] = wincl;
-                __syncthreads();                     // also orders this block's H / F stores of earlier rows
-                const int4 T = X.T[par];
-                const int32_t t0 = wave > 0 ? T.x : POA_NEG, t1 = wave > 1 ? T.y : POA_NEG, t2 = wave > 2 ? T.z : POA_NEG;
-                const int32_t base = max(max(max(carry, t0), max(t1, t2)), texcl);
-                int4 hv, ev;
-                ev.x = max(base, ex[0]) + ((int32_t)c0 + 1) * POA_E; ev.y = max(base, ex[1]) + ((int32_t)c0 + 2) * POA_E;
-                ev.z = max(base, ex[2]) + ((int32_t)c0 + 3) * POA_E; ev.w = max(base, ex[3]) + ((int32_t)c0 + 4) * POA_E;
-                hv.x = max(hn[0], ev.x); hv.y = max(hn[1], ev.y); hv.z = max(hn[2], ev.z); hv.w = max(hn[3], ev.w);
-                if (act) {
-                    *(int4 *)(H + (uint64_t)row * Lp + c0) = hv;
-                    const uint32_t n0 = (uint32_t)min(hv.x - fr[0], 3) | ((uint32_t)min(hv.x - ev.x, 3) << 2);
-                    const uint32_t n1 = (uint32_t)min(hv.y - fr[1], 3) | ((uint32_t)min(hv.y - ev.y, 3) << 2);
-                    const uint32_t n2 = (uint32_t)min(hv.z - fr[2], 3) | ((uint32_t)min(hv.z - ev.z, 3) << 2);
-                    const uint32_t n3 = (uint32_t)min(hv.w - fr[3], 3) | ((uint32_t)min(hv.w - ev.w, 3) << 2);
-                    NB[((uint64_t)row * Lp + c0) >> 2] = (uint16_t)(n0 | (n1 << 4) | (n2 << 8) | (n3 << 12));
-                    rowmax = max(rowmax, max(max(hv.x, hv.y), max(hv.z, hv.w)));
+                if (lane == 63) X.TW[par][wave] = wincl;
+                __syncthreads();                     // also orders this block's H / nibble stores of earlier rows
+                int32_t tv = lane < NW ? X.TW[par][lane] : POA_NEG;
+                tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
+                tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x112 /*row_shr:2*/, 0xF, 0xF, false));
+                tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x114 /*row_shr:4*/, 0xF, 0xF, false));
+                tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x118 /*row_shr:8*/, 0xF, 0xF, false));
+                const int32_t before = wave > 0 ? __builtin_amdgcn_readlane(tv, wave - 1) : POA_NEG;      // wavefronts 0 .. wave-1 of this segment
+                const int32_t total = __builtin_amdgcn_readlane(tv, NW - 1);
+                const int32_t base = max(max(carry, before), texcl);
+                int32_t hv[CPL];
+                uint32_t nbo = 0;
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const int32_t ev = max(base, ex[t]) + ((int32_t)c0 + t + 1) * POA_E;
+                    hv[t] = max(hn[t], ev);
+                    nbo |= ((uint32_t)min(hv[t] - fr[t], 3) | ((uint32_t)min(hv[t] - ev, 3) << 2)) << (4 * t);
+                    rowmax = act ? max(rowmax, hv[t]) : rowmax;
                 }
-                carry = max(max(carry, T.x), max(max(T.y, T.z), NW > 3 ? T.w : POA_NEG));
+                if (act) {
+                    int32_t *hq = H + (uint64_t)row * Lp + c0;
+                    *(int4 *)hq = make_int4(hv[0], hv[1], hv[2], hv[3]);
+                    *(int4 *)(hq + 4) = make_int4(hv[4], hv[5], hv[6], hv[7]);
+                    NB[((uint64_t)row * Lp + c0) >> 3] = nbo;
+                }
+                carry = max(carry, total);
             }
             const bool gt = rowmax > lbest, eq = rowmax == lbest;
             lcnt = gt ? 1u : lcnt + (eq ? 1u : 0u);
@@ -1408,7 +1628,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
 constexpr int poa_min_waves(int CPL, int NW, int PK) {
-    return PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
+    return PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
            : PK == 1 && NW == 1 && CPL == 16 ? POA_MW_1x16 : 1;
 }
 template <int CPL, int RING, int NW, int PK>
@@ -1431,7 +1651,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb); S.planc = (uint4 *)(base + A.o_planc);
         S.H = (int16_t *)(base + A.o_H); S.F = (int16_t *)(base + A.o_F); S.E = (int16_t *)(base + A.o_E);
         S.aln = (int32_t *)(base + A.o_aln); S.ainfo = (uint4 *)(base + A.o_ainfo); S.spill = (uint32_t *)(base + A.o_spill);
-        const uint32_t bit_words = (A.node_cap + 31) / 32;
+        const uint32_t bit_words = poa_bit_words(A.node_cap);
         S.sq = (uint8_t *)lds;                                   // seq_cap bytes (multiple of 16)
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
@@ -1505,7 +1725,8 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
                 bool multi = false;
-                if constexpr (PK == 2) dp_rows_long<NW>(S, X, s, n, L, Lp, best, best_row, multi);
+                if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
+                else if constexpr (PK == 3) dp_rows_wide<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1 && POA_V3) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
@@ -1530,14 +1751,14 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                                 bool hit = false;
 #pragma unroll
                                 for (int u = 0; u < CPL; ++u) hit |= (PK == 1 ? (v[u] & 0x3FFF) : v[u]) == best;
-                                if (hit) { S.rowmax[r] = 1; if (PK == 1) atomicMin(&X.brow, r); }
+                                if (hit) { S.rowmax[r] = 1; if (PK == 1 || PK == 3) atomicMin(&X.brow, r); }
                             }
                         } else {
                             for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NW) {
                                 const cell_t *Hr = (const cell_t *)S.H + (uint64_t)r * Lp;
                                 bool hit = false;
                                 for (uint32_t c = tid & 63; c < L; c += 64) hit |= (PK == 1 ? (int32_t)(Hr[c] & 0x3FFF) : (int32_t)Hr[c]) == best;
-                                if (hit) { S.rowmax[r] = 1; if (PK == 1) atomicMin(&X.brow, r); }
+                                if (hit) { S.rowmax[r] = 1; if (PK == 1 || PK == 3) atomicMin(&X.brow, r); }
                             }
                         }
                         __syncthreads();
@@ -1546,7 +1767,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         if (cnt) atomicAdd(&s_bc[5], cnt);
                     }
                     __syncthreads();
-                    if (PK == 1) best_row = X.brow;             // packed rows: the rescan is where the first row comes from
+                    if (PK == 1 || PK == 3) best_row = X.brow;  // packed and wide rows: the rescan is where the first row comes from
                     // cheap exit: if every tied row except the first has a tied direct predecessor, all of
                     // them descend from the first one, which then precedes them in ANY topological order
                     bool need_sort = s_bc[5] > 1;
@@ -1664,7 +1885,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     // by the general code (all lanes uniformly, lane 0 writes).  aln[] receives (row | -1, pos | -1);
                     // rows become node ids in add_alignment.
                     uint16_t *tq0 = (uint16_t *)S.done;                   // [n+1] row of the first in-edge (0: none / virtual)
-                    const uint32_t tb_bytes = (2u * ((A.node_cap + 31) / 32) + POA_STACK) * 4u + (uint32_t)RING * NT * (CPL / 2) * 4u + (uint32_t)RING * 16u;
+                    const uint32_t tb_bytes = (2u * poa_bit_words(A.node_cap) + POA_STACK) * 4u + (uint32_t)RING * NT * (CPL / 2) * 4u + (uint32_t)RING * 16u;
                     const bool fast_tb = 3u * (n + 2u) <= tb_bytes && n < 0xFFFFu && !(A.debug & 2u);
                     uint8_t *tlet = (uint8_t *)(tq0 + (n + 2u));          // [n+1] letter of the row's node
                     if (fast_tb) {
@@ -1851,7 +2072,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
             // the kind of every pair also goes to LDS (bitmap / stack area, idle here) so that the sequential
             // pass below touches global memory only for the pairs that create nodes
             uint8_t *kind = (uint8_t *)S.done;
-            const bool use_kind = n_aln <= (((A.node_cap + 31) / 32) * 2 + POA_STACK) * 4;
+            const bool use_kind = n_aln <= (poa_bit_words(A.node_cap) * 2 + POA_STACK) * 4;
             for (uint32_t f = tid; f < n_aln; f += NT) {
                 const int32_t ar = S.aln[2 * (n_aln - 1 - f)], pos = S.aln[2 * (n_aln - 1 - f) + 1];
                 const int32_t an = ar < 0 ? -1 : (int32_t)S.order[ar - 1];      // traceback recorded rows
@@ -2085,8 +2306,8 @@ struct poa_variant {
 #define POA_CLASSES 8
 static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144, 8192};
 static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1),
-                                                   POA_VARIANT(16, 4, 4, 0), POA_VARIANT(24, 5, 4, 0), POA_VARIANT(32, 3, 4, 0),
-                                                   POA_VARIANT(4, 0, 4, 2) /* longer than 8192: int32 cells, segmented rows */};
+                                                   POA_VARIANT(8, POA_WIDE_RING, 8, 3), POA_VARIANT(8, POA_WIDE_RING, 12, 3), POA_VARIANT(8, POA_WIDE_RING, 16, 3),
+                                                   POA_VARIANT(8, 0, 16, 2) /* longer than 8192: int32 cells, segmented rows */};
 static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
@@ -2226,7 +2447,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         const uint64_t cell_bytes = long_rows ? 4 : 2;
         if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(0);      // E is rebuilt on demand by the traceback
-        } else if (P.V->pk == 0) {         // H int16 plus a nibble per column (min(H-F,3), min(H-E,3))
+        } else if (P.V->pk == 0 || P.V->pk == 3) {   // H int16 plus a nibble per column (min(H-F,3), min(H-E,3))
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * ((cpl + 7) / 8) * 4);
         } else {                           // segmented int32 rows: H int32 plus a nibble per column
             A.o_H = take(ccap * cell_bytes); A.o_F = take(0); A.o_E = take(ccap / 2 + 64);
@@ -2237,7 +2458,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         auto lds_bytes = [&](const poa_variant *V) {
             const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
-            return (size_t)lds_seq + ((size_t)((ncap + 31) / 32) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 16 + 64;
+            return (size_t)lds_seq + ((size_t)poa_bit_words(ncap) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 4 * std::max<uint32_t>(4, V->nw) + 64;
         };
         if ((c == 4 || c == 5 || c == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 4];
         P.shm = lds_bytes(P.V);
@@ -2336,17 +2557,43 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         {
             ktimer T(ctx, K_POA, 0);
             e = hipEventRecord(ctx->poa_go, st);
-            // longest class first: its persistent blocks take the device, the shorter classes move in as its queue drains,
-            // and the pass ends on short packs (a small tail) instead of on the longest ones
-            for (int c = POA_CLASSES - 1; c >= 0 && e == hipSuccess; --c) {
+            // The classes of a pass run concurrently, but the device takes kernels from a handful of hardware queues (four by
+            // default) that HIP streams share: seven classes on seven streams left the 6144-column class waiting behind the
+            // 8192-column one for its whole run (config 5, profiles/round3_*).  So the classes are dealt onto at most four
+            // streams, longest estimated run first onto the least loaded stream; a stream runs its classes in that order.
+            // Estimate: a pack costs bases x longest read / threads of its workgroup; a class lasts as long as its longest
+            // pack or its total over its slots.
+            double est[POA_CLASSES] = {0};
+            int order[POA_CLASSES], n_run = 0;
+            for (int c = 0; c < POA_CLASSES; ++c) {
                 cls_plan &P = C[c];
                 if (!P.n_slots) continue;
-                hipStream_t cs = ctx->poa_st[c];
-                e = hipStreamWaitEvent(cs, ctx->poa_go, 0);
+                double tot = 0, longest = 0;
+                for (uint32_t p : P.todo) { const double w = (double)pbases[p] * (double)pmaxL[p] / (64.0 * P.V->nw); tot += w; longest = std::max(longest, w); }
+                est[c] = std::max(longest, tot / P.n_slots);
+                order[n_run++] = c;
+            }
+            std::sort(order, order + n_run, [&](int a, int b) { return est[a] != est[b] ? est[a] > est[b] : a > b; });
+            // (the drivers -- rattle, bench.py, rattle_amd -- raise GPU_MAX_HW_QUEUES to 8 before the HIP runtime starts, so that
+            // every class gets a queue of its own; a host application that did not is dealt four streams)
+            const int hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+            const int n_streams = std::max(1, std::min(POA_CLASSES, getenv("RATTLE_POA_STREAMS") ? atoi(getenv("RATTLE_POA_STREAMS")) : hwq));
+            double load[POA_CLASSES] = {0};
+            bool used[POA_CLASSES] = {false};
+            for (int i = 0; i < n_run && e == hipSuccess; ++i) {
+                const int c = order[i];
+                int sidx = 0;
+                for (int t = 1; t < n_streams; ++t) if (load[t] < load[sidx]) sidx = t;
+                load[sidx] += est[c];
+                cls_plan &P = C[c];
+                hipStream_t cs = ctx->poa_st[sidx];
+                if (!used[sidx]) { e = hipStreamWaitEvent(cs, ctx->poa_go, 0); used[sidx] = true; }
                 if (e != hipSuccess) break;
                 e = P.V->launch(P.A, P.n_slots, P.shm, cs);
-                if (e == hipSuccess) e = hipEventRecord(ctx->poa_ev[c], cs);
-                if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[c], 0);
+            }
+            for (int t = 0; t < n_streams && e == hipSuccess; ++t) if (used[t]) {
+                e = hipEventRecord(ctx->poa_ev[t], ctx->poa_st[t]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[t], 0);
             }
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);

@@ -1066,6 +1066,7 @@ int mode_polish(int argc, char **argv) {
 }  // namespace
 
 int main(int argc, char **argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);      // before the HIP runtime starts: the POA column classes of a pass run concurrently, one hardware queue each (poa.hip)
     if (argc < 2) {
         std::cout << "Run with mode: ./rattle <cluster|cluster_summary|extract_clusters|correct|polish>" << std::endl;
         return EXIT_FAILURE;

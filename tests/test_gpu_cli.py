@@ -137,3 +137,101 @@ def test_both_count_passes_give_the_same_clusters(built, tmp_path, k):
                        env=dict(os.environ, RATTLE_PAIR_COUNT=mode))
         outs[mode] = (d / "clusters.out").read_bytes()
     assert outs["seed"] == outs["search"] and len(outs["seed"]) > 1000
+
+
+def test_labels_and_several_input_files_match_oracle_cli(built, tmp_path):
+    """`-i a.fq,b.fq -l s1,s2` (main.cpp:16-112: one running record index over the files, "," + label appended to every
+    header) through cluster and correct: the consensus headers carry `labels=s1:<n>,s2:<n>,` counted from the members'
+    headers (correct.cpp:453-469,495-515); every file byte-identical to the oracle CLI."""
+    seqs, quals, _, _ = synth.reads(360, 3, 1, True, seed=31)
+    (tmp_path / "a.fq").write_bytes(synth.fastq_text(seqs[:200], quals[:200]))
+    (tmp_path / "b.fastq").write_bytes(synth.fastq_text(seqs[200:], quals[200:]))
+    inp = f"{tmp_path / 'a.fq'},{tmp_path / 'b.fastq'}"
+    a = tmp_path / "a"; b = tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    for tool, out in ((RATTLE, a), (ORACLE, b)):
+        subprocess.run([tool, "cluster", "-i", inp, "-l", "s1,s2", "-o", str(out)], check=True, capture_output=True)
+    assert (a / "clusters.out").read_bytes() == (b / "clusters.out").read_bytes()
+    for tool, out in ((RATTLE, a), (ORACLE, b)):
+        subprocess.run([tool, "correct", "-i", inp, "-l", "s1,s2", "-c", str(out / "clusters.out"), "-o", str(out), "-s", "50"], check=True, capture_output=True)
+    for f in ("corrected.fq", "uncorrected.fq", "consensi.fq"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    heads = (a / "consensi.fq").read_bytes().split(b"\n")[0::4]
+    assert heads[0].startswith(b"@gene_cluster_0 reads=") and b" labels=s1:" in heads[0] and b",s2:" in heads[0]
+    import re
+    n1 = sum(int(re.search(rb"s1:(\d+),", h).group(1)) for h in heads if h)
+    n2 = sum(int(re.search(rb"s2:(\d+),", h).group(1)) for h in heads if h)
+    assert 0 < n1 <= 200 and 0 < n2 <= 160
+    assert b",s1,gene_cluster_" in (a / "corrected.fq").read_bytes()[:400]
+
+
+def test_fasta_input_matches_oracle_cli(built, tmp_path):
+    """FASTA input (fasta.cpp:33-205): multi-line records, lower-case bases upper-cased (:131), a record with N skipped, a
+    short one filtered; `correct` gives every base quality '~'.  Also a mix of one FASTA and one FASTQ file."""
+    seqs, quals, _, _ = synth.reads(260, 3, 1, True, seed=37)
+    lines = []
+    for i, s in enumerate(seqs[:160]):
+        if i == 4:
+            s = s[:30] + b"N" + s[31:]
+        if i == 7:
+            s = s[:90]
+        if i % 3 == 0:
+            s = s.lower()
+        lines.append(b">f%d some text\n" % i)
+        lines += [s[p:p + 70] + b"\n" for p in range(0, len(s), 70)]
+    (tmp_path / "x.fasta").write_bytes(b"".join(lines))
+    (tmp_path / "y.fq").write_bytes(synth.fastq_text(seqs[160:], quals[160:]))
+    for inp, tag in ((str(tmp_path / "x.fasta"), "one"), (f"{tmp_path / 'x.fasta'},{tmp_path / 'y.fq'}", "two")):
+        a = tmp_path / ("a" + tag); b = tmp_path / ("b" + tag)
+        a.mkdir(); b.mkdir()
+        for tool, out in ((RATTLE, a), (ORACLE, b)):
+            subprocess.run([tool, "cluster", "-i", inp, "-o", str(out)], check=True, capture_output=True)
+        assert (a / "clusters.out").read_bytes() == (b / "clusters.out").read_bytes(), tag
+        for tool, out in ((RATTLE, a), (ORACLE, b)):
+            subprocess.run([tool, "correct", "-i", inp, "-c", str(out / "clusters.out"), "-o", str(out), "-s", "60"], check=True, capture_output=True)
+        for f in ("corrected.fq", "uncorrected.fq", "consensi.fq"):
+            assert (a / f).read_bytes() == (b / f).read_bytes(), (tag, f)
+        cor = (a / "corrected.fq").read_bytes().split(b"\n")
+        assert cor[0].startswith(b">f") and len(cor) > 400               # FASTA headers keep their '>' (fasta.cpp:47)
+
+
+def test_mixed_length_flow_matches_oracle_cli(built, tmp_path):
+    """BASELINE configs[4] in miniature, exact: --rna reads from 200 nt to 14 kb (every column class of kernel C up to the
+    segmented rows beyond 8192 columns) through cluster -> correct -> polish, every file byte-identical to the oracle CLI."""
+    import numpy as np
+    rng = np.random.default_rng(41)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    lens = [220, 700, 1300, 1900, 2400, 3300, 5200, 7300, 9800, 14000]
+    depth = [14, 12, 10, 9, 8, 7, 6, 6, 5, 5]
+    seqs, quals = [], []
+    for L, d in zip(lens, depth):
+        tx = acgt[rng.integers(0, 4, L)]
+        for _ in range(d):
+            r = rng.random(L)
+            s = tx.copy()
+            sub = (r >= 0.02) & (r < 0.05)
+            s[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+            s = s[r >= 0.02]
+            pos = np.sort(rng.integers(0, len(s) + 1, int(0.02 * len(s))))
+            s = np.insert(s, pos, acgt[rng.integers(0, 4, len(pos))])
+            s = s[int(rng.integers(0, max(1, L // 20))):]
+            seqs.append(s.tobytes())
+            quals.append(bytes(rng.integers(36, 74, len(s)).astype(np.uint8)))
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]; quals = [quals[i] for i in order]
+    fq = tmp_path / "mixed.fastq"
+    fq.write_bytes(synth.fastq_text(seqs, quals))
+    a = tmp_path / "a"; b = tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    for tool, out in ((RATTLE, a), (ORACLE, b)):
+        subprocess.run([tool, "cluster", "-i", str(fq), "-o", str(out), "--rna"], check=True, capture_output=True)
+    assert (a / "clusters.out").read_bytes() == (b / "clusters.out").read_bytes()
+    assert len(hps.decode((a / "clusters.out").read_bytes(), fields=3)) >= 10
+    for tool, out in ((RATTLE, a), (ORACLE, b)):
+        subprocess.run([tool, "correct", "-i", str(fq), "-c", str(out / "clusters.out"), "-o", str(out)], check=True, capture_output=True)
+    for f in ("corrected.fq", "uncorrected.fq", "consensi.fq"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    assert max(len(l) for l in (a / "consensi.fq").read_bytes().split(b"\n")[1::4]) > 13000
+    for tool, out in ((RATTLE, a), (ORACLE, b)):
+        subprocess.run([tool, "polish", "-i", str(out / "consensi.fq"), "-o", str(out), "--rna"], check=True, capture_output=True)
+    assert (a / "transcriptome.fq").read_bytes() == (b / "transcriptome.fq").read_bytes()

@@ -211,3 +211,49 @@ def test_packs_beyond_the_device_are_skipped_and_reported(gpu_ctx, oracle, monke
     got2 = correct_command(gpu_ctx, headers, seqs, quals, clusters, with_skipped=True, max_pack_cells=60_000_000)
     assert len(got2[4]) == 1 and got2[4][0]["stage"] == 0 and sorted(got2[4][0]["reads"]) == sorted(long_ids)
     assert got2[0] == want[0] and n_rec(got2[0]) + n_rec(got2[1]) == len(seqs)
+
+
+def test_fix_msa_ends_trims_through_the_hip_path(gpu_ctx, oracle):
+    """Packs built so that fix_msa_ends (correct.cpp:32-92, kernel D) has something to cut: a read with 9 junk bases in
+    front of the shared core while a longer read's unaligned 29-base prefix opens 29 columns between them (left end, phase
+    1), the mirror image at the right end (phase 2, on the reversed row), and a 9-base read that aligns nowhere (its row is
+    blanked whole, the read comes back empty in uncorrected.fq).  Byte-identical to the oracle, and the cuts really happen."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda k: acgt[rng.integers(0, 4, k)].tobytes()
+
+    def noisy(s, rate=0.02):
+        a = np.frombuffer(s, np.uint8).copy()
+        m = rng.random(len(a)) < rate
+        a[m] = acgt[rng.integers(0, 4, int(m.sum()))]
+        return a.tobytes()
+
+    seqs, clusters = [], []
+
+    def cluster_of(members):
+        base = len(seqs)
+        seqs.extend(members)
+        ids = sorted(range(base, base + len(members)), key=lambda i: -len(seqs[i]))
+        clusters.append(((ids[0], 0, -1), [(i, 0, -1) for i in ids]))
+
+    core = rnd(300)
+    # left end: R1 = junk9 + core + tail25 (longest, first into the graph), R2 = junk29' + core (its prefix stays unaligned)
+    cluster_of([b"GATTACAGA" + core + rnd(25), rnd(29) + noisy(core)] + [noisy(core) for _ in range(6)])
+    core2 = rnd(320)
+    # right end: first lead40 + core2 + junk29, then core2 + junk9 (9 unaligned bases behind 29 foreign columns)
+    cluster_of([rnd(40) + core2 + rnd(29), noisy(core2) + b"TTAGGCATC"] + [noisy(core2) for _ in range(6)])
+    core3 = rnd(280)
+    cluster_of([core3] + [noisy(core3) for _ in range(6)] + [b"ACGGTCAAT"])        # a 9-base member that aligns nowhere
+    quals = [bytes(rng.integers(40, 70, len(s)).astype(np.uint8)) for s in seqs]
+    headers = [b"@t%d" % i for i in range(len(seqs))]
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters)
+    want = oracle.correct(headers, seqs, quals, hps.encode(clusters))
+    assert got[0] == want[0], "corrected.fq differs"
+    assert got[1] == want[1], "uncorrected.fq differs"
+    assert got[2] == want[2], "consensi.fq differs"
+    cor = {l.split(b",")[0]: s for l, s in zip(got[0].split(b"\n")[0::4], got[0].split(b"\n")[1::4])}
+    assert not cor[b"@t0"].startswith(b"GATTACAGA") and len(cor[b"@t0"]) <= 300 + 25 + 3        # the junk prefix was cut
+    assert not cor[b"@t9"].endswith(b"TTAGGCATC") and len(cor[b"@t9"]) <= 320 + 3                # the junk suffix was cut
+    unc = got[1].split(b"\n")
+    k = [i for i, l in enumerate(unc) if l.startswith(b"@t%d," % (len(seqs) - 1))]
+    assert k and unc[k[0] + 1] == b""                                                            # blanked whole: empty read

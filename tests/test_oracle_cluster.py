@@ -1,4 +1,6 @@
 """Pin the cluster-path oracle: fixture parity + agreement with the real reference TUs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -53,3 +55,31 @@ def test_var_edge_cases(oracle, ref_lib):
     for n in (2, 3, 17, 400):
         v = rng.integers(-60, 60, n)
         assert oracle.var(v) == ref_lib.var(v)
+
+
+def test_restated_readers_match_the_real_fasta_cpp(oracle, ref_lib, tmp_path):
+    """The four readers of fasta.cpp (FASTQ / FASTA x plain / cluster variant: labels appended to headers, running record
+    index, length filter, N skip, upper-casing of FASTA, DOS line ends) as restated in oracle/orc_io.hpp, record for record
+    against the real translation unit in oracle/_ref."""
+    import ctypes as C
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "oracle_cli")
+    ref_lib.lib.ref_dump_reads.restype = C.c_int32
+    ref_lib.lib.ref_dump_reads.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    fq = b"@a 1\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\n@b\nACGTNACGT\n+x\n#########\n@c\nACG\n+\n!!!\n@d extra words\nacgtACGTacgtACGTacgt\n+\nJJJJJJJJJJJJJJJJJJJJ\n"
+    fa = b">s1 first\nACGTACGTAC\nGTACGTAC\n\n>s2\nacgtnacgt\n>s3\nACG\n>s4\nacgtacgtacgtacgtacgt\nACGT\n"
+    files = {"u.fq": fq, "d.fq": fq.replace(b"\n", b"\r\n"), "u.fa": fa, "d.fa": fa.replace(b"\n", b"\r\n")}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    for name in files:
+        for cluster_variant in (0, 1):
+            kind = (2 if name.endswith(".fa") else 0) + cluster_variant
+            for label, index, raw, lower in ((b"", 0, 0, 5), (b",lab1", 7, 0, 5), (b",x", 3, 1, 5), (b"", 0, 0, 19)):
+                want = tmp_path / "want.txt"; got = tmp_path / "got.txt"
+                nxt = ref_lib.lib.ref_dump_reads(str(tmp_path / name).encode(), label, kind, index, raw, lower, 1000, str(want).encode())
+                args = [cli, "dump-reads", "-i", str(tmp_path / name), "--kind", str(kind), "--index", str(index), "--lower-length", str(lower),
+                        "--upper-length", "1000", "-o", str(got)] + (["-l", label.decode()] if label else []) + (["--raw"] if raw else [])
+                r = subprocess.run(args, capture_output=True, text=True, check=True)
+                assert got.read_bytes() == want.read_bytes(), (name, kind, label, index, raw, lower)
+                if cluster_variant and want.read_bytes():
+                    assert int(r.stdout.strip()) == nxt, (name, kind, label, index, raw, lower)

@@ -123,3 +123,28 @@ def test_vote_order_is_libstdcxx_iteration_order(tmp_path):
     from rattle_amd import _lib
     assert b'"U-GTCA"' in open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "correct_driver.hip"), "rb").read()
     assert b'"U-GTCA"' in open(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "orc_correct.hpp"), "rb").read()
+
+
+def test_fix_msa_ends_hand_built_rows(oracle):
+    """correct.cpp:32-92 on three hand-built rows, expectations worked out by hand from the reference's control flow:
+    (a) a block of fewer than 10 bases followed by >= 20 gaps at the LEFT end is blanked and its bases leave seq / quality;
+    (b) the same at the RIGHT end happens in the second phase, on the reversed row: the LAST bases leave;
+    (c) phase 1 stops at a small block followed by only 15 gaps (reverses), phase 2 then finds the same block followed by 25
+        gaps and blanks it, runs off the row end and never reverses back: the row is all gaps and the read is empty (the
+        "stays reversed" quirk has nothing left to show);
+    (d) a 9-base block followed by 19 gaps stays (the limit is >= 20), and 4 gaps inside a block split it, 3 do not."""
+    G = lambda k: b"-" * k
+    rows = [b"ACGTACGTA" + G(25) + b"CCCCCGGGGGTTTTT",
+            b"CCCCCGGGGGTTTTT" + G(22) + b"ACGTACGT" + G(4),
+            G(25) + b"ACGTTGCAA" + G(15),
+            b"ACGTACGTA" + G(19) + b"CCCCCGGGGGTTTTT" + G(6),
+            b"ACGTA---CGTAC" + G(20) + b"GGGGGCCCCC" + G(6)]
+    seqs = [r.replace(b"-", b"") for r in rows]
+    quals = [bytes(range(40, 40 + len(s))) for s in seqs]
+    out_rows, out_s, out_q = oracle.fix_msa_ends(rows, seqs, quals)
+    assert out_rows[0] == G(34) + b"CCCCCGGGGGTTTTT" and out_s[0] == b"CCCCCGGGGGTTTTT" and out_q[0] == quals[0][9:]
+    assert out_rows[1] == b"CCCCCGGGGGTTTTT" + G(34) and out_s[1] == b"CCCCCGGGGGTTTTT" and out_q[1] == quals[1][:15]
+    assert out_rows[2] == G(49) and out_s[2] == b"" and out_q[2] == b""
+    assert out_rows[3] == rows[3] and out_s[3] == seqs[3] and out_q[3] == quals[3]
+    # "ACGTA---CGTAC" is ONE block of 10 bases (3 gaps do not end it): nothing is cut although 20 gaps follow
+    assert out_rows[4] == rows[4] and out_s[4] == seqs[4]
