@@ -162,7 +162,8 @@ def test_labels_and_several_input_files_match_oracle_cli(built, tmp_path):
     n1 = sum(int(re.search(rb"s1:(\d+),", h).group(1)) for h in heads if h)
     n2 = sum(int(re.search(rb"s2:(\d+),", h).group(1)) for h in heads if h)
     assert 0 < n1 <= 200 and 0 < n2 <= 160
-    assert b",s1,gene_cluster_" in (a / "corrected.fq").read_bytes()[:400]
+    txt = (a / "corrected.fq").read_bytes()
+    assert b",s1,gene_cluster_" in txt and b",s2,gene_cluster_" in txt
 
 
 def test_fasta_input_matches_oracle_cli(built, tmp_path):
@@ -202,7 +203,7 @@ def test_mixed_length_flow_matches_oracle_cli(built, tmp_path):
     rng = np.random.default_rng(41)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     lens = [220, 700, 1300, 1900, 2400, 3300, 5200, 7300, 9800, 14000]
-    depth = [14, 12, 10, 9, 8, 7, 6, 6, 5, 5]
+    depth = [14, 12, 10, 9, 8, 7, 6, 6, 6, 6]
     seqs, quals = [], []
     for L, d in zip(lens, depth):
         tx = acgt[rng.integers(0, 4, L)]
