@@ -1046,7 +1046,7 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         const int j0 = (int)c0 + 2 * u + 1, j1 = j0 + 1;
         const s16x2 je = {(short)(j0 * POA_E), (short)(j1 * POA_E)};
         const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
-        JE[u] = je; UC[u] = uc;
+        JE[u] = je; UC[u] = act ? uc : pk_splat(-30000);      // threads beyond the row: u = Hn - 30000 < 0 < every valid u (>= 4), no select before the scan
     }
     s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
     const bool wave_act = (uint32_t)wave * 64u * CPL < Lp;
@@ -1060,8 +1060,11 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc) : : "memory");
     const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
 
-    auto step = [&](auto par_tag, const uint32_t row, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
+    auto step = [&](auto w0_tag, auto par_tag, const uint32_t row, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
         constexpr uint32_t par = decltype(par_tag)::value;
+        constexpr bool W0 = decltype(w0_tag)::value;          // wavefront 0 of the block: nothing to its left
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));                      // lane tests are redone per row: a hoisted mask ends up in a spilled SGPR pair (two v_readlane per use)
         const uint32_t info = pa.x;
         const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
         s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
@@ -1070,8 +1073,12 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             if (row - prow <= (uint32_t)RING) {
                 const uint32_t slot = prow % (uint32_t)RING;
                 const uint32_t *rp = ring_thr + slot * (uint32_t)(NT * NP);
+                if constexpr (NP == 2) { const uint2 a2 = *(const uint2 *)rp; raw[k][0] = a2.x; raw[k][1] = a2.y; }
+                else if constexpr (NP == 4) { const uint4 a4 = *(const uint4 *)rp; raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; }
+                else {
 #pragma unroll
-                for (int u = 0; u < NP; ++u) raw[k][u] = rp[u];
+                    for (int u = 0; u < NP; ++u) raw[k][u] = rp[u];
+                }
                 rawl[k] = lhr[4 * slot];
             } else {
 #pragma unroll
@@ -1168,24 +1175,24 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             RUN = pk_max(v, __builtin_shufflevector(v, v, 1, 0));                          // max(run, u_a, u_b) in both halves
         }
         const int32_t run = (int32_t)(int16_t)(as_u(RUN) & 0xFFFFu);
-        const int32_t wincl = wave_scan_max_fused(act ? run : POA_NEG);
+        const int32_t wincl = wave_scan_max_fused(run);
         const int32_t texcl = wave_shr1(wincl, POA_NEG);
         int32_t base = POA_G - POA_E;            // u_0
         int32_t hl_new = 0;
         if (NW > 1) {
-            if (lane == 63) {
+            if (lane_o == 63) {
                 const int32_t ex_last = (int32_t)as_u(EX[NP - 1]) >> 16, hn_last = (int32_t)as_u(HNp[NP - 1]) >> 16;
                 ((int32_t *)&X.T[par])[wave] = wincl;
                 if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex_last), hn_last);
             }
             row_barrier();
-            const int4 T = X.T[par];
-            const int32_t Tx = __builtin_amdgcn_readfirstlane(T.x), Ty = __builtin_amdgcn_readfirstlane(T.y), Tz = __builtin_amdgcn_readfirstlane(T.z);
-            const int32_t t0 = wave > 0 ? Tx : POA_NEG, t1 = wave > 1 ? Ty : POA_NEG, t2 = wave > 2 ? Tz : POA_NEG;
-            const int32_t b0 = wave > 1 ? Tx : POA_NEG, b1 = wave > 2 ? Ty : POA_NEG;
-            base = max(max(base, t0), max(t1, t2));
             if (wave > 0) {
+                const int4 T = X.T[par];
                 const int2 q = X.Q[par][wave];
+                const int32_t Tx = __builtin_amdgcn_readfirstlane(T.x), Ty = __builtin_amdgcn_readfirstlane(T.y), Tz = __builtin_amdgcn_readfirstlane(T.z);
+                const int32_t t1 = wave > 1 ? Ty : POA_NEG, t2 = wave > 2 ? Tz : POA_NEG;
+                const int32_t b0 = wave > 1 ? Tx : POA_NEG, b1 = wave > 2 ? Ty : POA_NEG;
+                base = max(max(base, Tx), max(t1, t2));
                 const int32_t qx = __builtin_amdgcn_readfirstlane(q.x), qy = __builtin_amdgcn_readfirstlane(q.y);
                 const int32_t bp = max(max(POA_G - POA_E, b0), b1);
                 const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);
@@ -1205,9 +1212,13 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         {
             const uint32_t slot = row % (uint32_t)RING;
             uint32_t *rp = ring_thr + slot * (uint32_t)(NT * NP);
+            if constexpr (NP == 2) *(uint2 *)rp = make_uint2(W[0], W[1]);
+            else if constexpr (NP == 4) *(uint4 *)rp = make_uint4(W[0], W[1], W[2], W[3]);
+            else {
 #pragma unroll
-            for (int u = 0; u < NP; ++u) rp[u] = W[u];
-            if (lane == 0) lhr[4 * slot] = (uint32_t)hl_new << 16;
+                for (int u = 0; u < NP; ++u) rp[u] = W[u];
+            }
+            if (lane_o == 0) lhr[4 * slot] = (uint32_t)hl_new << 16;
             if (act) {
                 uint32_t *hq = Hrec + ((uint64_t)row * Lp >> 1) + (c0 >> 1);
                 if (NP % 2 == 0) {
@@ -1221,23 +1232,24 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         }
     };
 
-    if (!wave_act) {
-        if (NW > 1) for (uint32_t r = 0; r < n; ++r) row_barrier();
-    } else {
+    auto rows = [&](auto w0_tag) __attribute__((always_inline)) {
         u32x4 na = cpa[0], nb = cpb[0], nc = cpc[0];      // plan of the next row, one row ahead
         for (uint32_t row = 1; row <= n; row += 2) {
             {
                 const u32x4 pa = na, pb = nb, pc = nc;
                 if (row < n) { na = cpa[row]; nb = cpb[row]; nc = cpc[row]; }
-                step(std::integral_constant<uint32_t, 1>{}, row, pa, pb, pc);
+                step(w0_tag, std::integral_constant<uint32_t, 1>{}, row, pa, pb, pc);
             }
             if (row + 1 <= n) {
                 const u32x4 pa = na, pb = nb, pc = nc;
                 if (row + 1 < n) { na = cpa[row + 1]; nb = cpb[row + 1]; nc = cpc[row + 1]; }
-                step(std::integral_constant<uint32_t, 0>{}, row + 1, pa, pb, pc);
+                step(w0_tag, std::integral_constant<uint32_t, 0>{}, row + 1, pa, pb, pc);
             }
         }
-    }
+    };
+    if (!wave_act) {
+        if (NW > 1) for (uint32_t r = 0; r < n; ++r) row_barrier();
+    } else rows(std::false_type{});
     // block-wide best score and the threads whose columns reach it (the first row that reaches it comes from a rescan of
     // those threads' columns in the record, kernel body)
     const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
@@ -1701,6 +1713,9 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                 // ---- 1. rows are taken in the incrementally maintained block order (merge_order) ----
                 unsigned long long t0 = PT_NOW();
                 // ---- 2. plan + sequence to LDS (all threads) ----
+#ifdef POA_PREDSTAT
+                unsigned long long ps_in = 0, ps_far = 0, ps_prev = 0;      // measurement build: in-edges, those beyond the ring, those from the previous row
+#endif
                 for (uint32_t r = tid; r < n; r += NT) {
                     const uint32_t v = S.order[r];
                     const uint4 rec = S.nrec[v];
@@ -1712,12 +1727,21 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         if (k == 4) e5 = e;
                         if (k == 0) b = rec.y; else { const uint2 ed = S.edges[e]; e = ed.y; b = ed.x; }
                         if (k < 4) u4_set(pr, k, (uint32_t)S.rank[b] + 1); else u4_set(pr2, k - 4, (uint32_t)S.rank[b] + 1);
+#ifdef POA_PREDSTAT
+                        { const uint32_t d = r + 1 - ((uint32_t)S.rank[b] + 1); ++ps_in; if (d > (uint32_t)(RING > 0 ? RING : 1)) ++ps_far; if (d == 1) ++ps_prev; }
+#endif
                     }
+#ifdef POA_PREDSTAT
+                    if (n_in > 8) ps_in += n_in - 8;
+#endif
                     if (n_in <= 4) e5 = e;
                     S.plan[r] = make_uint4(rec.x, v, e5, e);        // .z: 5th in-edge (general code paths), .w: 9th (packed rows)
                     S.planb[r] = pr;
                     if (PK == 1) S.planc[r] = pr2;
                 }
+#ifdef POA_PREDSTAT
+                atomicAdd(&A.counters[4], ps_in); atomicAdd(&A.counters[5], ps_far); atomicAdd(&A.counters[6], ps_prev);
+#endif
                 if (PK != 2) for (uint32_t t = tid; t < Lp; t += NT) S.sq[t] = t < L ? s[t] : 0;       // long rows read the sequence in place
                 __syncthreads();
                 unsigned long long t1 = PT_NOW();
