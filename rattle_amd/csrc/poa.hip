@@ -50,16 +50,16 @@ namespace rattle {
 #define POA_V3 1                           // packed classes whose ring is a power of two take dp_rows_v3
 #endif
 #ifndef POA_MW_4x4
-#define POA_MW_4x4 6
+#define POA_MW_4x4 7
 #endif
 #ifndef POA_MW_4x6
-#define POA_MW_4x6 5
+#define POA_MW_4x6 6
 #endif
 #ifndef POA_RING_4x4
 #define POA_RING_4x4 8
 #endif
 #ifndef POA_RING_4x6
-#define POA_RING_4x6 8
+#define POA_RING_4x6 6
 #endif
 #ifndef POA_MW_2x8
 #define POA_MW_2x8 4
