@@ -143,14 +143,26 @@ def cpu_baseline_all_cores(cat, qcat, off, tid):
             "sample": f"{j['reads']} reads = every read of {j['tasks']} transcripts (6..100 reads each), one oracle task per transcript, {j['seconds']:.1f} s"}
 
 
+PMC_FILE = os.path.join("profiles", "round3_pmc_poa.json")
+
+
 def pmc_reference():
-    """Counter-derived constants of kernel C for THIS tree, measured in separate rocprofv3 --pmc passes and
-    committed under profiles/ (the counters cannot be read from inside the benchmark process)."""
-    path = os.path.join(ROOT, "profiles", "round2_pmc_poa.json")
+    """Counter-derived constants of kernel C, measured in separate rocprofv3 --pmc passes (tools/gpu_pmc_only.sh) and
+    committed under profiles/ (the counters cannot be read from inside the benchmark process).  The file records a hash of
+    the kernel's sources; `stale` says whether the tree this benchmark runs in still has those sources."""
+    import hashlib
     try:
-        return json.load(open(path))
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
         return None
+    h = hashlib.sha256()
+    try:
+        for f in d.get("kernel_sources", []):
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        d["stale"] = h.hexdigest() != d.get("kernel_sources_sha256")
+    except Exception:
+        d["stale"] = True
+    return d
 
 
 def main():
@@ -389,7 +401,10 @@ def main():
                         "stored_bytes_per_cell": pmc.get("hbm_bytes_per_cell") if pmc else None,
                         "achieved_stored_gbs": gcups * pmc["hbm_bytes_per_cell"] if pmc and pmc.get("hbm_bytes_per_cell") else None},
                 "traffic": (pmc["hbm_bytes_per_cell"] * cells * a.steps / max(launches, 1)) if pmc and pmc.get("hbm_bytes_per_cell") else None,
-                "pmc_source": "profiles/round2_pmc_poa.json" if pmc else None,
+                "pmc_source": PMC_FILE if pmc else None,
+                # true: poa.hip / common.h changed after the counter passes were collected -- the per-cell constants (and `frac`,
+                # `traffic`) then describe an older kernel; GCUPS and the timings are always live
+                "pmc_stale": bool(pmc.get("stale")) if pmc else None,
                 "note": "achieved = exact DP cells / kernel time (HIP events on the library's streams) x VALU wave-instructions per cell from the "
                         "committed SQ_INSTS_VALU pass of this tree; traffic = FETCH_SIZE(x2) + WRITE_SIZE per cell from the committed PMC passes x cells per launch"}
             if not a.no_cpu_baseline:

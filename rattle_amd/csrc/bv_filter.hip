@@ -74,25 +74,31 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
     const uint32_t cid = live ? cand_ids[c] : 0;
     const uint32_t cpc = live ? pcf[cid] : 0;
 
-    // one (seed, candidate) verdict; res bit0 = forward passes, bit1 = reverse passes
+    // one (seed, candidate) verdict per lane; res bit0 = forward passes, bit1 = reverse passes.  Called by EVERY lane of the
+    // wavefront together (lanes without a candidate pass live = false): survivors are appended with ONE atomic per wavefront
+    // and strand -- 41 M survivors at 1e6 reads, 25 M of them in the threshold-0 pass where every pair survives, used to be
+    // 41 M atomics on one counter.
     auto emit = [&](uint32_t s, uint32_t common_f, uint32_t common_r) {
         uint32_t res = 0;
-        if (c >= s_first[s]) {
+        if (live && c >= s_first[s]) {
             uint32_t mmax = max(s_pc[s], cpc);                 // cluster.cpp:16 forward counts only
             uint32_t need = lut[mmax];
             if (fwd_bypass || common_f >= need) res |= 1u;     // cluster.cpp:19
             if (BOTH && common_r >= need) res |= 2u;           // cluster.cpp:43
         }
-        if (dense) dense[(uint64_t)(s0 - J.s_base + s) * J.nc + (c - J.c_base)] = (uint8_t)res;
-        if (list && res) {
-            uint32_t cnt = (res & 1u) + ((res >> 1) & 1u);
-            uint32_t at = atomicAdd(list_count, cnt);
-            if (res & 1u) {
-                if (at < list_cap) { list[2 * (uint64_t)at] = ((s0 + s) << 1); list[2 * (uint64_t)at + 1] = c; }
-                ++at;
-            }
-            if (res & 2u) {
-                if (at < list_cap) { list[2 * (uint64_t)at] = ((s0 + s) << 1) | 1u; list[2 * (uint64_t)at + 1] = c; }
+        if (dense && live) dense[(uint64_t)(s0 - J.s_base + s) * J.nc + (c - J.c_base)] = (uint8_t)res;
+        if (list) {
+#pragma unroll
+            for (uint32_t strand = 0; strand < (BOTH ? 2u : 1u); ++strand) {
+                const bool mine = (res >> strand) & 1u;
+                const unsigned long long m = __ballot(mine);
+                if (m == 0) continue;
+                const uint32_t lane = threadIdx.x & 63u;
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(list_count, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+                const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (mine && at < list_cap) { list[2 * (uint64_t)at] = ((s0 + s) << 1) | strand; list[2 * (uint64_t)at + 1] = c; }
             }
         }
     };
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
 #pragma unroll
             for (int w = 0; w < 64; ++w) a += __popcll(v[w] & s_bv[s][w]);
             if (BOTH) s_cf[s][threadIdx.x] = (uint16_t)a;
-            else if (live) emit(s, a, 0);
+            else emit(s, a, 0);
         }
     }
     if (BOTH) {
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
             uint32_t a = 0;
 #pragma unroll
             for (int w = 0; w < 64; ++w) a += __popcll(v[w] & s_bv[s][w]);
-            if (live) emit(s, s_cf[s][threadIdx.x], a);
+            emit(s, s_cf[s][threadIdx.x], a);
         }
     }
 }

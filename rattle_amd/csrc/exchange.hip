@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 
@@ -42,19 +43,27 @@ struct rccl_api {
 rccl_api &rccl() { static rccl_api A; return A; }
 
 int load_rccl() {
-    rccl_api &A = rccl();
-    if (A.h) return 0;
-    const char *chosen = getenv("RATTLE_RCCL_LIB");                 // a particular RCCL build (or the tests' double)
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    if (chosen && *chosen) A.h = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
-    else for (const char *n : names) { A.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (A.h) break; }
-    if (!A.h) { set_error(std::string(chosen && *chosen ? chosen : "librccl.so") + " not loadable: " + dlerror()); return RATTLE_ERR_HIP; }
-#define SYM(field, name) *(void **)(&A.field) = dlsym(A.h, name); if (!A.field) { set_error("librccl.so lacks " name); A.h = nullptr; return RATTLE_ERR_HIP; }
-    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
-    SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
-    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+    // one loader for the process: rattle --devices runs one host thread per GPU, and the handle must not be visible before
+    // every symbol is resolved
+    static std::once_flag once;
+    static int rc = 0;
+    static std::string why;
+    std::call_once(once, []() {
+        rccl_api T;
+        const char *chosen = getenv("RATTLE_RCCL_LIB");                 // a particular RCCL build (or the tests' double)
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        if (chosen && *chosen) T.h = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+        else for (const char *n : names) { T.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (T.h) break; }
+        if (!T.h) { why = std::string(chosen && *chosen ? chosen : "librccl.so") + " not loadable: " + dlerror(); rc = RATTLE_ERR_HIP; return; }
+#define SYM(field, name) *(void **)(&T.field) = dlsym(T.h, name); if (!T.field) { why = "librccl.so lacks " name; rc = RATTLE_ERR_HIP; return; }
+        SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+        SYM(AllGather, "ncclAllGather") SYM(Broadcast, "ncclBroadcast") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
+        SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
-    return 0;
+        rccl() = T;
+    });
+    if (rc) set_error(why);
+    return rc;
 }
 
 #define RT_NCCL(call)                                                                                    \
@@ -72,11 +81,14 @@ int rccl_allgatherv(rattle_ctx *ctx, const uint8_t *d_send, uint8_t *d_recv, con
     rccl_api &A = rccl();
     RT_NCCL(A.GroupStart());
     uint64_t at = 0;
-    for (int r = 0; r < X.nranks; ++r) {
-        if (bytes[r]) RT_NCCL(A.Broadcast(r == X.rank ? d_send : d_recv + at, d_recv + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, ctx->stream));
+    int bad = 0;                                  // an error inside the group must not leave it open
+    for (int r = 0; r < X.nranks && !bad; ++r) {
+        if (bytes[r]) bad = A.Broadcast(r == X.rank ? d_send : d_recv + at, d_recv + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, ctx->stream);
         at += bytes[r];
     }
-    RT_NCCL(A.GroupEnd());
+    const int end = A.GroupEnd();
+    if (bad) { set_error(std::string("ncclBroadcast: ") + A.GetErrorString(bad)); return RATTLE_ERR_HIP; }
+    RT_NCCL(end);
     return 0;
 }
 
@@ -169,12 +181,15 @@ static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int r
     RT_TRY(d_recv.reserve(total + 16));
     RT_NCCL(A.GroupStart());
     uint64_t at = 0;
-    for (int r = 0; r < X.nranks; ++r) {
+    int bad = 0;
+    for (int r = 0; r < X.nranks && !bad; ++r) {
         if (r == root || !bytes[r]) continue;
-        RT_NCCL(A.Recv(d_recv.p + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, st));
+        bad = A.Recv(d_recv.p + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, st);
         at += bytes[r];
     }
-    RT_NCCL(A.GroupEnd());
+    const int end = A.GroupEnd();
+    if (bad) { set_error(std::string("ncclRecv: ") + A.GetErrorString(bad)); return RATTLE_ERR_HIP; }
+    RT_NCCL(end);
     G.flat.reset(new uint8_t[total + 16]);
     if (total) RT_HIP(hipMemcpyAsync(G.flat.get(), d_recv.p, total, hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));

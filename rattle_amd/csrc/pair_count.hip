@@ -137,11 +137,8 @@ int launch_pair_count_seed(rattle_ctx *ctx, uint32_t n_pairs) {
     A.res = ctx->d_res.p;
     const int bits = 2 * X.k < 20 ? 2 * X.k : 20;
     const size_t shm = ((bits > 5 ? (size_t)1 << (bits - 5) : 4) + PC_REP) * 4;
-    static size_t attr_shm = 0;
-    if (shm > attr_shm) {
-        RT_HIP(hipFuncSetAttribute((const void *)pair_count_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        attr_shm = shm;
-    }
+    // the attribute is per device (rattle --devices runs one host thread per GPU): set it on every call, it costs nothing
+    if (shm > 60 * 1024) RT_HIP(hipFuncSetAttribute((const void *)pair_count_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     ktimer T(ctx, K_SCORE, 0);
     hipLaunchKernelGGL(pair_count_seed_kernel, dim3((n_pairs + PC_CHUNK - 1) / PC_CHUNK), dim3(PC_THREADS), shm, ctx->stream, A);
     hipError_t e = hipGetLastError();

@@ -53,13 +53,13 @@ namespace rattle {
 #define POA_MW_4x4 7
 #endif
 #ifndef POA_MW_4x6
-#define POA_MW_4x6 6
+#define POA_MW_4x6 8
 #endif
 #ifndef POA_RING_4x4
 #define POA_RING_4x4 8
 #endif
 #ifndef POA_RING_4x6
-#define POA_RING_4x6 6
+#define POA_RING_4x6 4
 #endif
 #ifndef POA_MW_2x8
 #define POA_MW_2x8 4

@@ -39,5 +39,12 @@ if "FETCH_SIZE" in poa and "WRITE_SIZE" in poa:
     res["hbm_write_bytes_per_cell"] = 1024 * poa["WRITE_SIZE"] / cells
     res["hbm_bytes_per_cell"] = res["hbm_fetch_bytes_per_cell_x2"] + res["hbm_write_bytes_per_cell"]
     res["note"] = "FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE as reported"
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in ("rattle_amd/csrc/poa.hip", "rattle_amd/csrc/common.h"):
+    h.update(open(os.path.join(root, f), "rb").read())
+res["kernel_sources_sha256"] = h.hexdigest()          # bench.py compares it with the tree it runs in (pmc_stale)
+res["kernel_sources"] = ["rattle_amd/csrc/poa.hip", "rattle_amd/csrc/common.h"]
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k not in ("counters_by_kernel",)}, indent=1))
