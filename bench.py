@@ -68,10 +68,12 @@ def cluster_digest(cl):
     return crc
 
 
-def cpu_baseline(cat, qcat, off, tid, correct_reads=600, cluster_reads=5000):
+def cpu_baseline(cat, qcat, off, tid, correct_reads=1800, cluster_reads=5000):
     """Oracle (CPU restatement, 1 thread), timed per phase on bounded samples of the same workload: `cluster` on
     every read of randomly chosen transcripts up to ~cluster_reads, `correct` on a ~correct_reads subset of whole
-    transcripts (so per-cluster depth matches the full workload).  The combined rate is the harmonic sum."""
+    transcripts (so per-cluster depth matches the full workload).  The POA matrices are filled by the oracle's AVX2 int16
+    row kernel (16 columns per instruction, what spoa's own SIMD engine does; tests/test_oracle_correct.py checks it against
+    the scalar loops); the scalar rate is measured beside it on a third of the sample.  The combined rate is the harmonic sum."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc_mod
     from rattle_amd import hps
@@ -96,20 +98,32 @@ def cpu_baseline(cat, qcat, off, tid, correct_reads=600, cluster_reads=5000):
     order = sorted(range(len(s)), key=lambda i: -len(s[i]))
     cl, cnt = orc.cluster_reads([s[i] for i in order], k=10)
     dt_cluster = time.time() - t0
-    ids_k = sample(correct_reads, 6, correct_reads // 2)
-    s2 = [cat[int(off[i]):int(off[i + 1])].tobytes() for i in ids_k]
-    q2 = [qcat[int(off[i]):int(off[i + 1])].tobytes() for i in ids_k]
-    order2 = sorted(range(len(s2)), key=lambda i: -len(s2[i]))
-    cl2, _ = orc.cluster_reads([s2[i] for i in order2], k=10)
-    clusters = [((order2[m[0]], m[1], -1), [(order2[x[0]], x[1], -1) for x in mem]) for m, mem in cl2]
-    t1 = time.time()
-    orc.correct([b"@r%d" % i for i in range(len(s2))], s2, q2, hps.encode(clusters))
-    dt_correct = time.time() - t1
-    r_cluster, r_correct = len(s) / dt_cluster, len(s2) / dt_correct
+
+    def time_correct(n_target, simd):
+        ids_k = sample(n_target, 6, max(12, n_target // 2))
+        s2 = [cat[int(off[i]):int(off[i + 1])].tobytes() for i in ids_k]
+        q2 = [qcat[int(off[i]):int(off[i + 1])].tobytes() for i in ids_k]
+        order2 = sorted(range(len(s2)), key=lambda i: -len(s2[i]))
+        cl2, _ = orc.cluster_reads([s2[i] for i in order2], k=10)
+        clusters = [((order2[m[0]], m[1], -1), [(order2[x[0]], x[1], -1) for x in mem]) for m, mem in cl2]
+        have = orc.set_poa_simd(simd)
+        t1 = time.time()
+        try:
+            orc.correct([b"@r%d" % i for i in range(len(s2))], s2, q2, hps.encode(clusters))
+        finally:
+            orc.set_poa_simd(False)
+        return len(s2), time.time() - t1, have
+
+    n_v, dt_v, avx2 = time_correct(correct_reads, True)
+    n_s, dt_s, _ = time_correct(correct_reads // 3, False)
+    r_cluster, r_correct, r_scalar = len(s) / dt_cluster, n_v / dt_v, n_s / dt_s
     return {"value": 1.0 / (1.0 / r_cluster + 1.0 / r_correct), "unit": "reads/s", "cores": 1, "kind": "port",
-            "cluster_reads_per_s": r_cluster, "correct_reads_per_s": r_correct,
+            "poa_rows": "AVX2 int16" if avx2 else "scalar (no AVX2 on this CPU)",
+            "cluster_reads_per_s": r_cluster, "correct_reads_per_s": r_correct, "correct_reads_per_s_scalar_rows": r_scalar,
+            "value_scalar_rows": 1.0 / (1.0 / r_cluster + 1.0 / r_scalar),
             "sample": f"oracle, one thread, per phase on whole transcripts of the same workload: cluster {len(s)} reads in {dt_cluster:.1f} s "
-                      f"({int(cnt[0])} pair tests, {int(cnt[1])} full comparisons), correct {len(s2)} reads in {dt_correct:.1f} s; value = harmonic sum"}
+                      f"({int(cnt[0])} pair tests, {int(cnt[1])} full comparisons), correct {n_v} reads in {dt_v:.1f} s with AVX2 int16 POA rows "
+                      f"({n_s} reads in {dt_s:.1f} s with scalar rows); value = harmonic sum"}
 
 
 def cpu_baseline_all_cores(cat, qcat, off, tid):
@@ -139,7 +153,7 @@ def cpu_baseline_all_cores(cat, qcat, off, tid):
     if r.returncode != 0:
         return {"error": r.stderr[-300:]}
     j = json.loads(r.stdout.strip().splitlines()[-1])
-    return {"value": j["reads"] / j["seconds"], "unit": "reads/s", "cores": int(min(cores, j["tasks"])), "nproc": cores, "cpu": model, "kind": "port",
+    return {"value": j["reads"] / j["seconds"], "unit": "reads/s", "cores": int(min(cores, j["tasks"])), "nproc": cores, "cpu": model, "kind": "port", "poa_rows": "AVX2 int16" if j.get("avx2") else "scalar",
             "sample": f"{j['reads']} reads = every read of {j['tasks']} transcripts (6..100 reads each), one oracle task per transcript, {j['seconds']:.1f} s"}
 
 

@@ -130,6 +130,11 @@ class Oracle(_Lib):
         return out + (cnt,)
 
 
+    def set_poa_simd(self, on: bool) -> bool:
+        """POA matrices filled by the AVX2 int16 row kernel (what spoa's SIMD engine does) instead of the scalar loops;
+        returns whether this CPU has AVX2 (without it the scalar fill keeps running)."""
+        return bool(self.lib.orc_set_poa_simd(C.c_int(int(on))))
+
     def fix_msa_ends(self, rows, seqs, quals):
         """correct.cpp:32-92 on hand-built rows; returns (rows, seqs, quals) as the reference leaves them."""
         n, width = len(rows), len(rows[0])

@@ -141,6 +141,16 @@ void orc_fix_msa_ends(char *rows, uint32_t n, uint32_t width, char *seqs, char *
 
 void orc_free(void *p) { free(p); }
 
+// AVX2 int16 row fill of the POA matrices (orc_poa.hpp); returns whether this CPU can run it.
+int orc_set_poa_simd(int on) {
+    poa_simd_default() = on != 0;
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx2") ? 1 : 0;
+#else
+    return 0;
+#endif
+}
+
 // Column-vote tie-break order (6 symbols), see orc_correct.hpp.
 void orc_set_cv_order(const char *o) { set_cv_order(o); }
 

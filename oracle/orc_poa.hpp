@@ -210,22 +210,49 @@ struct poa_graph_t {
     }
 };
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define ORC_X86 1
+#endif
+
 struct poa_engine_t {
     int m = 5, n = -4, g = -8, e = -6;          // correct.cpp:395-396
+    // simd = true: the matrices are filled by an AVX2 int16 row kernel (16 columns per instruction, horizontal gaps by an
+    // in-register prefix maximum) when the CPU has AVX2 and 5 * |seq| fits 16 bits -- what spoa's own SIMD engine does.
+    // Same H / F / E values, same traceback: used for the CPU baseline of bench.py, checked against the scalar fill in
+    // tests/test_oracle_correct.py.
+    bool simd = false;
     std::vector<int32_t> H, F, E;
+    std::vector<int16_t> H16, F16, E16;
 
     // AlignmentEngine::align for type kSW, affine gaps (g < e).
     poa_alignment_t align(const std::string &seq, poa_graph_t &G) {
-        const int32_t NEG = INT_MIN / 2;
         poa_alignment_t aln;
         size_t nv = G.nodes.size();
         if (nv == 0 || seq.empty()) return aln;
-        size_t W = seq.size() + 1, R = nv + 1;
         G.dp_cells += (uint64_t)seq.size() * nv;
-        H.assign(W * R, 0); F.assign(W * R, NEG); E.assign(W * R, NEG);
         std::vector<uint32_t> rank(nv);
         for (size_t r = 0; r < nv; ++r) rank[G.rank_to_node[r]] = (uint32_t)r;
-        int32_t best = 0; long bi = -1, bj = -1;
+        long bi = -1, bj = -1;
+#ifdef ORC_X86
+        if (simd && 5 * seq.size() + 64 < 32000 && __builtin_cpu_supports("avx2")) {
+            const size_t W = ((seq.size() + 1 + 15) / 16) * 16 + 32;
+            fill_avx2(seq, G, rank, W, bi, bj);
+            if (bi == -1) return aln;
+            return trace(seq, G, rank, H16.data(), F16.data(), E16.data(), W, (size_t)bi, (size_t)bj);
+        }
+#endif
+        const size_t W = seq.size() + 1;
+        fill_scalar(seq, G, rank, W, bi, bj);
+        if (bi == -1) return aln;
+        return trace(seq, G, rank, H.data(), F.data(), E.data(), W, (size_t)bi, (size_t)bj);
+    }
+
+    void fill_scalar(const std::string &seq, poa_graph_t &G, const std::vector<uint32_t> &rank, size_t W, long &bi, long &bj) {
+        const int32_t NEG = INT_MIN / 2;
+        size_t nv = G.nodes.size(), R = nv + 1;
+        H.assign(W * R, 0); F.assign(W * R, NEG); E.assign(W * R, NEG);
+        int32_t best = 0;
         for (size_t r = 0; r < nv; ++r) {
             const poa_node_t &nd = G.nodes[G.rank_to_node[r]];
             size_t i = r + 1;
@@ -248,8 +275,92 @@ struct poa_engine_t {
                 if (best < Hr[j]) { best = Hr[j]; bi = (long)i; bj = (long)j; }   // first max in (rank, col) order
             }
         }
-        if (bi == -1) return aln;
-        size_t i = (size_t)bi, j = (size_t)bj;
+    }
+
+#ifdef ORC_X86
+    // whole register moved up by N 16-bit lanes, the vacated lanes filled from `fill`
+    template <int N>
+    __attribute__((target("avx2"))) static inline __m256i shl16(__m256i x, __m256i fill) {
+        const __m256i t = _mm256_permute2x128_si256(x, fill, 0x02);       // low half: fill, high half: x.low
+        if (N == 8) return t;
+        return _mm256_alignr_epi8(x, t, 16 - 2 * (N & 7));
+    }
+
+    __attribute__((target("avx2"))) void fill_avx2(const std::string &seq, poa_graph_t &G, const std::vector<uint32_t> &rank, size_t W, long &bi, long &bj) {
+        const int16_t NEG = -32768;
+        const size_t nv = G.nodes.size(), R = nv + 1, L = seq.size();
+        // no clearing pass: every row is written in full below, only the borders need values (row 0: H = 0, F = -inf; column 0
+        // of every row: H = 0, E = -inf)
+        if (H16.size() < W * R) { H16.resize(W * R); F16.resize(W * R); E16.resize(W * R); }
+        for (size_t j = 0; j < W; ++j) { H16[j] = 0; F16[j] = NEG; E16[j] = NEG; }
+        // query profile: match / mismatch score of every column for the letters that occur in the graph
+        std::vector<std::vector<int16_t>> prof(256);
+        const __m256i vg = _mm256_set1_epi16((short)g), ve = _mm256_set1_epi16((short)e), vneg = _mm256_set1_epi16(NEG), vzero = _mm256_setzero_si256();
+        const __m256i ramp = _mm256_setr_epi16((short)(1 * e), (short)(2 * e), (short)(3 * e), (short)(4 * e), (short)(5 * e), (short)(6 * e), (short)(7 * e), (short)(8 * e),
+                                               (short)(9 * e), (short)(10 * e), (short)(11 * e), (short)(12 * e), (short)(13 * e), (short)(14 * e), (short)(15 * e), (short)(16 * e));
+        const __m256i ve2 = _mm256_set1_epi16((short)(2 * e)), ve4 = _mm256_set1_epi16((short)(4 * e)), ve8 = _mm256_set1_epi16((short)(8 * e));
+        int32_t best = 0;
+        for (size_t r = 0; r < nv; ++r) {
+            const poa_node_t &nd = G.nodes[G.rank_to_node[r]];
+            std::vector<int16_t> &pr = prof[(unsigned char)nd.letter];
+            if (pr.empty()) {
+                pr.assign(W, 0);
+                for (size_t j = 1; j <= L; ++j) pr[j] = (int16_t)(nd.letter == seq[j - 1] ? m : n);
+            }
+            const size_t i = r + 1;
+            int16_t *Hr = &H16[i * W], *Fr = &F16[i * W], *Er = &E16[i * W];
+            const size_t np = nd.in_edges.size();
+            for (size_t pi = 0; pi < std::max<size_t>(np, 1); ++pi) {
+                const size_t p = np == 0 ? 0 : rank[G.edges[nd.in_edges[pi]].begin] + 1;
+                const int16_t *Hp = &H16[p * W], *Fp = &F16[p * W];
+                for (size_t j = 1; j <= L; j += 16) {
+                    const __m256i hp1 = _mm256_loadu_si256((const __m256i *)(Hp + j - 1)), hpj = _mm256_loadu_si256((const __m256i *)(Hp + j));
+                    const __m256i fp = _mm256_loadu_si256((const __m256i *)(Fp + j));
+                    __m256i f = _mm256_max_epi16(_mm256_adds_epi16(hpj, vg), _mm256_adds_epi16(fp, ve));
+                    __m256i h = _mm256_adds_epi16(hp1, _mm256_loadu_si256((const __m256i *)(pr.data() + j)));
+                    if (pi != 0) {
+                        f = _mm256_max_epi16(f, _mm256_loadu_si256((const __m256i *)(Fr + j)));
+                        h = _mm256_max_epi16(h, _mm256_loadu_si256((const __m256i *)(Hr + j)));
+                    }
+                    _mm256_storeu_si256((__m256i *)(Fr + j), f);
+                    _mm256_storeu_si256((__m256i *)(Hr + j), h);
+                }
+            }
+            // Hn = max(diagonal, F, 0); E[j] = max(H[j-1] + g, E[j-1] + e) = max(Hn[j-1] + g, E[j-1] + e) because e >= g:
+            // a prefix maximum with a penalty of e per lane, carried from vector to vector
+            int16_t carry = NEG;                 // E of the column before the vector
+            Hr[0] = 0; Fr[0] = NEG; Er[0] = NEG;
+            for (size_t j = 1; j <= L; j += 16) {
+                __m256i hn = _mm256_max_epi16(_mm256_max_epi16(_mm256_loadu_si256((const __m256i *)(Hr + j)), _mm256_loadu_si256((const __m256i *)(Fr + j))), vzero);
+                _mm256_storeu_si256((__m256i *)(Hr + j), hn);                                   // so that column j-1 of the NEXT vector reads Hn (>= its final H minus E)
+                __m256i x = _mm256_adds_epi16(_mm256_loadu_si256((const __m256i *)(Hr + j - 1)), vg);      // opening a gap after column j-1+t
+                // NB: column j-1 of this vector is the previous vector's last FINAL H (>= Hn): the recurrence wants the final H
+                x = _mm256_max_epi16(x, _mm256_adds_epi16(shl16<1>(x, vneg), ve));
+                x = _mm256_max_epi16(x, _mm256_adds_epi16(shl16<2>(x, vneg), ve2));
+                x = _mm256_max_epi16(x, _mm256_adds_epi16(shl16<4>(x, vneg), ve4));
+                x = _mm256_max_epi16(x, _mm256_adds_epi16(shl16<8>(x, vneg), ve8));
+                x = _mm256_max_epi16(x, _mm256_adds_epi16(_mm256_set1_epi16(carry), ramp));
+                _mm256_storeu_si256((__m256i *)(Er + j), x);
+                const __m256i hf = _mm256_max_epi16(hn, x);
+                _mm256_storeu_si256((__m256i *)(Hr + j), hf);
+                carry = Er[j + 15];
+            }
+            // columns beyond the sequence were computed from padding: put the borders back
+            for (size_t j = L + 1; j < W; ++j) { Hr[j] = 0; Fr[j] = NEG; Er[j] = NEG; }
+            int16_t rowmax = 0;
+            for (size_t j = 1; j <= L; ++j) rowmax = std::max(rowmax, Hr[j]);
+            if (rowmax > best) {
+                best = rowmax; bi = (long)i;
+                for (size_t j = 1; j <= L; ++j) if (Hr[j] == rowmax) { bj = (long)j; break; }
+            }
+        }
+    }
+#endif
+
+    template <typename T>
+    poa_alignment_t trace(const std::string &seq, poa_graph_t &G, const std::vector<uint32_t> &rank, const T *H, const T *F, const T *E, size_t W,
+                          size_t i, size_t j) {
+        poa_alignment_t aln;
         size_t pi_ = 0, pj_ = 0;
         while (H[i * W + j] != 0) {
             int32_t Hij = H[i * W + j];
@@ -260,7 +371,7 @@ struct poa_engine_t {
                 size_t np = nd.in_edges.size();
                 for (size_t k = 0; k < std::max<size_t>(np, 1); ++k) {
                     size_t p = np == 0 ? 0 : rank[G.edges[nd.in_edges[k]].begin] + 1;
-                    if (Hij == H[p * W + j - 1] + mc) { pi_ = p; pj_ = j - 1; found = true; break; }
+                    if (Hij == (int32_t)H[p * W + j - 1] + mc) { pi_ = p; pj_ = j - 1; found = true; break; }
                 }
             }
             if (!found && i != 0) {
@@ -268,13 +379,13 @@ struct poa_engine_t {
                 size_t np = nd.in_edges.size();
                 for (size_t k = 0; k < std::max<size_t>(np, 1); ++k) {
                     size_t p = np == 0 ? 0 : rank[G.edges[nd.in_edges[k]].begin] + 1;
-                    if ((ext_up = (Hij == F[p * W + j] + e)) || Hij == H[p * W + j] + g) {
+                    if ((ext_up = (Hij == (int32_t)F[p * W + j] + e)) || Hij == (int32_t)H[p * W + j] + g) {
                         pi_ = p; pj_ = j; found = true; break;
                     }
                 }
             }
             if (!found && j != 0) {
-                if ((ext_left = (Hij == E[i * W + j - 1] + e)) || Hij == H[i * W + j - 1] + g) {
+                if ((ext_left = (Hij == (int32_t)E[i * W + j - 1] + e)) || Hij == (int32_t)H[i * W + j - 1] + g) {
                     pi_ = i; pj_ = j - 1; found = true;
                 }
             }
@@ -284,7 +395,7 @@ struct poa_engine_t {
                 while (true) {
                     aln.emplace_back(-1, (int32_t)(j - 1));
                     --j;
-                    if (E[i * W + j] + e != E[i * W + j + 1]) break;
+                    if ((int32_t)E[i * W + j] + e != (int32_t)E[i * W + j + 1]) break;
                 }
             } else if (ext_up) {
                 while (true) {
@@ -293,7 +404,7 @@ struct poa_engine_t {
                     const poa_node_t &nd = G.nodes[G.rank_to_node[i - 1]];
                     for (uint32_t ei : nd.in_edges) {
                         size_t p = rank[G.edges[ei].begin] + 1;
-                        if ((stop = (F[i * W + j] == H[p * W + j] + g)) || F[i * W + j] == F[p * W + j] + e) {
+                        if ((stop = ((int32_t)F[i * W + j] == (int32_t)H[p * W + j] + g)) || (int32_t)F[i * W + j] == (int32_t)F[p * W + j] + e) {
                             pi_ = p; break;
                         }
                     }
@@ -309,9 +420,12 @@ struct poa_engine_t {
 };
 
 // The call pattern of correct.cpp:398-405.
+inline bool &poa_simd_default() { static bool v = false; return v; }      // bench.py's CPU baseline switches the AVX2 rows on
+
 inline std::vector<std::string> poa_msa(const std::vector<std::string> &seqs, uint64_t *cells = nullptr) {
     poa_graph_t G;
     poa_engine_t eng;
+    eng.simd = poa_simd_default();
     for (auto &s : seqs) {
         poa_alignment_t a = eng.align(s, G);
         G.add_alignment(a, s);

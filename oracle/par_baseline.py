@@ -1,5 +1,5 @@
 """ORACLE-side helper of bench.py's cpu_baseline_all_cores leg (test / measurement infrastructure, not shipped):
-the scalar oracle (cluster + correct) over a sample of whole transcripts, one task per transcript, on a
+the oracle (cluster + correct, POA rows in AVX2 int16 where available) over a sample of whole transcripts, one task per transcript, on a
 process pool.  usage: par_baseline.py SAMPLE.npz WORKERS  ->  one JSON line."""
 import json
 import multiprocessing as mp
@@ -22,6 +22,7 @@ def _run(task):
     orc = _G.get("orc")
     if orc is None:
         orc = _G["orc"] = orc_mod.Oracle()
+        _G["simd"] = orc.set_poa_simd(True)              # AVX2 int16 POA rows where the CPU has them (what spoa's SIMD engine runs)
     s, q = task
     order = sorted(range(len(s)), key=lambda i: -len(s[i]))
     cl, _ = orc.cluster_reads([s[i] for i in order], k=10)
@@ -43,7 +44,8 @@ def main():
     with mp.get_context("fork").Pool(workers) as pool:
         done = pool.map(_run, tasks, chunksize=1)
     dt = time.time() - t0
-    print(json.dumps({"reads": int(sum(done)), "seconds": dt, "workers": workers, "tasks": len(tasks)}))
+    import oracle as orc_mod
+    print(json.dumps({"reads": int(sum(done)), "seconds": dt, "workers": workers, "tasks": len(tasks), "avx2": bool(orc_mod.Oracle().set_poa_simd(True))}))
 
 
 if __name__ == "__main__":

@@ -148,3 +148,27 @@ def test_fix_msa_ends_hand_built_rows(oracle):
     assert out_rows[3] == rows[3] and out_s[3] == seqs[3] and out_q[3] == quals[3]
     # "ACGTA---CGTAC" is ONE block of 10 bases (3 gaps do not end it): nothing is cut although 20 gaps follow
     assert out_rows[4] == rows[4] and out_s[4] == seqs[4]
+
+
+def test_avx2_row_fill_gives_the_scalar_alignments(oracle):
+    """The AVX2 int16 fill of H / F / E (bench.py's CPU baseline) against the scalar restatement: identical MSAs on noisy packs
+    (deep graphs, ties, long gaps) and identical `correct` outputs."""
+    import numpy as np
+    from rattle_amd import hps, synth
+    if not oracle.set_poa_simd(False):
+        pytest.skip("no AVX2 on this CPU")
+    seqs, quals, tid, _ = synth.reads(260, 4, 1, False, seed=3)
+    packs = [[seqs[i] for i in range(len(seqs)) if tid[i] == g][:40] for g in range(4)]
+    packs.append([b"ACGT" * 30, b"ACGT" * 28 + b"AC", b"CGT" + b"ACGT" * 29, b"ACGA" * 30, b"TTTTTTTT", b"ACGT" * 12 + b"G" * 40 + b"ACGT" * 18])
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters = [((int(np.nonzero(tid == g)[0][0]), 0, -1), [(int(i), 0, -1) for i in np.nonzero(tid == g)[0]]) for g in range(4)]
+    want = [oracle.poa_msa(p)[0] for p in packs]
+    want_c = oracle.correct(headers, seqs, quals, hps.encode(clusters), split=30)
+    try:
+        oracle.set_poa_simd(True)
+        got = [oracle.poa_msa(p)[0] for p in packs]
+        got_c = oracle.correct(headers, seqs, quals, hps.encode(clusters), split=30)
+    finally:
+        oracle.set_poa_simd(False)
+    assert got == want
+    assert got_c[:3] == want_c[:3]
