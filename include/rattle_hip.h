@@ -180,6 +180,7 @@ void rattle_hip_msa_set_free(rattle_msa_set *ms);
  * collected in pack order (the reference's multi-thread run uses completion order).
  * Headers are not handled here: the caller derives them from read_id / cluster_id / gene_id.
  */
+struct rattle_read_set_s;      /* rattle_read_set, defined below */
 typedef struct {
     double min_occ, gap_occ, err_ratio;   /* 0.3, 0.3, 30.0 */
     int split, min_reads;                 /* 200, 5 */
@@ -204,9 +205,16 @@ typedef struct {
      * pack whose largest alignment would need more than that many DP cells by the bound
      * (6 * longest read + 64) * longest read; 0 = no such limit. */
     uint64_t max_pack_cells;
+    /* Optional (ABI 3; NULL = off): called ONCE, from a thread of the library, as soon as this call's corrected reads are
+     * complete in host memory -- the consensus stages (POA #2 / #3) still run on the device, so a caller can format and
+     * write corrected.fq meanwhile (the reference writes its three files after correct_reads returns, main.cpp:405-408).
+     * `corrected` is the set the call will return in rattle_correction::corrected (same pointers, read-only here),
+     * `corrected_pack` its per-record pack index.  Not called when the call fails before that point or has no pack. */
+    void (*corrected_ready)(void *user, const struct rattle_read_set_s *corrected, const uint32_t *corrected_pack);
+    void *corrected_ready_user;
 } rattle_correct_params;
 
-typedef struct {
+typedef struct rattle_read_set_s {
     uint32_t n;
     int32_t *read_id;       /* original read index, or -1 for a consensus */
     int32_t *cluster_id;    /* index of the cluster in the input cluster set */

@@ -32,7 +32,7 @@ class CorrectParams(C.Structure):
                 ("min_reads", C.c_int), ("n_threads", C.c_int), ("vote_order", C.c_char * 8),
                 ("n_pack_orders", C.c_uint32), ("pack_order_cluster", C.POINTER(C.c_uint32)),
                 ("pack_order_offsets", C.POINTER(C.c_uint32)), ("pack_order_perm", C.POINTER(C.c_uint32)),
-                ("max_pack_cells", C.c_uint64)]
+                ("max_pack_cells", C.c_uint64), ("corrected_ready", C.c_void_p), ("corrected_ready_user", C.c_void_p)]
 
 
 class ReadSet(C.Structure):

@@ -36,7 +36,7 @@ static int use_device(rattle_ctx *c) {
 extern "C" {
 
 const char *rattle_hip_last_error(void) { return g_err.c_str(); }
-int rattle_hip_abi_version(void) { return 2; }
+int rattle_hip_abi_version(void) { return 3; }
 
 int rattle_hip_ctx_create(int device, rattle_ctx **out) {
     if (!out) { set_error("out is null"); return RATTLE_ERR_ARG; }

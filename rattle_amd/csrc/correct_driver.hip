@@ -470,11 +470,17 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
                 char *dst_s = C.seq, *dst_q = C.qual;
                 const uint8_t *src_s = d_os.p, *src_q = d_oq.p;
                 const int dev = ctx->device;
+                const rattle_read_set *ready_set = &R->corrected;
+                const uint32_t *ready_pack = cor_pack.data();
+                auto ready_fn = P->corrected_ready;
+                void *ready_user = P->corrected_ready_user;
                 d2h = std::thread([=, &d2h_err]() {
                     hipError_t e = hipSetDevice(dev);
                     if (e == hipSuccess) e = hipMemcpy(dst_s, src_s, tot, hipMemcpyDeviceToHost);
                     if (e == hipSuccess) e = hipMemcpy(dst_q, src_q, tot, hipMemcpyDeviceToHost);
                     d2h_err = e;
+                    // the corrected reads are final from here on: the caller may start writing them out while POA #2 / #3 run
+                    if (e == hipSuccess && ready_fn) ready_fn(ready_user, ready_set, ready_pack);
                 });
             }
         }

@@ -782,19 +782,6 @@ int mode_correct(int argc, char **argv) {
     if (a.has("max-pack-cells")) P.max_pack_cells = std::stoull(a.str("max-pack-cells", "0"));
     t_cl.reset();
     { cli_timer t("wait for device + arena"); opener.wait(); }
-    rattle_correction *R = nullptr;
-    std::unique_ptr<cli_timer> t_lib(new cli_timer("library: correct_reads"));
-    team.run([&](int r, rattle_ctx *ctx) {                                      // packs sharded over the ranks, result reassembled on rank 0
-        rattle_correction *mine = nullptr, *merged = nullptr;
-        chk(rattle_hip_correct_reads(ctx, cat.data(), qcat.data(), off.data(), n_reads, (uint32_t)clusters.size(), coff.data(), mid.data(),
-                                     mrev.data(), &P, &mine));
-        if (team.n() == 1) { R = mine; return; }
-        chk(rattle_hip_correction_gather(ctx, mine, 0, &merged));
-        rattle_hip_correction_free(mine);
-        if (r == 0) R = merged;
-    });
-    t_lib.reset();
-    cli_timer t_out("format + write outputs");
     auto tag = [&](int cid) {                                                    // correct.cpp:348-353
         int gid = clusters[cid].main_seq.gene_id;
         if (gid == -1) return ",gene_cluster_" + std::to_string(cid);
@@ -830,6 +817,28 @@ int mode_correct(int argc, char **argv) {
         });
         if (!text.finish()) die("Error: cannot write " + path);
     };
+    const std::string outdir = a.str("output", ".");
+    // corrected.fq is formatted and written from the library's corrected_ready callback, while POA #2 / #3 still run on the
+    // device (one device: the sharded job reassembles its reads at the end)
+    struct early_out { std::function<void(const rattle_read_set &)> write; std::atomic<bool> done{false}; } early;
+    early.write = [&](const rattle_read_set &S) { cli_timer t("corrected.fq (behind the consensus stages)"); write_set(S, true, outdir + "/corrected.fq"); };
+    rattle_correction *R = nullptr;
+    std::unique_ptr<cli_timer> t_lib(new cli_timer("library: correct_reads"));
+    if (team.n() == 1) {
+        P.corrected_ready = [](void *u, const rattle_read_set_s *S, const uint32_t *) { early_out *E = (early_out *)u; E->write(*S); E->done = true; };
+        P.corrected_ready_user = &early;
+    }
+    team.run([&](int r, rattle_ctx *ctx) {                                      // packs sharded over the ranks, result reassembled on rank 0
+        rattle_correction *mine = nullptr, *merged = nullptr;
+        chk(rattle_hip_correct_reads(ctx, cat.data(), qcat.data(), off.data(), n_reads, (uint32_t)clusters.size(), coff.data(), mid.data(),
+                                     mrev.data(), &P, &mine));
+        if (team.n() == 1) { R = mine; return; }
+        chk(rattle_hip_correction_gather(ctx, mine, 0, &merged));
+        rattle_hip_correction_free(mine);
+        if (r == 0) R = merged;
+    });
+    t_lib.reset();
+    cli_timer t_out("format + write outputs");
     read_set_t consensi;
     // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's packs
     std::vector<std::vector<int>> label_counts(clusters.size(), std::vector<int>(labels.size(), 0));
@@ -865,8 +874,7 @@ int mode_correct(int argc, char **argv) {
         consensi.push_back(r);
     }
     std::cerr << std::endl << "Generating consensi..." << std::endl;
-    std::string outdir = a.str("output", ".");
-    write_set(R->corrected, true, outdir + "/corrected.fq");
+    if (!early.done) write_set(R->corrected, true, outdir + "/corrected.fq");
     write_set(R->uncorrected, false, outdir + "/uncorrected.fq");
     write_fastq_file(consensi, outdir + "/consensi.fq");
     if (R->skipped.n) {
