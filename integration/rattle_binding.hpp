@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -111,13 +112,23 @@ correction_results_t correct_reads(const cluster_set_t &clusters, read_set_t &re
     to_reads(R->uncorrected, false, out.uncorrected);
     // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's queued packs
     std::vector<std::vector<int>> label_counts(clusters.size(), std::vector<int>(labels.size(), 0));
-    if (!labels.empty())
+    if (!labels.empty()) {
+        // packs the library skipped (rattle_skip_list: stage 0 indexed among all packs of the cluster, stages 1-2 among its
+        // queued packs) produced no pack consensus and are not counted, as in `reads=`
+        std::set<std::pair<int, uint32_t>> skip_all, skip_queued;
+        for (uint32_t i = 0; i < R->skipped.n; ++i) {
+            if (R->skipped.stage[i] == 0) skip_all.insert({R->skipped.cluster_id[i], R->skipped.pack[i]});
+            else if (R->skipped.stage[i] <= 2) skip_queued.insert({R->skipped.cluster_id[i], R->skipped.pack[i]});
+        }
         for (size_t c = 0; c < clusters.size(); ++c) {
             const int n = (int)clusters[c].seqs.size();
             if (n == 0) continue;
             const int n_files = (n - 1) / split + 1;
+            uint32_t queued = 0;
             for (int nf = 0; nf < n_files; ++nf) {
                 if ((n - 1 - nf) / n_files + 1 <= min_reads) continue;
+                if (skip_all.count({(int)c, (uint32_t)nf})) continue;
+                if (skip_queued.count({(int)c, queued++})) continue;
                 for (int j = nf; j < n; j += n_files) {
                     const std::string &h = reads[clusters[c].seqs[j].seq_id].header;
                     const size_t q = h.find_first_of(",");
@@ -127,6 +138,7 @@ correction_results_t correct_reads(const cluster_set_t &clusters, read_set_t &re
                 }
             }
         }
+    }
     for (uint32_t i = 0; i < R->consensi.n; ++i) {
         const int cid = R->consensi.cluster_id[i];
         std::string lr;

@@ -7,7 +7,7 @@ context is created, the call fails loudly.
 from __future__ import annotations
 
 import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: one hardware queue per POA column class (csrc/poa.hip)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")      # before the HIP runtime starts: one hardware queue per POA column class (csrc/poa.hip)
 import ctypes as C
 import os
 

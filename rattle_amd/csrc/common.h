@@ -269,8 +269,8 @@ struct rattle_ctx {
     // POA arena: kept across stages and calls (allocating ~100 GB costs seconds)
     uint8_t *poa_arena = nullptr;
     size_t poa_arena_bytes = 0;
-    hipStream_t poa_st[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // one per column class: classes run concurrently
-    hipEvent_t poa_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t poa_st[16] = {};     // one per column class: classes run concurrently
+    hipEvent_t poa_ev[16] = {};
     hipEvent_t poa_go = nullptr;
     rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns
     // reads staged in HBM by rattle_hip_stage_reads (keys: the host buffers they were copied from)
@@ -294,7 +294,7 @@ struct rattle_ctx {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         if (poa_arena) (void)hipFree(poa_arena);
-        for (int i = 0; i < 8; ++i) { if (poa_st[i]) (void)hipStreamDestroy(poa_st[i]); if (poa_ev[i]) (void)hipEventDestroy(poa_ev[i]); }
+        for (int i = 0; i < 16; ++i) { if (poa_st[i]) (void)hipStreamDestroy(poa_st[i]); if (poa_ev[i]) (void)hipEventDestroy(poa_ev[i]); }
         if (poa_go) (void)hipEventDestroy(poa_go);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);

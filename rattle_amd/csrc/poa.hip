@@ -46,6 +46,9 @@ namespace rattle {
 #ifndef POA_WIDE_RING
 #define POA_WIDE_RING 4                    // rows of the wide classes kept in LDS (a dword per cell: 32 KB per row at 8192 columns)
 #endif
+#ifndef POA_LONG_RING
+#define POA_LONG_RING 3                    // rows of a segment kept in LDS beyond 8192 columns (32 KB per row)
+#endif
 #ifndef POA_V3
 #define POA_V3 1                           // packed classes whose ring is a power of two take dp_rows_v3
 #endif
@@ -1590,6 +1593,227 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
     multi = X.multi != 0;
 }
 
+// ---- the same rows, SEGMENT-MAJOR with an LDS ring (PK == 2, RING > 0) ----------------------------------------------
+// dp_rows_long walks a row segment by segment and re-reads every predecessor from HBM: ~3 us per row and segment, a pack of
+// 200 reads of 15 kb sits on its CU for 80 s (config 5, profiles/README.md round 3).  A cell (row, segment) depends on the
+// predecessor rows of the SAME segment and, through the prefix maximum of u and the H of the column left of the segment, on
+// (row, segment - 1): so the segments can be done one after the other, each over ALL rows -- and one segment is exactly
+// dp_rows_wide (plan through the scalar cache, predecessors from the ring, one barrier per row) with two numbers per row
+// carried from the segment before: Cin[row] = max of u over all columns left of the segment (lh[4 row + parity]) and
+// H[row][seg0 - 1] (in the record).  int32 record as dp_rows_long: H plus a nibble per column.
+template <int CPL, int RING, int NW>
+__device__ void dp_rows_longr(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row,
+                              bool &multi) {
+    static_assert(CPL == 8 && NW <= 16 && RING > 0, "two int4 per thread, row and segment");
+    constexpr int NT = 64 * NW;
+    constexpr uint32_t SEG = (uint32_t)NT * CPL;
+    int32_t *H = (int32_t *)S.H;
+    uint32_t *NB = (uint32_t *)S.E;                  // per eight columns: nibbles min(H-F,3) | min(H-E,3) << 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *const ring_thr = S.ring + (size_t)tid * CPL;             // slot s of this thread: ring_thr + s * NT * CPL
+    uint32_t *const lhr = (uint32_t *)S.lh_ring + wave;                // slot s of this wavefront: lhr[NW * s]
+    int32_t lbest = 0;
+    uint32_t lrow = 0, lcnt = 0;                     // first row in which this thread's columns reach lbest, and in how many (row, segment) steps they do
+    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb;
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb) : : "memory");
+    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb;
+
+    uint32_t segi = 0;
+    for (uint32_t seg0 = 0; seg0 < Lp; seg0 += SEG, ++segi) {
+        const uint32_t c0 = seg0 + (uint32_t)tid * CPL;
+        const bool act = c0 < Lp;
+        const bool wave_act = seg0 + (uint32_t)wave * 64u * CPL < Lp;
+        const uint32_t n_aw = min((uint32_t)NW, (Lp - seg0 + 64u * CPL - 1u) / (64u * CPL));      // wavefronts with columns in this segment
+        const int32_t *Cin = S.lh + (segi & 1u);                       // Cin[4 * row]: written by the segment before
+        int32_t *Cout = S.lh + ((segi + 1u) & 1u);
+        uint32_t sw[CPL / 4];
+#pragma unroll
+        for (int u = 0; u < CPL / 4; ++u) sw[u] = 0;
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { const uint32_t col = c0 + t; sw[t >> 2] |= (uint32_t)(col < L ? s[col] : 0) << (8 * (t & 3)); }
+        }
+        const int32_t je0 = ((int32_t)c0 + 1) * POA_E;
+        __syncthreads();                             // the ring and the exchange area are reused from the segment before; its record stores are visible
+
+        auto step = [&](auto par_tag, const uint32_t row, const u32x4 pa, const u32x4 pb) __attribute__((always_inline)) {
+            constexpr uint32_t par = decltype(par_tag)::value;
+            const uint32_t info = pa.x;
+            const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+            // what the segment before left for this row: the prefix maximum of u, and (wavefront 0) the H left of the segment
+            int32_t cin = POA_G - POA_E, hseg = 0;
+            if (seg0) {
+                cin = __builtin_amdgcn_readfirstlane(Cin[4 * (size_t)row]);
+                if (wave == 0) hseg = __builtin_amdgcn_readfirstlane(H[(uint64_t)row * Lp + seg0 - 1]);
+            }
+            int32_t hm[CPL], fm[CPL];
+            auto pred = [&](auto first_tag, const uint32_t prow) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(first_tag)::value;
+                int32_t hp[CPL], fd[CPL];
+                int32_t hl;
+                if (row - prow <= (uint32_t)RING) {
+                    const uint32_t slot = prow % (uint32_t)RING;
+                    const uint4 *rp = (const uint4 *)(ring_thr + slot * (uint32_t)(NT * CPL));
+#pragma unroll
+                    for (int u = 0; u < CPL / 4; ++u) {
+                        const uint4 a = rp[u];
+                        hp[4 * u] = (int32_t)(a.x & 0x0FFFFFFFu); fd[4 * u] = hp[4 * u] - (int32_t)(a.x >> 30);
+                        hp[4 * u + 1] = (int32_t)(a.y & 0x0FFFFFFFu); fd[4 * u + 1] = hp[4 * u + 1] - (int32_t)(a.y >> 30);
+                        hp[4 * u + 2] = (int32_t)(a.z & 0x0FFFFFFFu); fd[4 * u + 2] = hp[4 * u + 2] - (int32_t)(a.z >> 30);
+                        hp[4 * u + 3] = (int32_t)(a.w & 0x0FFFFFFFu); fd[4 * u + 3] = hp[4 * u + 3] - (int32_t)(a.w >> 30);
+                    }
+                    hl = (int32_t)lhr[(uint32_t)NW * slot];
+                } else {
+                    hl = 0;
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) { hp[t] = 0; fd[t] = POA_G - POA_E; }
+                    if (act) {
+                        const int32_t *hq = H + (uint64_t)prow * Lp + c0;
+                        const int4 h0 = *(const int4 *)hq, h1 = *(const int4 *)(hq + 4);
+                        const uint32_t nbv = NB[((uint64_t)prow * Lp + c0) >> 3];
+                        if (lane == 0 && c0) hl = hq[-1];
+                        hp[0] = h0.x; hp[1] = h0.y; hp[2] = h0.z; hp[3] = h0.w; hp[4] = h1.x; hp[5] = h1.y; hp[6] = h1.z; hp[7] = h1.w;
+#pragma unroll
+                        for (int t = 0; t < CPL; ++t) fd[t] = hp[t] - min((int32_t)((nbv >> (4 * t)) & 3u), 2);
+                    }
+                    drain_vector_loads();
+                }
+                const int32_t hleft = wave_shr1(hp[CPL - 1], hl);
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const int32_t hd = t == 0 ? hleft : hp[t - 1];
+                    hm[t] = FIRST ? hd : max(hm[t], hd);
+                    fm[t] = FIRST ? fd[t] : max(fm[t], fd[t]);
+                }
+            };
+            if (n_in == 0) {
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) { hm[t] = 0; fm[t] = POA_G - POA_E; }
+            } else {
+                pred(std::true_type{}, pb.x);
+                if (n_in > 1) pred(std::false_type{}, pb.y);
+                if (n_in > 2) pred(std::false_type{}, pb.z);
+                if (n_in > 3) {
+                    pred(std::false_type{}, pb.w);
+                    uint32_t e = pa.z;
+                    for (uint32_t k = 4; k < n_in; ++k) {
+                        const uint2 ed = S.edges[e]; e = ed.y;
+                        const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
+                        drain_vector_loads();
+                        pred(std::false_type{}, prow);
+                    }
+                }
+            }
+            int32_t hn[CPL], fr[CPL], ex[CPL];
+            int32_t run = POA_NEG;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int32_t sc = ((sw[t >> 2] >> (8 * (t & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                fr[t] = fm[t] + POA_E;
+                hn[t] = max(max(hm[t] + sc, fr[t]), 0);
+                ex[t] = run;
+                run = max(run, hn[t] + (POA_G - POA_E) - je0 - t * POA_E);
+            }
+            const int32_t wincl = wave_scan_max_fused(act ? run : POA_NEG);
+            const int32_t texcl = wave_shr1(wincl, POA_NEG);
+            int32_t base = cin;
+            int32_t hl_new = hseg;
+            if (lane == 63) {
+                X.TW[par][wave] = wincl;
+                if (wave < NW - 1) X.QW[par][wave + 1] = make_int2(max(texcl, ex[CPL - 1]), hn[CPL - 1]);
+            }
+            row_barrier();
+            int32_t tv = lane < NW ? X.TW[par][lane] : POA_NEG;
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x112 /*row_shr:2*/, 0xF, 0xF, false));
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x114 /*row_shr:4*/, 0xF, 0xF, false));
+            tv = max(tv, __builtin_amdgcn_update_dpp(POA_NEG, tv, 0x118 /*row_shr:8*/, 0xF, 0xF, false));
+            if (wave > 0) {
+                const int32_t pw = __builtin_amdgcn_readlane(tv, wave - 1);
+                const int32_t pw1 = wave > 1 ? __builtin_amdgcn_readlane(tv, wave - 2) : POA_NEG;
+                const int2 q = X.QW[par][wave];
+                const int32_t qx = __builtin_amdgcn_readfirstlane(q.x), qy = __builtin_amdgcn_readfirstlane(q.y);
+                base = max(base, pw);
+                const int32_t bp = max(cin, pw1);
+                const int32_t c0w = (int32_t)(seg0 + (uint32_t)wave * 64u * CPL);        // 1-based index of the column left of the wave
+                hl_new = max(qy, max(bp, qx) + c0w * POA_E);
+            } else if (tid == 0) {
+                Cout[4 * (size_t)row] = max(cin, __builtin_amdgcn_readlane(tv, n_aw - 1));     // for the next segment (idle wavefronts publish nothing)
+            }
+            base = max(base, texcl);
+            uint32_t nbo = 0;
+            uint32_t rw[CPL];
+            int32_t hv[CPL];
+            int32_t rmax = 0;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int32_t ev = max(base, ex[t]) + je0 + t * POA_E;
+                hv[t] = max(hn[t], ev);
+                rmax = max(rmax, hv[t]);
+                const uint32_t df = (uint32_t)min(hv[t] - fr[t], 3);
+                nbo |= (df | ((uint32_t)min(hv[t] - ev, 3) << 2)) << (4 * t);
+                rw[t] = (uint32_t)hv[t] | (min(df, 2u) << 30);
+            }
+            if (act) {                               // per thread: best value, the smallest row that reaches it, how often it is reached
+                const bool gt = rmax > lbest, eq = rmax == lbest;
+                lcnt = gt ? 1u : lcnt + (eq ? 1u : 0u);
+                lrow = gt ? row : (eq ? min(lrow, row) : lrow);
+                lbest = gt ? rmax : lbest;
+            }
+            {
+                const uint32_t slot = row % (uint32_t)RING;
+                uint4 *rp = (uint4 *)(ring_thr + slot * (uint32_t)(NT * CPL));
+#pragma unroll
+                for (int u = 0; u < CPL / 4; ++u) rp[u] = make_uint4(rw[4 * u], rw[4 * u + 1], rw[4 * u + 2], rw[4 * u + 3]);
+                if (lane == 0) lhr[(uint32_t)NW * slot] = (uint32_t)hl_new;
+                if (act) {
+                    int32_t *hq = H + (uint64_t)row * Lp + c0;
+                    *(int4 *)hq = make_int4(hv[0], hv[1], hv[2], hv[3]);
+                    *(int4 *)(hq + 4) = make_int4(hv[4], hv[5], hv[6], hv[7]);
+                    NB[((uint64_t)row * Lp + c0) >> 3] = nbo;
+                }
+            }
+        };
+
+        if (!wave_act) {
+            for (uint32_t r = 0; r < n; ++r) row_barrier();
+        } else {
+            u32x4 na = cpa[0], nb = cpb[0];
+            for (uint32_t row = 1; row <= n; row += 2) {
+                {
+                    const u32x4 pa = na, pb = nb;
+                    if (row < n) { na = cpa[row]; nb = cpb[row]; }
+                    step(std::integral_constant<uint32_t, 1>{}, row, pa, pb);
+                }
+                if (row + 1 <= n) {
+                    const u32x4 pa = na, pb = nb;
+                    if (row + 1 < n) { na = cpa[row + 1]; nb = cpb[row + 1]; }
+                    step(std::integral_constant<uint32_t, 0>{}, row + 1, pa, pb);
+                }
+            }
+        }
+        drain_vector_loads();
+    }
+    __syncthreads();
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wave] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 0; X.ntl = 0; }
+    __syncthreads();
+    best = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
+    const bool mine = best > 0 && lbest == best;
+    if (mine) atomicMin(&X.brow, lrow);
+    __syncthreads();
+    best_row = best > 0 ? X.brow : 0u;
+    if (mine) {
+        if (lcnt != 1 || lrow != best_row) X.multi = 1;      // another row (or the same row in another thread's later pass) reaches it too
+        X.ntl = 17;                                  // a thread's columns are spread over the segments: ties rescan whole rows
+    }
+    __syncthreads();
+    multi = X.multi != 0;
+}
+
 // ---- graph update helpers (lane 0) --------------------------------------------------------------
 __device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
     if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return 0; }
@@ -1749,7 +1973,8 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
                 bool multi = false;
-                if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
+                if constexpr (PK == 2 && RING > 0) dp_rows_longr<CPL, RING, NW>(S, X, s, n, L, Lp, best, best_row, multi);
+                else if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 3) dp_rows_wide<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1 && POA_V3) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
@@ -2328,10 +2553,16 @@ struct poa_variant {
 };
 #define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, PK, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
 #define POA_CLASSES 8
+#define POA_GROUPS 12                          // + the shallow packs of classes 4 .. 7 as groups of their own (poa_device_run)
+#ifndef POA_SHALLOW_READS
+#define POA_SHALLOW_READS 40
+#endif
+static inline int poa_group_class(int g) { return g < POA_CLASSES ? g : g - 4; }
 static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144, 8192};
 static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1),
                                                    POA_VARIANT(8, POA_WIDE_RING, 8, 3), POA_VARIANT(8, POA_WIDE_RING, 12, 3), POA_VARIANT(8, POA_WIDE_RING, 16, 3),
-                                                   POA_VARIANT(8, 0, 16, 2) /* longer than 8192: int32 cells, segmented rows */};
+                                                   POA_VARIANT(8, POA_LONG_RING, 16, 2) /* longer than 8192: int32 cells, 8192-column segments one after the other */};
+static const poa_variant k_long_noring = POA_VARIANT(8, 0, 16, 2);      // ... row-major segments without a ring when the graph's bitmaps leave no LDS for it
 static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
@@ -2360,7 +2591,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // length class of each pack: 1024 / 1536 / 2048 / 2560 / 4096 / 6144 columns, or longer (segmented int32 rows)
     std::vector<uint64_t> pbases(n_packs);
     std::vector<uint32_t> pmaxL(n_packs);
-    std::vector<uint32_t> by_class[POA_CLASSES];
+    std::vector<uint32_t> by_class[POA_GROUPS];      // groups 0 .. 7: the column classes; 8 .. 11: the SHALLOW packs of classes 4 .. 7 (smaller slots, more of them)
     for (uint32_t p = 0; p < n_packs; ++p) {
         uint32_t m = 0;
         for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) m = std::max<uint32_t>(m, (uint32_t)(off[q + 1] - off[q]));
@@ -2373,6 +2604,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         }
         int cls = 0;
         while (cls < POA_CLASSES - 1 && m > k_class_cols[cls]) ++cls;
+        // a long-read pack's slot is its DP record: hundreds of MB to GBs, sized by the rows its graph will reach -- which depends
+        // on its depth (~1.15 + 0.02 x reads nodes per base, measured at 10 % error).  The shallow packs of a long class get a
+        // group of their own, so that the deep ones do not dictate everybody's slot (config 5: 47 slots of 1.15 GB for 747 packs)
+        if (cls >= 4 && pack_first[p + 1] - pack_first[p] <= POA_SHALLOW_READS) cls += 4;
         by_class[cls].push_back(p);
     }
 
@@ -2406,13 +2641,13 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     int rc = 0;
     if (!ctx->poa_go) {
         RT_HIP(hipEventCreateWithFlags(&ctx->poa_go, hipEventDisableTiming));
-        for (int i = 0; i < POA_CLASSES; ++i) {
+        for (int i = 0; i < 16; ++i) {
             RT_HIP(hipStreamCreateWithFlags(&ctx->poa_st[i], hipStreamNonBlocking));
             RT_HIP(hipEventCreateWithFlags(&ctx->poa_ev[i], hipEventDisableTiming));
         }
     }
     dbuf<uint32_t> d_heads;
-    RT_TRY(d_heads.reserve(8));
+    RT_TRY(d_heads.reserve(16));
     // RATTLE_POA_TIMELINE=<file>: when each pack's workgroup started and finished it (measurement aid: how full the device is over a pass)
     const char *tl_path = getenv("RATTLE_POA_TIMELINE");
     dbuf<unsigned long long> d_tl;
@@ -2429,13 +2664,13 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         int rounds = 0;                            // passes this class has taken
         bool clamped = false;                      // cell_cap was cut to what one slot can get: packs that still fail are skipped
         const poa_variant *V = nullptr;
-    } C[POA_CLASSES];
+    } C[POA_GROUPS];
     // RATTLE_POA_WAVES=1 selects the one/two-wave variants (measured slower than four waves per pack even
     // with thousands of packs in flight: 353 vs 401 GCUPS at 1 kb, 395 vs 429 at 1.4 kb; kept for experiments)
     const int force_waves = getenv("RATTLE_POA_WAVES") ? atoi(getenv("RATTLE_POA_WAVES")) : 0;
-    for (int c = 0; c < POA_CLASSES; ++c) {
+    for (int c = 0; c < POA_GROUPS; ++c) {
         C[c].todo = by_class[c];
-        C[c].V = &k_latency[c];
+        C[c].V = &k_latency[poa_group_class(c)];
         if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
         if (c < 2 && getenv("RATTLE_POA_EXP")) {
             int a = -1, b = -1;
@@ -2453,7 +2688,8 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     auto plan_class = [&](int c, uint64_t tb, uint32_t tl) {
         cls_plan &P = C[c];
         const uint32_t cpl = P.V->cpl;
-        const bool long_rows = c == POA_CLASSES - 1;     // int32 cells, sequence read in place (no LDS copy)
+        const int gc = poa_group_class(c);
+        const bool long_rows = gc == POA_CLASSES - 1;    // int32 cells, sequence read in place (no LDS copy)
         uint32_t ncap = (uint32_t)std::min<uint64_t>(P.node_cap, tb + 1);
         ncap = (ncap + 31u) & ~31u;
         const uint32_t ecap = (uint32_t)std::min<uint64_t>(tb + 1, 0x7FFFFFFFull);
@@ -2484,7 +2720,8 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
             return (size_t)lds_seq + ((size_t)poa_bit_words(ncap) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 4 * std::max<uint32_t>(4, V->nw) + 64;
         };
-        if ((c == 4 || c == 5 || c == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[c - 4];
+        if ((gc == 4 || gc == 5 || gc == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[gc - 4];
+        if (gc == POA_CLASSES - 1 && lds_bytes(P.V) > 158u * 1024) P.V = &k_long_noring;
         P.shm = lds_bytes(P.V);
         A.node_cap = ncap; A.edge_cap = ecap; A.cell_cap = ccap; A.aln_cap = acap; A.spill_cap = scap; A.seq_cap = lds_seq;
         return o;
@@ -2498,7 +2735,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     for (int pass = 0; pass < 64 && rc == 0; ++pass) {
         bool any = false;
         uint64_t want_bytes = 0;
-        for (int c = 0; c < POA_CLASSES && rc == 0; ++c) {
+        for (int c = 0; c < POA_GROUPS && rc == 0; ++c) {
             cls_plan &P = C[c];
             P.n_slots = 0;
             if (P.todo.empty()) continue;
@@ -2513,12 +2750,24 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 // the DP record is the arena: 7 nodes per base of the longest read (measured: ~4.5 at the end of a 200-read pack
                 // at 10 % error), not a fixed floor -- a third of the memory, and of the seconds the allocation takes
                 P.cell_cap = (uint64_t)(std::min<uint64_t>(std::max<uint64_t>(7ull * tl, 2048), tb + 1) + 64) * (tl + 32);
+                if (poa_group_class(c) >= 4) {
+                    // long reads: rows by depth, pack by pack (x 1.25 of the measured growth; a pack that still outgrows its slot is re-run)
+                    uint64_t nmax = 0, cmax = 0;
+                    for (uint32_t p : P.todo) {
+                        const uint32_t reads = std::min<uint32_t>(pack_first[p + 1] - pack_first[p], 200u);
+                        const uint64_t rows = std::min<uint64_t>(pbases[p] + 1, (uint64_t)(pmaxL[p] * (1.15 + 0.02 * reads) * 1.25) + 256);
+                        nmax = std::max(nmax, rows);
+                        cmax = std::max(cmax, (rows + 64) * (pmaxL[p] + 32));
+                    }
+                    P.node_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nmax, 2048), 1u << 20);
+                    P.cell_cap = cmax;
+                }
             }
             uint64_t per = plan_class(c, tb, tl);
             if (per > budget) {
                 // one slot does not fit the HBM that is left: cut the DP record to what does fit; a pack that
                 // still fails with that is beyond this device (skip-and-report, or an error for the MSA entry)
-                const uint64_t cell_b2 = c == POA_CLASSES - 1 ? 9 : 4;                   // twice the bytes per cell
+                const uint64_t cell_b2 = poa_group_class(c) == POA_CLASSES - 1 ? 9 : 4;       // twice the bytes per cell
                 const uint64_t fixed = per - (P.A.cell_cap * cell_b2 + 1) / 2;
                 if (P.clamped || fixed + (1ull << 20) >= budget) { rc = give_up(P); continue; }
                 P.cell_cap = (budget - fixed - (1ull << 20)) * 2 / cell_b2;
@@ -2533,14 +2782,36 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         }
         if (rc || !any) break;
         if (want_bytes > budget) {
-            // scale every class down proportionally (at least one slot each); classes whose single slots do
-            // not fit side by side wait for a later pass
-            const double f = (double)budget / (double)want_bytes;
+            // Memory decides how many packs of each group run at once.  A group lasts about (its work) / (its slots), so the pass
+            // is shortest when every group gets slots in proportion to its work: T = sum(work x bytes per slot) / budget,
+            // slots = work / T (config 5: the deep 8 - 20 kb packs are a few per cent of the packs and most of the work; a cut in
+            // proportion to the number of packs left them 4 slots and the pass to one class).  Work of a pack as below: bases x
+            // longest read / threads.  Groups capped by their pack count or by the device hand their share back (two rounds).
+            double work[POA_GROUPS] = {0};
+            uint32_t cap[POA_GROUPS] = {0};
+            bool fixed[POA_GROUPS] = {false};
+            for (int c = 0; c < POA_GROUPS; ++c) if (C[c].n_slots) {
+                cap[c] = C[c].n_slots;
+                for (uint32_t p : C[c].todo) work[c] += (double)pbases[p] * (double)pmaxL[p] / (64.0 * C[c].V->nw);
+            }
+            for (int round = 0; round < 3; ++round) {
+                double wm = 0, left = (double)budget;
+                for (int c = 0; c < POA_GROUPS; ++c) if (cap[c]) {
+                    if (fixed[c]) left -= (double)C[c].per_slot * C[c].n_slots;
+                    else wm += work[c] * (double)C[c].per_slot;
+                }
+                if (wm <= 0 || left <= 0) break;
+                const double T = wm / left;
+                for (int c = 0; c < POA_GROUPS; ++c) if (cap[c] && !fixed[c]) {
+                    const double want = work[c] / T;
+                    if (want >= cap[c]) { C[c].n_slots = cap[c]; fixed[c] = true; }
+                    else C[c].n_slots = std::max<uint32_t>(1, (uint32_t)want);
+                }
+            }
             want_bytes = 0;
-            for (int c = POA_CLASSES - 1; c >= 0; --c) if (C[c].n_slots) {
-                C[c].n_slots = std::max<uint32_t>(1, (uint32_t)(C[c].n_slots * f));
+            for (int c = POA_GROUPS - 1; c >= 0; --c) if (C[c].n_slots) {
                 if (want_bytes + C[c].per_slot * C[c].n_slots > budget) {
-                    C[c].n_slots = (uint32_t)((budget - want_bytes) / C[c].per_slot);     // may become 0: deferred
+                    C[c].n_slots = (uint32_t)((budget - want_bytes) / C[c].per_slot);     // may become 0: deferred to a later pass
                 }
                 want_bytes += C[c].per_slot * C[c].n_slots;
             }
@@ -2558,23 +2829,23 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             }
             ctx->poa_arena_bytes = take_bytes;
         }
-        hipError_t e = hipMemsetAsync(d_heads.p, 0, 32, st);
+        hipError_t e = hipMemsetAsync(d_heads.p, 0, 64, st);
         uint64_t aoff = 0;
         uint32_t qoff = 0;
-        for (int c = 0; c < POA_CLASSES && e == hipSuccess; ++c) {
+        for (int c = 0; c < POA_GROUPS && e == hipSuccess; ++c) {
             cls_plan &P = C[c];
             if (!P.n_slots) continue;
             e = hipMemcpyAsync(d_queue.p + qoff, P.todo.data(), P.todo.size() * 4, hipMemcpyHostToDevice, st);
             poa_args &A = P.A;
             A.seq = d_seq.p; A.off = d_off.p; A.pack_first = d_pf.p; A.queue = d_queue.p + qoff; A.n_queue = (uint32_t)P.todo.size();
             A.queue_head = d_heads.p + c; A.arena = ctx->poa_arena + aoff; A.slot_stride = P.per_slot;
-            A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p; A.prof = d_cnt.p + 32 + 8 * c;
+            A.out_col = d_col.p; A.out_width = d_width.p; A.status = d_status.p; A.counters = d_cnt.p; A.prof = d_cnt.p + 32 + 8 * poa_group_class(c);
             A.timeline = tl_path ? d_tl.p : nullptr;
             aoff += P.per_slot * P.n_slots;
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
                 fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, ring %u) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        c == POA_CLASSES - 1 ? "> 8192: segments of " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, pass, P.todo.size(), P.n_slots,
+                        poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, pass, P.todo.size(), P.n_slots,
                         P.per_slot / 1e6, P.bpc);
         }
         if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
@@ -2587,9 +2858,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             // streams, longest estimated run first onto the least loaded stream; a stream runs its classes in that order.
             // Estimate: a pack costs bases x longest read / threads of its workgroup; a class lasts as long as its longest
             // pack or its total over its slots.
-            double est[POA_CLASSES] = {0};
-            int order[POA_CLASSES], n_run = 0;
-            for (int c = 0; c < POA_CLASSES; ++c) {
+            double est[POA_GROUPS] = {0};
+            int order[POA_GROUPS], n_run = 0;
+            for (int c = 0; c < POA_GROUPS; ++c) {
                 cls_plan &P = C[c];
                 if (!P.n_slots) continue;
                 double tot = 0, longest = 0;
@@ -2598,12 +2869,12 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 order[n_run++] = c;
             }
             std::sort(order, order + n_run, [&](int a, int b) { return est[a] != est[b] ? est[a] > est[b] : a > b; });
-            // (the drivers -- rattle, bench.py, rattle_amd -- raise GPU_MAX_HW_QUEUES to 8 before the HIP runtime starts, so that
+            // (the drivers -- rattle, bench.py, rattle_amd -- raise GPU_MAX_HW_QUEUES to 12 before the HIP runtime starts, so that
             // every class gets a queue of its own; a host application that did not is dealt four streams)
             const int hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
-            const int n_streams = std::max(1, std::min(POA_CLASSES, getenv("RATTLE_POA_STREAMS") ? atoi(getenv("RATTLE_POA_STREAMS")) : hwq));
-            double load[POA_CLASSES] = {0};
-            bool used[POA_CLASSES] = {false};
+            const int n_streams = std::max(1, std::min(POA_GROUPS, getenv("RATTLE_POA_STREAMS") ? atoi(getenv("RATTLE_POA_STREAMS")) : hwq));
+            double load[16] = {0};
+            bool used[16] = {false};
             for (int i = 0; i < n_run && e == hipSuccess; ++i) {
                 const int c = order[i];
                 int sidx = 0;
@@ -2623,7 +2894,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error(std::string("poa_kernel: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
-        for (int c = 0; c < POA_CLASSES && rc == 0; ++c) {
+        for (int c = 0; c < POA_GROUPS && rc == 0; ++c) {
             cls_plan &P = C[c];
             if (!P.n_slots) continue;
             ++P.rounds;
@@ -2644,7 +2915,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     d_heads.release();
     if (rc == 0) {
         size_t left = 0;
-        for (int c = 0; c < POA_CLASSES; ++c) left += C[c].todo.size();
+        for (int c = 0; c < POA_GROUPS; ++c) left += C[c].todo.size();
         if (left) { set_error("poa: " + std::to_string(left) + " pack(s) exceed the device arena"); rc = RATTLE_ERR_HIP; }
     }
     if (rc == 0) {
@@ -2695,7 +2966,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f", names[i], 100.0 * (double)q[i] / (double)q[7]);
             fprintf(stderr, "  (total %.3f block-seconds)\n", (double)q[7] * 1e-8);
             if (jf) {
-                fprintf(jf, "{\"class\": %d, \"cols\": %u, \"n_packs\": %zu, \"block_seconds\": %.6f", c, c < POA_CLASSES - 1 ? k_class_cols[c] : 0u, by_class[c].size(), (double)q[7] * 1e-8);
+                fprintf(jf, "{\"class\": %d, \"cols\": %u, \"n_packs\": %zu, \"block_seconds\": %.6f", c, c < POA_CLASSES - 1 ? k_class_cols[c] : 0u, by_class[c].size() + (c >= 4 ? by_class[c + 4].size() : 0), (double)q[7] * 1e-8);
                 for (int i = 0; i < 7; ++i) fprintf(jf, ", \"%s_pct\": %.2f", names[i], 100.0 * (double)q[i] / (double)q[7]);
                 fprintf(jf, "}\n");
             }

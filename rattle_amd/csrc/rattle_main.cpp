@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -843,13 +844,23 @@ int mode_correct(int argc, char **argv) {
     // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's packs
     std::vector<std::vector<int>> label_counts(clusters.size(), std::vector<int>(labels.size(), 0));
     if (!labels.empty()) {
+        // only packs that produced a pack consensus count (as `reads=` does): packs the library skipped (budget rule: listed by
+        // their index among ALL packs of the cluster; POA #1 / #2 beyond the device: by their index among the QUEUED packs) do not
+        std::set<std::pair<int, uint32_t>> skip_all, skip_queued;
+        for (uint32_t i = 0; i < R->skipped.n; ++i) {
+            if (R->skipped.stage[i] == 0) skip_all.insert({R->skipped.cluster_id[i], R->skipped.pack[i]});
+            else if (R->skipped.stage[i] <= 2) skip_queued.insert({R->skipped.cluster_id[i], R->skipped.pack[i]});
+        }
         for (size_t c = 0; c < clusters.size(); ++c) {
             int n = (int)clusters[c].seqs.size();
             if (n == 0) continue;
             int n_files = (n - 1) / P.split + 1;
+            uint32_t queued = 0;
             for (int nf = 0; nf < n_files; ++nf) {
                 int sz = (n - 1 - nf) / n_files + 1;
                 if (sz <= P.min_reads) continue;
+                if (skip_all.count({(int)c, (uint32_t)nf})) continue;
+                if (skip_queued.count({(int)c, queued++})) continue;
                 for (int j = nf; j < n; j += n_files) {
                     const std::string h = T.head(clusters[c].seqs[j].seq_id);
                     size_t p = h.find_first_of(",");
@@ -1074,7 +1085,7 @@ int mode_polish(int argc, char **argv) {
 }  // namespace
 
 int main(int argc, char **argv) {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);      // before the HIP runtime starts: the POA column classes of a pass run concurrently, one hardware queue each (poa.hip)
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);      // before the HIP runtime starts: the POA column classes of a pass run concurrently, one hardware queue each (poa.hip)
     if (argc < 2) {
         std::cout << "Run with mode: ./rattle <cluster|cluster_summary|extract_clusters|correct|polish>" << std::endl;
         return EXIT_FAILURE;
