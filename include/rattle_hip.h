@@ -105,9 +105,12 @@ typedef struct {
     uint32_t *offsets;      /* [n_clusters+1] member range of each cluster */
     int32_t *member_id;     /* [n_members]    cseq_t::seq_id, in the order cluster_t::seqs holds them */
     uint8_t *member_rev;    /* [n_members]    cseq_t::rev */
-    /* exact work counters: [0] bit-vector pair tests, [1] full comparisons (pairs past the filter: their
-       common k-mers are counted), [2] k-mer matches, [3] seed rounds, [4] kernel launches, [5] pairs whose match count
-       could still reach t_s and went through the patience search (the others are rejected exactly on the count) */
+    /* work counters.  Exact and identical on every rank of a sharded job: [0] bit-vector pair tests, [1] full
+       comparisons (pairs past the filter: their common k-mers are counted).  [2] k-mer matches summed over the count pass:
+       exact when the pass counts per pair, an UPPER BOUND when the seed-major count kernel folds the hash (k > 10) or a
+       seed's repeat list overflows -- it depends on which form the driver picked and is for reporting only.  Local to the
+       calling rank: [3] seed rounds, [4] kernel launches, [5] pairs whose match count could still reach t_s and went
+       through the patience search (the others are rejected exactly on the count). */
     uint64_t counters[8];
     int32_t *gene_id;       /* [n_clusters] cseq_t::gene_id of the --iso flow (index of the gene cluster), else NULL */
 } rattle_cluster_set;
