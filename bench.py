@@ -160,6 +160,41 @@ def cpu_baseline_all_cores(cat, qcat, off, tid):
 PMC_FILE = os.path.join("profiles", "round3_pmc_poa.json")
 
 
+def toyset_line(ctx_cls, device):
+    """The reference's own data set (toyset/rna, 8306 real ONT reads, recovered into tests/golden/) through the HIP path:
+    `cluster --rna` + `correct`, timed beside the synthetic headline (the only published reference timings are for this set:
+    README.md:400-403, 16 s / 76 s on 1 thread, 759 reads/s for `correct` on 24 threads).  The clusters are checked against
+    the shipped clusters.out fixture."""
+    import gzip
+    from rattle_amd import hps
+    from rattle_amd.api import pack_reads
+    path = os.path.join(ROOT, "tests", "golden", "toyset_rna.fastq.gz")
+    if not os.path.exists(path):
+        return None
+    lines = gzip.open(path, "rb").read().split(b"\n")
+    seqs, quals = lines[1::4], lines[3::4]
+    seqs = [s for s in seqs if s]; quals = quals[:len(seqs)]
+    cat, off = pack_reads(seqs)
+    qcat = np.frombuffer(b"".join(quals), np.uint8).copy()
+    ctx = ctx_cls(device)
+    best = None
+    for _ in range(2):                                  # second pass: arena and kernels warm
+        t0 = time.time()
+        cl = ctx.cluster_unsorted_packed(cat, off, k=10, is_rna=True)
+        t1 = time.time()
+        res = ctx.correct_packed(cat, qcat, off, cl, vote_order=b"U-GTAC")
+        t2 = time.time()
+        best = (t1 - t0, t2 - t1, cl, res)
+    want = hps.decode(open(os.path.join(ROOT, "tests", "golden", "toyset_rna.clusters.out"), "rb").read(), fields=2)
+    same = [((m[0], m[1]), [(x[0], x[1]) for x in mem]) for m, mem in best[2].as_list()] == [((m[0], m[1]), [(x[0], x[1]) for x in mem]) for m, mem in want]
+    ctx.close()
+    n = len(seqs)
+    return {"reads": n, "cluster_s": best[0], "correct_s": best[1], "cluster_reads_per_s": n / best[0], "correct_reads_per_s": n / best[1],
+            "reads_per_s": n / (best[0] + best[1]), "clusters": int(len(best[2].main_id)), "clusters_equal_reference_fixture": bool(same),
+            "consensi": int(best[3][2]), "reference_published": "README.md:400-403: cluster 16 s, correct 76 s on 1 thread (516 / 109 reads/s); correct 759 reads/s on 24 threads",
+            "note": "small input: ~550 packs do not fill one MI355X (a pass lasts as long as its largest pack)"}
+
+
 def pmc_reference():
     """Counter-derived constants of kernel C, measured in separate rocprofv3 --pmc passes (tools/gpu_pmc_only.sh) and
     committed under profiles/ (the counters cannot be read from inside the benchmark process).  The file records a hash of
@@ -422,6 +457,10 @@ def main():
                 "note": "achieved = exact DP cells / kernel time (HIP events on the library's streams) x VALU wave-instructions per cell from the "
                         "committed SQ_INSTS_VALU pass of this tree; traffic = FETCH_SIZE(x2) + WRITE_SIZE per cell from the committed PMC passes x cells per launch"}
             if not a.no_cpu_baseline:
+                try:
+                    out["toyset"] = toyset_line(Context, local)
+                except Exception as e:       # the headline must not depend on the side measurement
+                    out["toyset"] = {"error": str(e)[:300]}
                 out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cat, qcat, off, tid)
         print(json.dumps(out))
