@@ -21,6 +21,8 @@ namespace rattle {
 // seed / candidate arrays): the greedy rounds of many independent clusterings (the gene clusters of `--iso`,
 // main.cpp:281-318) advance in lockstep and share the launch.  Rectangle j owns tiles [tile_base_j, tile_base_{j+1});
 // a workgroup finds its rectangle by bisection.  first_cand[] is in the index space of the candidate array.
+typedef const __attribute__((address_space(4))) unsigned long long *cbv_t;      // wave-uniform loads from it are scalar loads
+
 template <bool BOTH>
 __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restrict__ bvf, const uint64_t *__restrict__ bvr,
                                                         const uint32_t *__restrict__ pcf, const uint32_t *__restrict__ seed_ids,
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
                                                         const uint32_t *__restrict__ first_cand, const uint16_t *__restrict__ luts,
                                                         uint8_t *__restrict__ dense, uint32_t *__restrict__ list,
                                                         uint32_t list_cap, uint32_t *__restrict__ list_count) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_bv[BVF_TS][64];
+    __shared__ uint32_t s_seed[BVF_TS];                      // read ids of the tile's seeds (their vectors are read through the scalar cache)
     __shared__ uint32_t s_pc[BVF_TS];
     __shared__ uint32_t s_first[BVF_TS];
     __shared__ uint32_t s_minfirst;
@@ -64,10 +66,7 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
             for (uint32_t s = 0; s < ns; ++s) dense[(uint64_t)(s0 - J.s_base + s) * J.nc + (c - J.c_base)] = 0;
         return;
     }
-    for (uint32_t t = threadIdx.x; t < ns * 64; t += blockDim.x) {
-        uint32_t s = t >> 6, w = t & 63;
-        s_bv[s][w] = bvf[(uint64_t)seed_ids[s0 + s] * 64 + w];
-    }
+    if (threadIdx.x < ns) s_seed[threadIdx.x] = seed_ids[s0 + threadIdx.x];
     __syncthreads();
 
     const bool live = c < n_cands;
@@ -113,9 +112,12 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
             v[2 * q + 1] = (uint64_t)x.z | ((uint64_t)x.w << 32);
         }
         for (uint32_t s = 0; s < ns; ++s) {
+            // the seed's vector is the same for every lane: it comes through the scalar cache (s_load_dwordx16) and enters the
+            // v_and as an SGPR operand -- no LDS broadcast read per word, the VALU does nothing but and + popcount
+            const cbv_t sp = (cbv_t)(uintptr_t)(bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s]) * 64);
             uint32_t a = 0;
 #pragma unroll
-            for (int w = 0; w < 64; ++w) a += __popcll(v[w] & s_bv[s][w]);
+            for (int w = 0; w < 64; ++w) a += __popcll(v[w] & sp[w]);
             if (BOTH) s_cf[s][threadIdx.x] = (uint16_t)a;
             else emit(s, a, 0);
         }
@@ -130,9 +132,10 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
             v[2 * q + 1] = (uint64_t)x.z | ((uint64_t)x.w << 32);
         }
         for (uint32_t s = 0; s < ns; ++s) {
+            const cbv_t sp = (cbv_t)(uintptr_t)(bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s]) * 64);
             uint32_t a = 0;
 #pragma unroll
-            for (int w = 0; w < 64; ++w) a += __popcll(v[w] & s_bv[s][w]);
+            for (int w = 0; w < 64; ++w) a += __popcll(v[w] & sp[w]);
             emit(s, s_cf[s][threadIdx.x], a);
         }
     }

@@ -62,9 +62,18 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     const int strand = A.ps[pr];
     const uint32_t nA = (uint32_t)(A.koff[ri + 1] - A.koff[ri]);
     const uint32_t nB = (uint32_t)(A.koff[rj + 1] - A.koff[rj]);
-    const uint32_t *__restrict__ ah = A.uh + A.koff[ri];
-    const uint32_t *__restrict__ bh_g = A.kh[strand] + A.koff[rj];
-    const uint32_t *__restrict__ bp_g = A.kp[strand] + A.koff[rj];
+    // Which list is walked and which is searched.  The reference walks read i (the seed: in length-sorted order never the shorter
+    // of the two) and the matches come out in (pos1, pos2) order for free.  With mixed read lengths (config 5: a 50 kb seed
+    // against a 150 nt candidate, 330 M such comparisons at 5e5 reads) that is 800 search rounds for a handful of matches, so
+    // when i is much the longer the SHORT list is walked (j's sorted list, any order) against i's sorted list, and the few matches
+    // are sorted by (pos1, pos2) afterwards -- the same multiset (cross product on repeated hashes) in the same order.  The count
+    // pass needs no order at all and always walks the shorter list.
+    const bool swp = !A.gscratch && (COUNT ? nA > nB : nA > 4u * nB + 256u);
+    const uint32_t nW = swp ? nB : nA, nS = swp ? nA : nB;
+    const uint32_t *__restrict__ wh = swp ? A.kh[strand] + A.koff[rj] : A.uh + A.koff[ri];          // walked: hashes (swap: with positions wp)
+    const uint32_t *__restrict__ wp = swp ? A.kp[strand] + A.koff[rj] : nullptr;
+    const uint32_t *__restrict__ bh_g = swp ? A.kh[0] + A.koff[ri] : A.kh[strand] + A.koff[rj];     // searched: sorted hashes + positions
+    const uint32_t *__restrict__ bp_g = swp ? A.kp[0] + A.koff[ri] : A.kp[strand] + A.koff[rj];
 
     // LDS carve: [B bit-vector 128][queue pos 128][queue hash 128][B hashes bcap][pos1 mcap][pos2 mcap][m mcap+1 (+pad)][tv mcap+1 (+pad)][p mcap]
     uint32_t *s_bv = lds, *s_qp = lds + 128, *s_qh = lds + 256;
@@ -81,9 +90,9 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
         cap = A.mcap;
         pos1 = s_bh + A.bcap; pos2 = pos1 + cap; m = pos2 + cap; tv = m + cap + 2; pp = tv + cap + 2;
     }
-    const bool b_lds = nB <= A.bcap;
+    const bool b_lds = nS <= A.bcap;
     if (b_lds) {
-        for (uint32_t t = lane; t < nB; t += 64) s_bh[t] = bh_g[t];
+        for (uint32_t t = lane; t < nS; t += 64) s_bh[t] = bh_g[t];
         __syncthreads();
     }
     const uint32_t *bh = b_lds ? (const uint32_t *)s_bh : bh_g;
@@ -92,10 +101,10 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     // A k-mer of i can only occur in j if its leading 6-mer is in j's 4096-bit vector (k >= 6): the positions
     // that pass are queued (order kept) and searched 64 at a time, so unrelated reads -- most pairs -- cost
     // about a quarter of the searches.
-    const bool pre = A.k >= 6 && nB > 0;
+    const bool pre = A.k >= 6 && nS > 0;
     const int sh = 2 * (A.k - 6);
     if (pre) {
-        const uint32_t *bvj = (const uint32_t *)(A.bv[strand] + (uint64_t)rj * 64);
+        const uint32_t *bvj = swp ? (const uint32_t *)(A.bv[0] + (uint64_t)ri * 64) : (const uint32_t *)(A.bv[strand] + (uint64_t)rj * 64);
         for (uint32_t t = lane; t < 128; t += 64) s_bv[t] = bvj[t];
         __syncthreads();
     }
@@ -105,31 +114,34 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
         if ((uint32_t)lane < count) {
             p1 = s_qp[lane];
             const uint32_t h = s_qh[lane];
-            uint32_t a = 0, b = nB;                    // lower_bound
+            uint32_t a = 0, b = nS;                    // lower_bound
             while (a < b) {
                 uint32_t mid = (a + b) >> 1;
                 if (bh[mid] < h) a = mid + 1; else b = mid;
             }
             lo = a;
             uint32_t hi = lo;
-            while (hi < nB && bh[hi] == h) ++hi;
+            while (hi < nS && bh[hi] == h) ++hi;
             cnt = hi - lo;
         }
         uint32_t incl = wave_incl_scan(cnt, lane);
         uint32_t tot = __shfl(incl, 63, 64);
         if (!COUNT && total + tot <= cap) {
             uint32_t at = total + incl - cnt;
-            for (uint32_t t = 0; t < cnt; ++t) { pos1[at + t] = p1; pos2[at + t] = bp_g[lo + t]; }
+            if (swp) for (uint32_t t = 0; t < cnt; ++t) { pos1[at + t] = bp_g[lo + t]; pos2[at + t] = p1; }
+            else for (uint32_t t = 0; t < cnt; ++t) { pos1[at + t] = p1; pos2[at + t] = bp_g[lo + t]; }
         }
         total += tot;
     };
     uint32_t qn = 0;
-    for (uint32_t base = 0; base < nA && nB > 0; base += 64) {
-        const uint32_t p1 = base + lane;
+    for (uint32_t base = 0; base < nW && nS > 0; base += 64) {
+        const uint32_t w1 = base + lane;
+        uint32_t p1 = w1;                              // position of the walked k-mer in its read
         bool keep = false;
         uint32_t h = 0;
-        if (p1 < nA) {
-            h = ah[p1];
+        if (w1 < nW) {
+            h = wh[w1];
+            if (swp) p1 = wp[w1];
             const uint32_t six = h >> sh;
             keep = !pre || ((s_bv[six >> 5] >> (six & 31)) & 1u);
         }
@@ -162,6 +174,27 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
         return;
     }
     __syncthreads();
+    if (swp && total > 1) {
+        // matches of the swapped walk come in j's hash order: back into the reference's (pos1, pos2) order (kmer.cpp:65, a
+        // lexicographic sort of distinct pairs) with a bitonic network over the two LDS arrays
+        uint32_t P2 = 2;
+        while (P2 < total) P2 <<= 1;
+        for (uint32_t t = total + lane; t < P2; t += 64) { pos1[t] = 0xFFFFFFFFu; pos2[t] = 0xFFFFFFFFu; }
+        __syncthreads();
+        for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
+            for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                for (uint32_t t = lane; t < P2; t += 64) {
+                    const uint32_t u = t ^ j2;
+                    if (u > t) {
+                        const uint32_t a1 = pos1[t], a2 = pos2[t], b1 = pos1[u], b2 = pos2[u];
+                        const bool gt = a1 > b1 || (a1 == b1 && a2 > b2);
+                        if (gt == ((t & k2) == 0)) { pos1[t] = b1; pos2[t] = b2; pos1[u] = a1; pos2[u] = a2; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
 
     // ---- stage 2: similarity.cpp:10-31 patience LIS (strict on pos2, ceil-mid search) ---
     // The tails tv[1..l] are strictly increasing, so the reference's binary search returns

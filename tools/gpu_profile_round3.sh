@@ -11,6 +11,7 @@ timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 READS_PMC=300000 bash tools/gpu_pmc_only.sh ${TAG}_pmc > $O/pmc.log 2>&1; tail -2 $O/pmc.log | cut -c1-400
 timeout 900 python bench.py --iso --no-cpu-baseline > $O/bench_iso.json 2> $O/bench_iso.err
 timeout 1500 python tools/run_mixed.py $MIXED 20000 > $O/mixed.log 2> $O/mixed.err; tail -1 $O/mixed.log | cut -c1-900
+RATTLE_TIMING=1 timeout 900 bash tools/cli_e2e.sh 1000000 > $O/cli_e2e.txt 2>&1; tail -25 $O/cli_e2e.txt
 python -c "
 import json
 for f in ('bench_default','bench_under_rocprof','bench_iso'):
