@@ -46,7 +46,7 @@ __global__ void expand_pairs_kernel(const uint32_t *__restrict__ surv, uint32_t 
 
 // cluster.cpp:23-27 turned into an exact rejection on |common| (see run_local): pairs that can still reach t_s are compacted
 // for the full comparison; survivors / matches per rectangle and the algorithmic bytes are summed on the way.
-// stats: [0] pairs kept, [1] algorithmic bytes, then per rectangle (survivors, matches)
+// stats: [0] pairs kept, [1] algorithmic bytes, then per rectangle (survivors, matches, pairs kept)
 __global__ __launch_bounds__(256) void count_bound_kernel(const uint32_t *__restrict__ surv, const int32_t *__restrict__ common, uint32_t n,
                                                           const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj, const uint8_t *__restrict__ ps,
                                                           const uint32_t *__restrict__ len, uint32_t kk, double t_s,
@@ -76,12 +76,14 @@ __global__ __launch_bounds__(256) void count_bound_kernel(const uint32_t *__rest
     const int lane = threadIdx.x & 63;
     if (lane == 0) atomicAdd(&stats[1], bb);
     if (uniform) {
-        if (lane == 0 && one) { atomicAdd(&stats[2 + 2 * (size_t)rect0], one); atomicAdd(&stats[3 + 2 * (size_t)rect0], mm); }
+        if (lane == 0 && one) { atomicAdd(&stats[2 + 3 * (size_t)rect0], one); atomicAdd(&stats[3 + 3 * (size_t)rect0], mm); }
     } else if (live) {
-        atomicAdd(&stats[2 + 2 * (size_t)rect], 1ull); atomicAdd(&stats[3 + 2 * (size_t)rect], M);
+        atomicAdd(&stats[2 + 3 * (size_t)rect], 1ull); atomicAdd(&stats[3 + 3 * (size_t)rect], M);
     }
     const unsigned long long mask = __ballot(keep);
     if (mask) {
+        if (uniform) { if (lane == 0) atomicAdd(&stats[4 + 3 * (size_t)rect0], (unsigned long long)__popcll(mask)); }
+        else if (keep) atomicAdd(&stats[4 + 3 * (size_t)rect], 1ull);
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(&stats[0], (unsigned long long)__popcll(mask));
         base = __shfl(base, 0, 64);
@@ -89,6 +91,51 @@ __global__ __launch_bounds__(256) void count_bound_kernel(const uint32_t *__rest
             const uint64_t at = base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
             pi2[at] = ri; pj2[at] = rj; ps2[at] = ps[p];
             slot2[2 * at] = a; slot2[2 * at + 1] = c;
+        }
+    }
+}
+
+// cluster.cpp:23-36 / :47-61 on the device, in the reference's double arithmetic (an IEEE division and two comparisons, the same
+// expression the host evaluated until round 3): the accepted pairs are compacted as (seed slot << 1 | strand, candidate slot), so
+// the host sees the few accepted pairs instead of four integers and a double for every full comparison (10 M of them in the
+// --iso level at 1e6 reads).  Pairs whose match list did not fit LDS are listed for the oversize pass (out[0] = count, out[1] =
+// oversize pairs, out[2] = their largest match count) and judged by a second launch over that list.
+__global__ __launch_bounds__(256) void verdict_kernel(const int32_t *__restrict__ res, const double *__restrict__ var, uint32_t n,
+                                                      const uint32_t *__restrict__ remap, const uint32_t *__restrict__ pi,
+                                                      const uint32_t *__restrict__ pj, const uint32_t *__restrict__ slot2,
+                                                      const uint32_t *__restrict__ len, int use_hc, double t_s, double t_v,
+                                                      unsigned long long *__restrict__ out, uint32_t *__restrict__ hits,
+                                                      uint32_t *__restrict__ big) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool ok = false, over = false;
+    uint32_t q = 0, m_over = 0;
+    if (t < n) {
+        q = remap ? remap[t] : t;
+        const int32_t *r = res + 4 * (size_t)q;
+        if (r[0] == INT32_MIN) { over = true; m_over = (uint32_t)r[3]; }
+        else {
+            const uint32_t li = len[pi[q]], lj = len[pj[q]];
+            const double mn = (double)(li < lj ? li : lj);
+            const double score = use_hc ? (double)r[1] / mn : (double)r[0] / mn;
+            ok = score >= t_s && var[q] < t_v;
+        }
+    }
+    const unsigned long long mo = __ballot(over);
+    if (mo) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&out[1], (unsigned long long)__popcll(mo));
+        base = __shfl(base, 0, 64);
+        if (over) { big[base + (uint64_t)__popcll(mo & ((1ull << lane) - 1ull))] = q; atomicMax(&out[2], (unsigned long long)m_over); }
+    }
+    const unsigned long long mk = __ballot(ok);
+    if (mk) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&out[0], (unsigned long long)__popcll(mk));
+        base = __shfl(base, 0, 64);
+        if (ok) {
+            const uint64_t at = base + (uint64_t)__popcll(mk & ((1ull << lane) - 1ull));
+            hits[2 * at] = slot2[2 * (size_t)q]; hits[2 * at + 1] = slot2[2 * (size_t)q + 1];
         }
     }
 }
@@ -289,12 +336,12 @@ struct evaluator {
         RT_TRY(ctx->d_ps.reserve(nsurv));
         RT_TRY(ctx->d_res.reserve((size_t)nsurv * 4));
         RT_TRY(ctx->d_pi2.reserve(nsurv)); RT_TRY(ctx->d_pj2.reserve(nsurv)); RT_TRY(ctx->d_ps2.reserve(nsurv)); RT_TRY(ctx->d_slot2.reserve((size_t)nsurv * 2));
-        RT_TRY(ctx->d_bound_stats.reserve(2 + 2 * (size_t)nrect)); RT_TRY(ctx->h_bound_stats.reserve(2 + 2 * (size_t)nrect));
+        RT_TRY(ctx->d_bound_stats.reserve(2 + 3 * (size_t)nrect + 4)); RT_TRY(ctx->h_bound_stats.reserve(2 + 3 * (size_t)nrect + 4));
         if (many) {
             RT_TRY(ctx->d_seed_rect.reserve(ns));
             RT_HIP(hipMemcpyAsync(ctx->d_seed_rect.p, seed_req.data(), ns * 4, hipMemcpyHostToDevice, st));
         }
-        RT_HIP(hipMemsetAsync(ctx->d_bound_stats.p, 0, (2 + 2 * (size_t)nrect) * 8, st));
+        RT_HIP(hipMemsetAsync(ctx->d_bound_stats.p, 0, (2 + 3 * (size_t)nrect + 4) * 8, st));
         // Two count passes.  "seed": survivors sorted by seed, the seed's k-mer set as a bit set in LDS, its candidates' lists
         // streamed past it (pair_count.hip) -- pays where a seed has many surviving candidates (gene level: hundreds).
         // "search": one wavefront per pair, binary searches in the candidate's list (pair_score.hip) -- better for the short
@@ -315,56 +362,62 @@ struct evaluator {
                            ctx->d_pi.p, ctx->d_pj.p, ctx->d_ps.p, X.len.p, kk, t_s, many ? ctx->d_seed_rect.p : (const uint32_t *)nullptr,
                            ctx->d_bound_stats.p, ctx->d_pi2.p, ctx->d_pj2.p, ctx->d_ps2.p, ctx->d_slot2.p);
         launches += 3;
-        RT_HIP(hipMemcpyAsync(ctx->h_bound_stats.p, ctx->d_bound_stats.p, (2 + 2 * (size_t)nrect) * 8, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipMemcpyAsync(ctx->h_bound_stats.p, ctx->d_bound_stats.p, (2 + 3 * (size_t)nrect) * 8, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
         lap(2);
         const uint32_t n2 = (uint32_t)ctx->h_bound_stats.p[0];
         ctx->stats[K_SCORE].bytes += ctx->h_bound_stats.p[1];
         for (uint32_t j = 0; j < nrect; ++j) {
             uint64_t *cn = reqs[rect_req[j]]->counters;
-            cn[1] += ctx->h_bound_stats.p[2 + 2 * (size_t)j]; cn[2] += ctx->h_bound_stats.p[3 + 2 * (size_t)j];
+            cn[1] += ctx->h_bound_stats.p[2 + 3 * (size_t)j]; cn[2] += ctx->h_bound_stats.p[3 + 3 * (size_t)j];
+            cn[5] += ctx->h_bound_stats.p[4 + 3 * (size_t)j];                  // full comparisons (cluster.cpp:20 / :44 calls that ran)
         }
         lap(3);
         if (n2 == 0) return 0;
         // ---- pass 2: the reference's full comparison for the pairs that can still be accepted
-        RT_TRY(ctx->h_surv.reserve((size_t)n2 * 2));
-        RT_TRY(ctx->d_res.reserve((size_t)n2 * 4)); RT_TRY(ctx->h_res.reserve((size_t)n2 * 4));
-        RT_TRY(ctx->d_var.reserve(n2)); RT_TRY(ctx->h_var.reserve(n2));
-        RT_HIP(hipMemcpyAsync(ctx->h_surv.p, ctx->d_slot2.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+        RT_TRY(ctx->d_res.reserve((size_t)n2 * 4));
+        RT_TRY(ctx->d_var.reserve(n2));
         ctx->d_pi.swap(ctx->d_pi2); ctx->d_pj.swap(ctx->d_pj2); ctx->d_ps.swap(ctx->d_ps2);       // the launchers read d_pi / d_pj / d_ps
         struct unswap { rattle_ctx *c; ~unswap() { c->d_pi.swap(c->d_pi2); c->d_pj.swap(c->d_pj2); c->d_ps.swap(c->d_ps2); } } back{ctx};
         RT_TRY(launch_pair_score(ctx, n2));
         ++launches;
-        RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
-        RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+        // verdicts on the device: d_surv (free since the count pass compacted it into d_slot2) takes the accepted pairs, the tail
+        // of the statistics buffer the three counters, d_pi2 (= the swapped-out d_pi: n2 <= nsurv words) the oversize list
+        unsigned long long *vout = ctx->d_bound_stats.p + 2 + 3 * (size_t)nrect;
+        uint32_t *d_hits = ctx->d_surv.p, *d_big = ctx->d_pi2.p;
+        const int use_hc = P->use_hc ? 1 : 0;
+        hipLaunchKernelGGL(verdict_kernel, dim3((n2 + 255) / 256), dim3(256), 0, st, ctx->d_res.p, ctx->d_var.p, n2, (const uint32_t *)nullptr,
+                           ctx->d_pi.p, ctx->d_pj.p, ctx->d_slot2.p, X.len.p, use_hc, t_s, t_v, vout, d_hits, d_big);
+        ++launches;
+        unsigned long long *hv = ctx->h_bound_stats.p + 2 + 3 * (size_t)nrect;
+        RT_HIP(hipMemcpyAsync(hv, vout, 24, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
-        // pairs whose match list did not fit LDS: rerun through the global-scratch variant
-        std::vector<uint32_t> big;
-        uint32_t big_m = 0;
-        for (uint32_t q = 0; q < n2; ++q)
-            if (ctx->h_res.p[4 * (size_t)q] == INT32_MIN) {
-                big.push_back(q);
-                big_m = std::max(big_m, (uint32_t)ctx->h_res.p[4 * (size_t)q + 3]);
-            }
-        if (!big.empty()) {
+        if (hv[1]) {
+            // pairs whose match list did not fit LDS: rerun through the global-scratch variant, then judge them
+            const uint32_t nbig = (uint32_t)hv[1], big_m = (uint32_t)hv[2];
+            std::vector<uint32_t> big(nbig);
+            RT_HIP(hipMemcpyAsync(big.data(), d_big, (size_t)nbig * 4, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
             RT_TRY(launch_pair_score_oversize(ctx, big, big_m));
             ++launches;
-            RT_HIP(hipMemcpyAsync(ctx->h_res.p, ctx->d_res.p, (size_t)n2 * 16, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipMemcpyAsync(ctx->h_var.p, ctx->d_var.p, (size_t)n2 * 8, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipMemsetAsync(vout + 1, 0, 16, st));
+            hipLaunchKernelGGL(verdict_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, ctx->d_res.p, ctx->d_var.p, nbig, (const uint32_t *)d_big,
+                               ctx->d_pi.p, ctx->d_pj.p, ctx->d_slot2.p, X.len.p, use_hc, t_s, t_v, vout, d_hits, d_big);
+            ++launches;
+            RT_HIP(hipMemcpyAsync(hv, vout, 24, hipMemcpyDeviceToHost, st));
             RT_HIP(hipStreamSynchronize(st));
+            if (hv[1]) { set_error("pair_score: a pair is still oversize after the oversize pass"); return RATTLE_ERR_HIP; }
         }
-        // cluster.cpp:23-36 / :47-61 on the host in the reference's double arithmetic; verdicts back to their rectangle
-        for (uint32_t q = 0; q < n2; ++q) {
+        const uint32_t nhit = (uint32_t)hv[0];
+        RT_TRY(ctx->h_surv.reserve((size_t)nhit * 2 + 2));
+        if (nhit) RT_HIP(hipMemcpyAsync(ctx->h_surv.p, d_hits, (size_t)nhit * 8, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        // accepted pairs back to their rectangle
+        for (uint32_t q = 0; q < nhit; ++q) {
             const uint32_t a = ctx->h_surv.p[2 * (size_t)q], c = ctx->h_surv.p[2 * (size_t)q + 1];
-            const int32_t *res = ctx->h_res.p + 4 * (size_t)q;
-            reqs[rect_req[many ? seed_req[a >> 1] : 0]]->counters[5] += 1;
-            const uint32_t li = X.h_len[h_seed[a >> 1]], lj = X.h_len[h_cand[c]];
-            const double mn = (double)std::min<size_t>(li, lj);
-            const double score = P->use_hc ? double(res[1]) / mn : double(res[0]) / mn;
-            if (score >= t_s && ctx->h_var.p[q] < t_v) {
-                const bvf_rect &J = rects[many ? seed_req[a >> 1] : 0];
-                reqs[rect_req[many ? seed_req[a >> 1] : 0]]->hits.push_back(hit_t{(a >> 1) - J.s_base, c - J.c_base, (uint8_t)(a & 1u)});
-            }
+            const uint32_t rj = many ? seed_req[a >> 1] : 0;
+            const bvf_rect &J = rects[rj];
+            reqs[rect_req[rj]]->hits.push_back(hit_t{(a >> 1) - J.s_base, c - J.c_base, (uint8_t)(a & 1u)});
         }
         for (uint32_t j = 0; j < nrect; ++j) if (reqs[rect_req[j]]->triangular) sort_hits(reqs[rect_req[j]]->hits);      // level 2 takes them in any order
         lap(4);
