@@ -48,6 +48,36 @@ __device__ __forceinline__ uint32_t seed_dot(const uint64_t (&v)[64], const uint
     return a;
 }
 
+// A lane owns one candidate and keeps its 512-byte vector in 128 registers.  Read straight from memory that is 32 loads of 16
+// bytes per lane at a lane stride of 512 bytes: every instruction touches 64 different cache lines, every line is touched by 8
+// instructions, and with twelve wavefronts per CU doing the same the 256-line vector cache keeps nothing -- the kernel moved
+// several times its data through L2 and ran at a third of its and + popcount bound whatever the scalar side did (round 3,
+// measured).  Now the wavefront reads whole lines (8 lanes x 16 bytes = the 128-byte quarter of ONE candidate's vector, 8
+// candidates per instruction) and the quarters reach their lanes through LDS: row = candidate, 9 x 16 bytes per row so that the
+// lanes' 16-byte reads of one column spread over all banks.
+__device__ __forceinline__ void load_candidate_vectors(uint64_t (&v)[64], const uint64_t *__restrict__ bv, const uint32_t cid, uint4 (*tr)[9]) {
+    const int lane = threadIdx.x & 63, sub = lane & 7, row0 = lane >> 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint4 x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t rid = (uint32_t)__shfl((int)cid, i * 8 + row0, 64);           // the candidate of lane i * 8 + row0
+            x[i] = ((const uint4 *)(bv + (uint64_t)rid * 64))[q * 8 + sub];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tr[i * 8 + row0][sub] = x[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              // one wavefront: its LDS operations complete in order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint4 y = tr[lane][j];
+            v[(q * 8 + j) * 2] = (uint64_t)y.x | ((uint64_t)y.y << 32);
+            v[(q * 8 + j) * 2 + 1] = (uint64_t)y.z | ((uint64_t)y.w << 32);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 template <bool BOTH>
 __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restrict__ bvf, const uint64_t *__restrict__ bvr,
                                                         const uint32_t *__restrict__ pcf, const uint32_t *__restrict__ seed_ids,
@@ -60,6 +90,7 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
     __shared__ uint32_t s_first[BVF_TS];
     __shared__ uint32_t s_minfirst;
     __shared__ uint16_t s_cf[BOTH ? BVF_TS : 1][BVF_TC];     // forward counts parked while the reverse vector is in registers
+    __shared__ uint4 s_tr[BVF_TC / 64][64][9];               // per wavefront: 64 candidates x 128 bytes (+16 of padding) on their way to the lanes
 
     uint32_t lo = 0, hi = n_rects;
     while (hi - lo > 1) {
@@ -98,64 +129,75 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
     const uint32_t cid = live ? cand_ids[c] : 0;
     const uint32_t cpc = live ? pcf[cid] : 0;
 
-    // one (seed, candidate) verdict per lane; res bit0 = forward passes, bit1 = reverse passes.  Called by EVERY lane of the
-    // wavefront together (lanes without a candidate pass live = false): survivors are appended with ONE atomic per wavefront
-    // and strand -- 41 M survivors at 1e6 reads, 25 M of them in the threshold-0 pass where every pair survives, used to be
-    // 41 M atomics on one counter.
-    auto emit = [&](uint32_t s, uint32_t common_f, uint32_t common_r) {
+    // one (seed, candidate) verdict per lane; res bit0 = forward passes, bit1 = reverse passes.  Survivors are NOT appended
+    // here: an append is an atomic with a return value, a memory round trip of a microsecond or two that the wavefront sat out
+    // after every second seed (1.2 % of the pairs survive the gene-level pass, so about half of the 64-pair groups have one) --
+    // as long as the and + popcount work of two seeds.  The lanes collect their verdicts in two 32-bit masks (bit = seed of
+    // the tile) and the tile's survivors are appended once per wavefront below.  The threshold of the NEXT seed is fetched
+    // while this seed's vector is consumed.
+    uint32_t surv_f = 0, surv_r = 0;
+    auto need_of = [&](uint32_t s) -> uint32_t { return live && s < ns ? (uint32_t)lut[max(s_pc[s], cpc)] : 0u; };      // cluster.cpp:16 forward counts only
+    auto emit = [&](uint32_t s, uint32_t common_f, uint32_t common_r, uint32_t need) {
         uint32_t res = 0;
         if (live && c >= s_first[s]) {
-            uint32_t mmax = max(s_pc[s], cpc);                 // cluster.cpp:16 forward counts only
-            uint32_t need = lut[mmax];
             if (fwd_bypass || common_f >= need) res |= 1u;     // cluster.cpp:19
             if (BOTH && common_r >= need) res |= 2u;           // cluster.cpp:43
         }
         if (dense && live) dense[(uint64_t)(s0 - J.s_base + s) * J.nc + (c - J.c_base)] = (uint8_t)res;
-        if (list) {
-#pragma unroll
-            for (uint32_t strand = 0; strand < (BOTH ? 2u : 1u); ++strand) {
-                const bool mine = (res >> strand) & 1u;
-                const unsigned long long m = __ballot(mine);
-                if (m == 0) continue;
-                const uint32_t lane = threadIdx.x & 63u;
-                uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(list_count, (uint32_t)__popcll(m));
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
-                const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (mine && at < list_cap) { list[2 * (uint64_t)at] = ((s0 + s) << 1) | strand; list[2 * (uint64_t)at + 1] = c; }
-            }
-        }
+        surv_f |= (res & 1u) << s;
+        surv_r |= (res >> 1) << s;
     };
 
     {
         uint64_t v[64];
-        const uint4 *src = (const uint4 *)(bvf + (uint64_t)cid * 64);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            uint4 x = live ? src[q] : make_uint4(0, 0, 0, 0);
-            v[2 * q] = (uint64_t)x.x | ((uint64_t)x.y << 32);
-            v[2 * q + 1] = (uint64_t)x.z | ((uint64_t)x.w << 32);
-        }
+        load_candidate_vectors(v, bvf, cid, s_tr[threadIdx.x >> 6]);
+        uint32_t need_nx = BOTH ? 0u : need_of(0);
         for (uint32_t s = 0; s < ns; ++s) {
             // the seed's vector is the same for every lane: it comes through the scalar cache and enters the v_and as an SGPR
             // operand -- no LDS broadcast read per word, the VALU does nothing but and + popcount
+            const uint32_t need = need_nx;
+            if (!BOTH) need_nx = need_of(s + 1);
             const uint32_t a = seed_dot(v, bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s]) * 64);
             if (BOTH) s_cf[s][threadIdx.x] = (uint16_t)a;
-            else emit(s, a, 0);
+            else emit(s, a, 0, need);
         }
     }
     if (BOTH) {
         uint64_t v[64];
-        const uint4 *src = (const uint4 *)(bvr + (uint64_t)cid * 64);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            uint4 x = live ? src[q] : make_uint4(0, 0, 0, 0);
-            v[2 * q] = (uint64_t)x.x | ((uint64_t)x.y << 32);
-            v[2 * q + 1] = (uint64_t)x.z | ((uint64_t)x.w << 32);
-        }
+        load_candidate_vectors(v, bvr, cid, s_tr[threadIdx.x >> 6]);
+        uint32_t need_nx = need_of(0);
         for (uint32_t s = 0; s < ns; ++s) {
+            const uint32_t need = need_nx;
+            need_nx = need_of(s + 1);
             const uint32_t a = seed_dot(v, bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s]) * 64);
-            emit(s, s_cf[s][threadIdx.x], a);
+            emit(s, s_cf[s][threadIdx.x], a, need);
+        }
+    }
+    if (list) {
+        // the tile's survivors of this wavefront: one atomic for all of them, a lane's entries behind those of the lanes below it
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t cnt = (uint32_t)__popc(surv_f) + (uint32_t)__popc(surv_r);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= (uint32_t)d) incl += o;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(list_count, total);
+            uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - cnt;
+#pragma unroll
+            for (uint32_t strand = 0; strand < (BOTH ? 2u : 1u); ++strand) {
+                uint32_t mask = strand ? surv_r : surv_f;
+                while (mask) {
+                    const uint32_t sd = (uint32_t)__builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    if (at < list_cap) { list[2 * (uint64_t)at] = ((s0 + sd) << 1) | strand; list[2 * (uint64_t)at + 1] = c; }
+                    ++at;
+                }
+            }
         }
     }
 }

@@ -26,6 +26,12 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters) {
         if (OP == 9) { REP8(asm volatile(OPS8("v_lshl_or_b32", ", 4, %8") : REGS : "v"(b));) }
         if (OP == 10) { REP8(asm volatile(OPS8("v_cndmask_b32", ", %8, vcc") : REGS : "v"(b) : "vcc");) }
         if (OP == 11) { REP8(asm volatile(OPS8("v_pk_sub_i16", ", %8") : REGS : "v"(b));) }
+        if (OP == 12) { REP8(asm volatile(OPS8("v_bcnt_u32_b32", ", %8") : REGS : "v"(b));) }
+        if (OP == 13) { REP8(asm volatile(OPS8("v_and_b32", ", %8") : REGS : "s"(i));) }
+        if (OP == 14) { REP8(asm volatile(OPS8("v_add3_u32", ", %8, %9") : REGS : "v"(b), "v"(c));) }
+        if (OP == 15) { REP8(asm volatile(OPS8("v_xor_b32", ", %8") : REGS : "v"(b));) }
+        if (OP == 16) { REP8(asm volatile(OPS8("v_add_u32", ", %8") : REGS : "v"(b));) }
+        if (OP == 17) { REP8(asm volatile("v_and_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %0, %1\n v_and_b32 %2, %8, %2\n v_bcnt_u32_b32 %3, %2, %3\n v_and_b32 %4, %8, %4\n v_bcnt_u32_b32 %5, %4, %5\n v_and_b32 %6, %8, %6\n v_bcnt_u32_b32 %7, %6, %7" : REGS : "s"(i));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
@@ -57,5 +63,7 @@ int main(int argc, char **argv) {
     run<0>("v_pk_max_i16", d, blocks); run<1>("v_pk_add_u16", d, blocks); run<11>("v_pk_sub_i16", d, blocks); run<8>("v_pk_min_i16 imm", d, blocks);
     run<2>("v_max_i32", d, blocks); run<7>("v_max3_i32", d, blocks); run<3>("v_alignbit_b32", d, blocks); run<6>("v_perm_b32", d, blocks);
     run<4>("v_mov_b32_dpp", d, blocks); run<5>("v_and_b32", d, blocks); run<9>("v_lshl_or_b32", d, blocks); run<10>("v_cndmask_b32", d, blocks);
+    run<12>("v_bcnt_u32_b32", d, blocks); run<13>("v_and_b32 sgpr", d, blocks); run<14>("v_add3_u32", d, blocks); run<15>("v_xor_b32", d, blocks);
+    run<16>("v_add_u32", d, blocks); run<17>("and(sgpr)+bcnt mix", d, blocks);
     return 0;
 }
