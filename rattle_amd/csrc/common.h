@@ -172,6 +172,16 @@ struct exchange {
     void *comm = nullptr;               // ncclComm_t
     void *rccl = nullptr;               // dlopen handle of librccl.so
     uint64_t calls = 0, bytes = 0;      // statistics
+    // staging of the RCCL all-gather-v, kept between calls: the sharded cluster driver exchanges a few KB per greedy round
+    // (119 rounds at 1e6 reads) and three hipMalloc / hipFree pairs per exchange were three device-wide synchronisations each
+    dbuf<uint64_t> d_sz;
+    dbuf<uint8_t> d_send, d_recv;
+    hbuf<uint64_t> h_sz;
+    hbuf<uint8_t> h_send, h_recv;       // pinned: the copies are asynchronous and run at link speed
+    void reset() {
+        rank = 0; nranks = 1; fn = nullptr; user = nullptr; comm = nullptr; calls = 0; bytes = 0;      // the loader's handle (rccl) stays
+        d_sz.release(); d_send.release(); d_recv.release(); h_sz.release(); h_send.release(); h_recv.release();
+    }
 };
 
 // `correct` work list: the packs of correct.cpp:328-370 from ids and lengths only, plus the static

@@ -103,23 +103,25 @@ int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vect
     const uint64_t my_bytes = mine.size();
     if (X.comm) {
         hipStream_t st = ctx->stream;
-        dbuf<uint64_t> d_sz;
-        RT_TRY(d_sz.reserve((size_t)X.nranks + 1));
-        RT_HIP(hipMemcpyAsync(d_sz.p + X.nranks, &my_bytes, 8, hipMemcpyHostToDevice, st));
-        RT_NCCL(rccl().AllGather(d_sz.p + X.nranks, d_sz.p, 1, NCCL_UINT64, (nccl_comm)X.comm, st));
-        RT_HIP(hipMemcpyAsync(bytes.data(), d_sz.p, (size_t)X.nranks * 8, hipMemcpyDeviceToHost, st));
+        RT_TRY(X.d_sz.reserve((size_t)X.nranks + 1)); RT_TRY(X.h_sz.reserve((size_t)X.nranks + 1));
+        X.h_sz.p[X.nranks] = my_bytes;
+        RT_HIP(hipMemcpyAsync(X.d_sz.p + X.nranks, X.h_sz.p + X.nranks, 8, hipMemcpyHostToDevice, st));
+        RT_NCCL(rccl().AllGather(X.d_sz.p + X.nranks, X.d_sz.p, 1, NCCL_UINT64, (nccl_comm)X.comm, st));
+        RT_HIP(hipMemcpyAsync(X.h_sz.p, X.d_sz.p, (size_t)X.nranks * 8, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
         uint64_t total = 0;
-        for (uint64_t b : bytes) total += b;
-        dbuf<uint8_t> d_send, d_recv;
-        RT_TRY(d_send.reserve(my_bytes + 16)); RT_TRY(d_recv.reserve(total + 16));
-        if (my_bytes) RT_HIP(hipMemcpyAsync(d_send.p, mine.data(), my_bytes, hipMemcpyHostToDevice, st));
-        RT_TRY(rccl_allgatherv(ctx, d_send.p, d_recv.p, bytes));
-        std::vector<uint8_t> flat(total);
-        if (total) RT_HIP(hipMemcpyAsync(flat.data(), d_recv.p, total, hipMemcpyDeviceToHost, st));
+        for (int r = 0; r < X.nranks; ++r) { bytes[r] = X.h_sz.p[r]; total += bytes[r]; }
+        RT_TRY(X.d_send.reserve(my_bytes + 16)); RT_TRY(X.d_recv.reserve(total + 16));
+        RT_TRY(X.h_send.reserve(my_bytes + 16)); RT_TRY(X.h_recv.reserve(total + 16));
+        if (my_bytes) {
+            memcpy(X.h_send.p, mine.data(), my_bytes);
+            RT_HIP(hipMemcpyAsync(X.d_send.p, X.h_send.p, my_bytes, hipMemcpyHostToDevice, st));
+        }
+        RT_TRY(rccl_allgatherv(ctx, X.d_send.p, X.d_recv.p, bytes));
+        if (total) RT_HIP(hipMemcpyAsync(X.h_recv.p, X.d_recv.p, total, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
         uint64_t at = 0;
-        for (int r = 0; r < X.nranks; ++r) { all[r].assign(flat.begin() + at, flat.begin() + at + bytes[r]); at += bytes[r]; }
+        for (int r = 0; r < X.nranks; ++r) { all[r].assign(X.h_recv.p + at, X.h_recv.p + at + bytes[r]); at += bytes[r]; }
         X.bytes += total;
         return 0;
     }
@@ -158,12 +160,13 @@ static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int r
     hipStream_t st = ctx->stream;
     std::vector<uint64_t> bytes((size_t)X.nranks, 0);
     const uint64_t my_bytes = mine.size();
-    dbuf<uint64_t> d_sz;
-    RT_TRY(d_sz.reserve((size_t)X.nranks + 1));
-    RT_HIP(hipMemcpyAsync(d_sz.p + X.nranks, &my_bytes, 8, hipMemcpyHostToDevice, st));
-    RT_NCCL(rccl().AllGather(d_sz.p + X.nranks, d_sz.p, 1, NCCL_UINT64, (nccl_comm)X.comm, st));
-    RT_HIP(hipMemcpyAsync(bytes.data(), d_sz.p, (size_t)X.nranks * 8, hipMemcpyDeviceToHost, st));
+    RT_TRY(X.d_sz.reserve((size_t)X.nranks + 1)); RT_TRY(X.h_sz.reserve((size_t)X.nranks + 1));
+    X.h_sz.p[X.nranks] = my_bytes;
+    RT_HIP(hipMemcpyAsync(X.d_sz.p + X.nranks, X.h_sz.p + X.nranks, 8, hipMemcpyHostToDevice, st));
+    RT_NCCL(rccl().AllGather(X.d_sz.p + X.nranks, X.d_sz.p, 1, NCCL_UINT64, (nccl_comm)X.comm, st));
+    RT_HIP(hipMemcpyAsync(X.h_sz.p, X.d_sz.p, (size_t)X.nranks * 8, hipMemcpyDeviceToHost, st));
     RT_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < X.nranks; ++r) bytes[r] = X.h_sz.p[r];
     rccl_api &A = rccl();
     if (X.rank != root) {
         dbuf<uint8_t> d_send;
@@ -422,7 +425,7 @@ int rattle_hip_comm_destroy(rattle_ctx *c) {
         (void)hipStreamSynchronize(c->stream);
         (void)rccl().CommDestroy((nccl_comm)c->xchg.comm);
     }
-    c->xchg = exchange();
+    c->xchg.reset();
     return 0;
 }
 

@@ -1,5 +1,5 @@
 O=gpurun_out/s3b; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_cluster.py tests/test_gpu_edges.py -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+timeout 900 python -m pytest tests/test_gpu_cluster.py tests/test_gpu_edges.py tests/test_gpu_dist.py -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
 RATTLE_TIMING=1 timeout 900 python bench.py --iso --no-cpu-baseline > $O/iso.json 2> $O/iso.err
 grep -E "job\(s\)|host steps|greedy|iso|cluster" $O/iso.err | tail -14
 python -c "
