@@ -2,15 +2,14 @@
 // /root/reference/kmer.cpp:6-42 (hash: kmer.hpp:25-40; reverse strand: utils.cpp:15-24).
 //
 // One 256-thread workgroup per (read, strand).  The read is staged in LDS as 2-bit codes,
-// every thread hashes its positions, the (hash<<32|pos) keys are bitonic-sorted in LDS and
+// every thread hashes its positions, the (hash, pos) pairs are sorted in LDS (LSD radix sort, kmer_extract_lsd_kernel; the
+// bitonic kernel of round 1 is kept for lists beyond 8192 k-mers and as RATTLE_KMER_SORT=bitonic for the parity test) and
 // written back as two coalesced SoA streams (hash, pos).  The 4096-bit 6-mer bit-vector is
 // built with LDS atomics and written as 64 u64 words.
 //
 // HBM traffic per read (algorithmic): L bytes read; per strand (L-k)*8 B list + 512 B
 // bit-vector written, + (L-k)*4 B position-ordered hashes for the forward strand.
 #include <cstring>
-
-#include <rocprim/block/block_radix_sort.hpp>
 
 #include "common.h"
 
@@ -139,36 +138,50 @@ __global__ __launch_bounds__(256) void kmer_extract_kernel(const uint8_t *__rest
     }
 }
 
-// The same index with the list sorted by a block-wide LSD radix sort on the 2k hash bits (rocPRIM's block_radix_sort
-// primitive, keys and positions in registers, digits ranked through LDS): stable, so equal hashes keep their positions
-// ascending = the reference's (hash, pos) order (kmer.cpp:38-41 sorts pairs), and 2k/4 digit passes replace the
-// log^2(P)/2 compare-exchange stages of the bitonic network (55 barriers for a 1 kb read).  Thread t holds the
-// IPT consecutive positions t*IPT .. t*IPT+IPT-1; slots beyond the list carry the largest key and stay behind every real
-// k-mer (stability again).
-template <int IPT>
-__global__ __launch_bounds__(256) void kmer_extract_radix_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
-                                                                 const uint64_t *__restrict__ koff, const uint32_t *__restrict__ items,
-                                                                 int k, uint32_t Lmax, uint32_t *__restrict__ uh,
-                                                                 uint32_t *__restrict__ kh0, uint32_t *__restrict__ kp0,
-                                                                 uint32_t *__restrict__ kh1, uint32_t *__restrict__ kp1,
-                                                                 uint64_t *__restrict__ bv0, uint64_t *__restrict__ bv1,
-                                                                 uint32_t *__restrict__ pc0, uint32_t *__restrict__ pc1,
-                                                                 uint32_t *__restrict__ bad_flag) {
-    using sort_t = rocprim::block_radix_sort<uint32_t, 256, IPT, uint32_t>;
-    __shared__ typename sort_t::storage_type sort_storage;
+// The same index with the list sorted by an LSD radix sort on the 2k hash bits, eight bits per pass, entirely in LDS (round 3:
+// hand-written; rounds 1-2 used a bitonic network, then rocPRIM's block_radix_sort).  Keys (hash) and values (position, 16 bits:
+// lists of up to 8192 k-mers) ping-pong between two LDS arrays.  A pass: (1) every wavefront histograms the digits of ITS
+// contiguous quarter of the list with LDS atomics; (2) thread d scans digit d over (digit, wavefront) -- the start of each
+// wavefront's run of each digit; (3) every wavefront walks its quarter in order, 64 keys at a time: the lanes that hold the
+// same digit find each other with eight ballots, a lane's slot is its digit's cursor plus the number of such lanes below it,
+// and the last of them moves the cursor.  Order is kept at every step, so the sort is stable and equal hashes stay in position
+// order = the reference's std::sort on (hash, pos) pairs (kmer.cpp:38-41).  ceil(2k / 8) passes (3 for k = 10, 11) of 2
+// barriers + a scan replace the 55 barriers of the bitonic network for a 1 kb read.
+__device__ __forceinline__ uint32_t kx_wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void kmer_extract_lsd_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                               const uint64_t *__restrict__ koff, const uint32_t *__restrict__ items,
+                                                               int k, uint32_t P, uint32_t Lmax, uint32_t *__restrict__ uh,
+                                                               uint32_t *__restrict__ kh0, uint32_t *__restrict__ kp0,
+                                                               uint32_t *__restrict__ kh1, uint32_t *__restrict__ kp1,
+                                                               uint64_t *__restrict__ bv0, uint64_t *__restrict__ bv1,
+                                                               uint32_t *__restrict__ pc0, uint32_t *__restrict__ pc1,
+                                                               uint32_t *__restrict__ bad_flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t r = items[blockIdx.x];
     const int strand = blockIdx.y;
     const uint64_t o = off[r];
     const uint32_t L = (uint32_t)(off[r + 1] - o);
     const uint32_t nk = L > (uint32_t)k ? L - k : 0;
     const uint32_t nb = L > 6 ? L - 6 : 0;
-    uint32_t *bits = (uint32_t *)smem;               // [bitset 128 u32][codes Lmax bytes]
+    // LDS carve: [bitset 128 u32][codes Lmax bytes, padded to 16][digit cursors 4 x 256][wave totals 16][keys P][keys P][positions P u16][positions P u16]
+    uint32_t *bits = (uint32_t *)smem;
     uint8_t *code = smem + 512;
-    (void)Lmax;
-    for (uint32_t t = threadIdx.x; t < 128; t += 256) bits[t] = 0;
+    uint32_t *hist = (uint32_t *)(smem + 512 + ((Lmax + 15u) & ~15u));
+    uint32_t *wsum = hist + 1024;
+    uint32_t *ka = wsum + 16, *kb = ka + P;
+    uint16_t *va = (uint16_t *)(kb + P), *vb = va + P;
+    for (uint32_t t = tid; t < 128; t += 256) bits[t] = 0;
     bool bad = false;
-    for (uint32_t p = threadIdx.x; p < L; p += 256) {
+    for (uint32_t p = tid; p < L; p += 256) {
         uint32_t c = strand == 0 ? base_code(seq[o + p]) : base_code(seq[o + (L - 1 - p)]);
         if (c > 3) { bad = true; c = 0; }
         code[p] = (uint8_t)(strand == 0 ? c : (c ^ 2u));
@@ -176,51 +189,72 @@ __global__ __launch_bounds__(256) void kmer_extract_radix_kernel(const uint8_t *
     if (bad) atomicOr(bad_flag, 1u);
     __syncthreads();
     const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
-    uint32_t key[IPT], val[IPT];
     const uint64_t ko = koff[r];
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const uint32_t p = threadIdx.x * IPT + i;
-        uint32_t h = 0xFFFFFFFFu;
-        if (p < nk) {
-            h = 0;
-            for (int j = 0; j < k; ++j) h = (h << 2) | code[p + j];
-            h &= kmask;
-            if (strand == 0) uh[ko + p] = h;
-        }
-        key[i] = h; val[i] = p;
+    for (uint32_t p = tid; p < nk; p += 256) {
+        uint32_t h = 0;
+        for (int j = 0; j < k; ++j) h = (h << 2) | code[p + j];
+        h &= kmask;
+        if (strand == 0) uh[ko + p] = h;
+        ka[p] = h; va[p] = (uint16_t)p;
     }
-    for (uint32_t p = threadIdx.x; p < nb; p += 256) {       // kmer.cpp:28-36, always 6-mers
+    for (uint32_t p = tid; p < nb; p += 256) {                // kmer.cpp:28-36, always 6-mers
         uint32_t h = 0;
         for (int j = 0; j < 6; ++j) h = (h << 2) | code[p + j];
         atomicOr(&bits[h >> 5], 1u << (h & 31));
     }
-    sort_t().sort(key, val, sort_storage, 0, (unsigned)(2 * k));
+    const uint32_t seg = (nk + 255u) / 256u * 64u;             // a wavefront's quarter, a multiple of 64
+    const uint32_t s0 = min(nk, wave * seg), s1 = min(nk, s0 + seg);
+    uint32_t *const cur = hist + wave * 256u;
+    for (int shift = 0; shift < 2 * k; shift += 8) {
+        for (uint32_t t = tid; t < 1024; t += 256) hist[t] = 0;
+        __syncthreads();                                      // also: the keys of the previous pass (or the hashes) are in place
+        for (uint32_t i = s0 + lane; i < s1; i += 64) atomicAdd(&cur[(ka[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            const uint32_t c0 = hist[tid], c1 = hist[256 + tid], c2 = hist[512 + tid], c3 = hist[768 + tid];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            const uint32_t incl = kx_wave_incl_scan(tot, lane);
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t base = incl - tot;
+            for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+            hist[tid] = base; hist[256 + tid] = base + c0; hist[512 + tid] = base + c0 + c1; hist[768 + tid] = base + c0 + c1 + c2;
+        }
+        __syncthreads();
+        for (uint32_t b0 = s0; b0 < s1; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            const bool valid = i < s1;
+            const uint32_t kv = valid ? ka[i] : 0u, vv = valid ? (uint32_t)va[i] : 0u;
+            const uint32_t d = (kv >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool one = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(valid && one);
+                peers &= one ? bal : ~bal;
+            }
+            const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), all = (uint32_t)__popcll(peers);
+            if (valid) {
+                const uint32_t at = cur[d];
+                kb[at + below] = kv; vb[at + below] = (uint16_t)vv;
+                if (below + 1u == all) cur[d] = at + all;       // the last lane of the digit moves its cursor (after every read of it: LDS keeps a wavefront's order)
+            }
+        }
+        __syncthreads();
+        { uint32_t *tk = ka; ka = kb; kb = tk; uint16_t *tv = va; va = vb; vb = tv; }
+    }
     uint32_t *kh = strand == 0 ? kh0 : kh1;
     uint32_t *kp = strand == 0 ? kp0 : kp1;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const uint32_t q = threadIdx.x * IPT + i;
-        if (q < nk) { kh[ko + q] = key[i]; kp[ko + q] = val[i]; }
-    }
-    __syncthreads();
+    for (uint32_t q = tid; q < nk; q += 256) { kh[ko + q] = ka[q]; kp[ko + q] = (uint32_t)va[q]; }
     uint64_t *bv = strand == 0 ? bv0 : bv1;
     uint32_t *pc = strand == 0 ? pc0 : pc1;
-    if (threadIdx.x < 64) {
-        uint64_t w = (uint64_t)bits[2 * threadIdx.x] | ((uint64_t)bits[2 * threadIdx.x + 1] << 32);
-        bv[(uint64_t)r * 64 + threadIdx.x] = w;
+    if (tid < 64) {
+        uint64_t w = (uint64_t)bits[2 * tid] | ((uint64_t)bits[2 * tid + 1] << 32);
+        bv[(uint64_t)r * 64 + tid] = w;
         uint32_t c = __popcll(w);
         for (int sft = 32; sft > 0; sft >>= 1) c += __shfl_xor(c, sft, 64);
-        if (threadIdx.x == 0) pc[r] = c;
+        if (tid == 0) pc[r] = c;
     }
-}
-
-template <int IPT>
-static hipError_t launch_radix(dim3 grid, size_t shm, hipStream_t st, const uint8_t *seq, const uint64_t *off, const uint64_t *koff, const uint32_t *items,
-                               int k, uint32_t Lmax, uint32_t *uh, uint32_t *kh0, uint32_t *kp0, uint32_t *kh1, uint32_t *kp1, uint64_t *bv0, uint64_t *bv1,
-                               uint32_t *pc0, uint32_t *pc1, uint32_t *bad) {
-    hipLaunchKernelGGL(kmer_extract_radix_kernel<IPT>, grid, dim3(256), shm, st, seq, off, koff, items, k, Lmax, uh, kh0, kp0, kh1, kp1, bv0, bv1, pc0, pc1, bad);
-    return hipGetLastError();
 }
 
 static uint32_t pow2ceil(uint32_t x) {
@@ -316,21 +350,18 @@ int build_index(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
                     gs = d_gs.p;
                 }
                 const bool use_bitonic = getenv("RATTLE_KMER_SORT") && !strcmp(getenv("RATTLE_KMER_SORT"), "bitonic");
-                if (in_lds && !use_bitonic && P >= 256) {
-                    // lists that fit a workgroup's registers: block radix sort, P / 256 keys per thread
-                    const size_t shm2 = 512 + ((Lmax + 15u) & ~15u);
-                    const dim3 grid(m, ns);
-                    const uint32_t *it = d_items.p + done + b;
-#define RADIX(IPT) e = launch_radix<IPT>(grid, shm2, st, X.seq.p, X.off.p, X.koff.p, it, k, Lmax, X.uh.p, X.kh[0].p, X.kp[0].p, X.kh[1].p, X.kp[1].p, X.bv[0].p, X.bv[1].p, X.pc[0].p, X.pc[1].p, d_bad.p)
-                    switch (P / 256) {
-                        case 1: RADIX(1); break;
-                        case 2: RADIX(2); break;
-                        case 4: RADIX(4); break;
-                        case 8: RADIX(8); break;
-                        case 16: RADIX(16); break;
-                        default: RADIX(32); break;
+                if (in_lds && !use_bitonic) {
+                    // lists that fit LDS twice over (keys + 16-bit positions, two copies): the LSD radix kernel
+                    const size_t shm2 = 512 + ((Lmax + 15u) & ~15u) + 4096 + 64 + (size_t)P * 12;
+                    if (shm2 > 64 * 1024 &&
+                        hipFuncSetAttribute((const void *)kmer_extract_lsd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2) != hipSuccess) {
+                        set_error("kmer_extract: this device cannot give a workgroup " + std::to_string(shm2) + " B of LDS (read of " + std::to_string(Lmax) + " nt)");
+                        rc = RATTLE_ERR_HIP;
+                        break;
                     }
-#undef RADIX
+                    hipLaunchKernelGGL(kmer_extract_lsd_kernel, dim3(m, ns), dim3(256), shm2, st, X.seq.p, X.off.p, X.koff.p, d_items.p + done + b, k, P, Lmax,
+                                       X.uh.p, X.kh[0].p, X.kp[0].p, X.kh[1].p, X.kp[1].p, X.bv[0].p, X.bv[1].p, X.pc[0].p, X.pc[1].p, d_bad.p);
+                    e = hipGetLastError();
                     if (e != hipSuccess) { set_error(std::string("kmer_extract (radix) launch: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
                     continue;
                 }

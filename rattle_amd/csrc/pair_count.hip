@@ -11,8 +11,6 @@
 // seeds): every hit is charged the whole list.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "common.h"
 
 namespace rattle {
@@ -110,18 +108,94 @@ __global__ __launch_bounds__(PC_THREADS) void pair_count_seed_kernel(pc_args A) 
     }
 }
 
-// sort the survivor list (ctx->d_surv, n entries of two words) by seed slot; n_seeds bounds the slot
+// ---- survivors grouped by seed: a counting sort (round 3: hand-written; round 2 called rocPRIM's device radix sort) -------------
+// Only the grouping matters -- the count kernel above walks runs of equal seed, nothing reads the order inside a run -- so one
+// histogram, one scan and one scatter do: a workgroup counts the seeds of its 16 K entries in LDS, adds its counts to the global
+// histogram (one atomic per workgroup and seed present, not per entry), and in the scatter reserves its share of every seed's
+// range the same way and places its entries with LDS atomics.  Evaluations with more seeds than the LDS table holds (many small
+// rectangles of `--iso`; those rarely take the seed-major form) use one global atomic per entry.
+#define SBS_CHUNK 16384u
+#define SBS_LDS 8192u
+
+__global__ __launch_bounds__(256) void sbs_hist_kernel(const uint2 *__restrict__ surv, uint32_t n, uint32_t ns, uint32_t *__restrict__ count) {
+    extern __shared__ uint32_t sbs_h[];
+    const bool lds = ns <= SBS_LDS;
+    const uint32_t b0 = blockIdx.x * SBS_CHUNK, b1 = min(n, b0 + SBS_CHUNK);
+    if (lds) {
+        for (uint32_t t = threadIdx.x; t < ns; t += 256) sbs_h[t] = 0;
+        __syncthreads();
+    }
+    for (uint32_t i = b0 + threadIdx.x; i < b1; i += 256) {
+        const uint32_t sd = surv[i].x >> 1;
+        if (lds) atomicAdd(&sbs_h[sd], 1u); else atomicAdd(&count[sd], 1u);
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < ns; t += 256) { const uint32_t c = sbs_h[t]; if (c) atomicAdd(&count[t], c); }
+    }
+}
+
+// exclusive scan of count[0 .. ns) in place (one workgroup; ns is a few hundred to a few hundred thousand)
+__global__ __launch_bounds__(1024) void sbs_scan_kernel(uint32_t *__restrict__ count, uint32_t ns) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < ns; b0 += 1024) {
+        const uint32_t i = b0 + tid;
+        const uint32_t v = i < ns ? count[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t base = carry;
+        for (uint32_t w = 0; w < wave; ++w) base += wtot[w];
+        if (i < ns) count[i] = base + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = base + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void sbs_scatter_kernel(const uint2 *__restrict__ surv, uint32_t n, uint32_t ns, uint32_t *__restrict__ cursor,
+                                                          uint2 *__restrict__ out) {
+    extern __shared__ uint32_t sbs_h[];
+    const bool lds = ns <= SBS_LDS;
+    const uint32_t b0 = blockIdx.x * SBS_CHUNK, b1 = min(n, b0 + SBS_CHUNK);
+    if (lds) {
+        for (uint32_t t = threadIdx.x; t < ns; t += 256) sbs_h[t] = 0;
+        __syncthreads();
+        for (uint32_t i = b0 + threadIdx.x; i < b1; i += 256) atomicAdd(&sbs_h[surv[i].x >> 1], 1u);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < ns; t += 256) { const uint32_t c = sbs_h[t]; if (c) sbs_h[t] = atomicAdd(&cursor[t], c); }      // this workgroup's share of seed t's range
+        __syncthreads();
+    }
+    for (uint32_t i = b0 + threadIdx.x; i < b1; i += 256) {
+        const uint2 e = surv[i];
+        const uint32_t sd = e.x >> 1;
+        const uint32_t at = lds ? atomicAdd(&sbs_h[sd], 1u) : atomicAdd(&cursor[sd], 1u);
+        out[at] = e;
+    }
+}
+
+// group the survivor list (ctx->d_surv, n entries of two words) by seed slot; n_seeds bounds the slot
 int sort_survivors_by_seed(rattle_ctx *ctx, uint32_t n, uint64_t n_seeds) {
     if (n < 2) return 0;
-    int sbits = 1;
-    while ((1ull << sbits) < n_seeds) ++sbits;
+    if (n_seeds >= 0x7FFFFFFFull) { set_error("survivor sort: too many seeds"); return RATTLE_ERR_ARG; }
+    const uint32_t ns = (uint32_t)n_seeds;
     RT_TRY(ctx->d_surv2.reserve((size_t)n * 2));
-    unsigned long long *in = (unsigned long long *)ctx->d_surv.p, *out = (unsigned long long *)ctx->d_surv2.p;
-    size_t tmp = 0;
-    // an entry read as one 64-bit key has the seed word in its low half: bits [1, 1 + sbits) are the seed slot
-    if (rocprim::radix_sort_keys(nullptr, tmp, in, out, (size_t)n, 1u, (unsigned)(1 + sbits), ctx->stream) != hipSuccess) { set_error("survivor sort: size query failed"); return RATTLE_ERR_HIP; }
-    RT_TRY(ctx->d_sort_tmp.reserve(tmp + 16));
-    if (rocprim::radix_sort_keys((void *)ctx->d_sort_tmp.p, tmp, in, out, (size_t)n, 1u, (unsigned)(1 + sbits), ctx->stream) != hipSuccess) { set_error("survivor sort failed"); return RATTLE_ERR_HIP; }
+    RT_TRY(ctx->d_sort_tmp.reserve(((size_t)ns + 1) * 4));
+    uint32_t *count = (uint32_t *)ctx->d_sort_tmp.p;
+    hipStream_t st = ctx->stream;
+    RT_HIP(hipMemsetAsync(count, 0, ((size_t)ns + 1) * 4, st));
+    const uint32_t blocks = (n + SBS_CHUNK - 1) / SBS_CHUNK;
+    const size_t shm = ns <= SBS_LDS ? (size_t)ns * 4 : 0;
+    hipLaunchKernelGGL(sbs_hist_kernel, dim3(blocks), dim3(256), shm, st, (const uint2 *)ctx->d_surv.p, n, ns, count);
+    hipLaunchKernelGGL(sbs_scan_kernel, dim3(1), dim3(1024), 0, st, count, ns);
+    hipLaunchKernelGGL(sbs_scatter_kernel, dim3(blocks), dim3(256), shm, st, (const uint2 *)ctx->d_surv.p, n, ns, count, (uint2 *)ctx->d_surv2.p);
+    RT_HIP(hipGetLastError());
     ctx->d_surv.swap(ctx->d_surv2);
     return 0;
 }

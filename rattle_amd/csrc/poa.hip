@@ -1014,6 +1014,10 @@ __device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 //   * the record word is decoded with v_pk_lshrrev_b16 (4 instructions per pair and predecessor instead of 5);
 //   * the in-thread prefix of u: v = max(RUN, u) ; EX = alignbit(v, RUN) ; RUN = max(v, swap(v)) -- 3 instructions per pair
 //     instead of 5 (the half swap is an op_sel of v_pk_max_i16).
+#ifndef POA_SHIFT_ONCE
+#define POA_SHIFT_ONCE 0          // 1: maxima over the predecessors on the unshifted H words, ONE shift per row (1.18 x (NP + 1) fewer instructions
+                                  // per row, but the shift then sits on the row's critical path: -1.3 % in an interleaved A/B, three rounds on one box)
+#endif
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x4 *cplan_t;      // wave-uniform loads from it are s_load_dwordx4
@@ -1095,7 +1099,8 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 }
                 drain_vector_loads();            // rare path (1-2 % of the fetches): nothing stays pending past it
             }
-        };
+        };                         // H of the column left of this wavefront (high half), maximum over the predecessors
+        uint32_t WL = 0;                         // H of the column left of this wavefront (high half), maximum over the predecessors
         auto combine = [&](auto first_tag, const uint32_t (&w)[NP], const uint32_t wl) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             uint32_t hp[NP];
@@ -1110,6 +1115,16 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 __builtin_memcpy(&ds, &d, 4);
                 FD[u] = as_pk(hp[u]) - ds;                                                            // max(H + g - e, F)
             }
+            // the maximum over the predecessors is taken on the UNSHIFTED H words (and on the words of the lane to the left of
+            // the wavefront); the shift by one column commutes with it and is done once per row below, not once per predecessor
+#if POA_SHIFT_ONCE
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                HM[u] = FIRST ? as_pk(hp[u]) : pk_max(HM[u], as_pk(hp[u]));
+                FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
+            }
+            WL = FIRST ? wl : max(WL, wl);
+#else
             const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
@@ -1117,6 +1132,7 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 HM[u] = FIRST ? HD : pk_max(HM[u], HD);
                 FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
             }
+#endif
         };
         if (n_in == 0) {                         // virtual start row: H = 0, F = -inf
 #pragma unroll
@@ -1152,6 +1168,11 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                     }
                 }
             }
+        }
+        if (POA_SHIFT_ONCE && n_in != 0) {       // H[p][j-1]: the maxima shifted by one column (lane 0 takes the word of the lane left of the wavefront)
+            const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HM[NP - 1]), (int32_t)WL);
+#pragma unroll
+            for (int u = NP - 1; u >= 0; --u) HM[u] = pk_left(as_u(HM[u]), u == 0 ? left : as_u(HM[u - 1]));
         }
         // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
         s16x2 HNp[NP], EX[NP], SC[NP], FN[NP];
