@@ -97,6 +97,46 @@ def test_pair_score_matches_oracle(gpu_ctx, oracle, small_reads, k):
     assert big >= 1
 
 
+@pytest.mark.parametrize("k", [10, 11])
+def test_pair_score_on_rearranged_reads(gpu_ctx, oracle, k):
+    """Kernel B's full pass advances by runs: chain-extending matches and kept chain elements 64 at a time, anything else one by
+    one (pair_score.hip).  Reads made of the same segments in other orders, with a segment doubled, dropped or repeated in
+    tandem give match lists full of elements that do NOT extend the chain, chains with elements that are NOT kept (exon-skip
+    like jumps, which cluster.cpp:28-34 rejects on variance), runs that end inside a 64-element step, and both strands."""
+    rng = np.random.default_rng(100 + k)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seg = [acgt[rng.integers(0, 4, n)] for n in (310, 95, 260, 64, 420, 33, 180)]
+    orders = [(0, 1, 2, 3, 4, 5, 6), (0, 2, 1, 3, 4, 6, 5), (0, 1, 1, 2, 3, 4, 5, 6), (0, 2, 4, 6), (4, 5, 6, 0, 1, 2, 3), (0, 1, 2, 2, 2, 3, 4),
+              (6, 5, 4, 3, 2, 1, 0), (0, 3, 4), (1, 3, 5, 1, 3, 5, 1, 3, 5), (0, 1, 2, 3, 4, 5, 6, 0, 1, 2)]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for o in orders:
+        tx = np.concatenate([seg[i] for i in o])
+        for err in (0.0, 0.03, 0.08, 0.12):
+            r = rng.random(len(tx))
+            sq = tx.copy()
+            sub = r < err * 0.5
+            sq[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+            sq = sq[r >= err * 0.25] if err else sq
+            b = sq.tobytes()
+            reads.append(b if len(reads) % 3 else b.translate(comp)[::-1])
+    gpu_ctx.load_reads(reads, k, True)
+    n = len(reads)
+    ii = np.repeat(np.arange(n), n); jj = np.tile(np.arange(n), n)
+    ss = np.asarray(rng.integers(0, 2, n * n), dtype=np.int64)
+    bases, hc, nd, var, nm = gpu_ctx.pair_score(ii, jj, ss)
+    searched = kept_gap = 0
+    for t in range(n * n):
+        b, h, d, v, m, _ = oracle.pair_score(reads[ii[t]], reads[jj[t]], k, int(ss[t]), dist_cap=1)
+        assert (bases[t], nd[t], nm[t]) == (b, d, m), (t, ii[t], jj[t], ss[t])
+        if m > 0:
+            assert hc[t] == h, t
+        assert _same_float(var[t], v), (t, var[t], v)
+        searched += m > 0 and d + 1 < m           # matches that did not all end up as kept chain elements
+        kept_gap += v > 25.0
+    assert searched > 200 and kept_gap > 50
+
+
 def _as_oracle_list(cl):
     return cl.as_list()
 
