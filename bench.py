@@ -158,6 +158,7 @@ def cpu_baseline_all_cores(cat, qcat, off, tid):
 
 
 PMC_FILE = os.path.join("profiles", "round3_pmc_poa.json")
+PMC_ISO_FILE = os.path.join("profiles", "round3_pmc_iso.json")      # kernel B in the --iso flow (tools/gpu_pmc_iso.sh)
 
 
 def toyset_line(ctx_cls, device):
@@ -195,13 +196,13 @@ def toyset_line(ctx_cls, device):
             "note": "small input: ~550 packs do not fill one MI355X (a pass lasts as long as its largest pack)"}
 
 
-def pmc_reference():
+def pmc_reference(path=None):
     """Counter-derived constants of kernel C, measured in separate rocprofv3 --pmc passes (tools/gpu_pmc_only.sh) and
     committed under profiles/ (the counters cannot be read from inside the benchmark process).  The file records a hash of
     the kernel's sources; `stale` says whether the tree this benchmark runs in still has those sources."""
     import hashlib
     try:
-        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+        d = json.load(open(os.path.join(ROOT, path or PMC_FILE)))
     except Exception:
         return None
     h = hashlib.sha256()
@@ -419,9 +420,15 @@ def main():
                              "reads": n_reads, "gene_clusters": checks["gene_clusters"], "transcript_clusters": checks["transcript_clusters"], "parallelism": par}
             ms, launches, alg = kst["pair_score"]
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "hbm", "kernel": "pair_score", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+            pmc_iso = pmc_reference(PMC_ISO_FILE)
+            ratio = pmc_iso.get("hbm_bytes_per_algorithmic_byte") if pmc_iso else None
+            out["roofline"] = {"bound": "hbm", "kernel": "pair_score", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                               "traffic": ratio * alg / max(launches, 1) if ratio else None,
+                               "hbm_bytes_per_algorithmic_byte": ratio, "pmc_source": PMC_ISO_FILE if pmc_iso else None,
+                               "pmc_stale": pmc_iso["stale"] if pmc_iso else None,
                                "alg_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-                               "note": "8 B x (nK_i + nK_j) per full comparison (SURVEY 8d) / kernel time from HIP events"}
+                               "note": "8 B x (nK_i + nK_j) per comparison (SURVEY 8d) / kernel time from HIP events; traffic = FETCH_SIZE(x2) + WRITE_SIZE of "
+                                       "kernel B from the committed PMC passes of the same flow (tools/gpu_pmc_iso.sh), per launch"}
         else:
             n_cor, n_unc, n_cons, counters = res.counts()
             cells = int(counters[0])
