@@ -31,21 +31,27 @@ namespace rattle {
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 #define BVF_SLOAD(bank, ptr, off) asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(bank) : "s"(ptr), "i"(off))
 #define BVF_SWAIT(bank, acc) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bank), "+v"(acc))
-__device__ __forceinline__ void bvf_chunk(const uint64_t (&v)[64], const u32x8 S, const int c, uint32_t &a) {
+// every popcount is ONE v_bcnt_u32_b32 with its accumulate operand, on four independent chains (written as `a += popc(x)` the
+// compiler re-associates the sum into bcnt(x, 0) pairs joined by v_add3: 2 more instructions per 8 words; inline asm pins it)
+__device__ __forceinline__ void bvf_bcnt_acc(uint32_t &acc, const uint32_t x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x)); }
+__device__ __forceinline__ void bvf_chunk(const uint64_t (&v)[64], const u32x8 S, const int c, uint32_t (&acc)[4]) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) a += __popcll(v[4 * c + w] & ((uint64_t)S[2 * w] | ((uint64_t)S[2 * w + 1] << 32)));
+    for (int w = 0; w < 4; ++w) {
+        bvf_bcnt_acc(acc[(2 * w) & 3], (uint32_t)v[4 * c + w] & S[2 * w]);
+        bvf_bcnt_acc(acc[(2 * w + 1) & 3], (uint32_t)(v[4 * c + w] >> 32) & S[2 * w + 1]);
+    }
 }
 __device__ __forceinline__ uint32_t seed_dot(const uint64_t (&v)[64], const uint64_t *seed_vec) {
     const uint64_t sp = (uint64_t)(uintptr_t)seed_vec;
     u32x8 A, B;
-    uint32_t a = 0;
+    uint32_t acc[4] = {0, 0, 0, 0};
     BVF_SLOAD(A, sp, 0);
 #define BVF_PAIR(c)                                                     \
-    BVF_SWAIT(A, a); BVF_SLOAD(B, sp, ((c) + 1) * 32); bvf_chunk(v, A, (c), a);      \
-    BVF_SWAIT(B, a); if ((c) + 2 < 16) BVF_SLOAD(A, sp, (((c) + 2) & 15) * 32); bvf_chunk(v, B, (c) + 1, a);
+    BVF_SWAIT(A, acc[0]); BVF_SLOAD(B, sp, ((c) + 1) * 32); bvf_chunk(v, A, (c), acc);      \
+    BVF_SWAIT(B, acc[0]); if ((c) + 2 < 16) BVF_SLOAD(A, sp, (((c) + 2) & 15) * 32); bvf_chunk(v, B, (c) + 1, acc);
     BVF_PAIR(0) BVF_PAIR(2) BVF_PAIR(4) BVF_PAIR(6) BVF_PAIR(8) BVF_PAIR(10) BVF_PAIR(12) BVF_PAIR(14)
 #undef BVF_PAIR
-    return a;
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // A lane owns one candidate and keeps its 512-byte vector in 128 registers.  Read straight from memory that is 32 loads of 16
