@@ -390,8 +390,14 @@ struct evaluator {
                            ctx->d_pi.p, ctx->d_pj.p, ctx->d_slot2.p, X.len.p, use_hc, t_s, t_v, vout, d_hits, d_big);
         ++launches;
         unsigned long long *hv = ctx->h_bound_stats.p + 2 + 3 * (size_t)nrect;
+        // the first accepted pairs travel with the counters (one synchronisation per evaluation instead of two: the --iso level
+        // runs ~1000 evaluations of ~1000 accepted pairs each)
+        const uint32_t spec = std::min<uint32_t>(n2, 8192u);
+        RT_TRY(ctx->h_surv.reserve((size_t)spec * 2 + 2));
         RT_HIP(hipMemcpyAsync(hv, vout, 24, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipMemcpyAsync(ctx->h_surv.p, d_hits, (size_t)spec * 8, hipMemcpyDeviceToHost, st));
         RT_HIP(hipStreamSynchronize(st));
+        const bool nbig_seen = hv[1] != 0;
         if (hv[1]) {
             // pairs whose match list did not fit LDS: rerun through the global-scratch variant, then judge them
             const uint32_t nbig = (uint32_t)hv[1], big_m = (uint32_t)hv[2];
@@ -409,9 +415,11 @@ struct evaluator {
             if (hv[1]) { set_error("pair_score: a pair is still oversize after the oversize pass"); return RATTLE_ERR_HIP; }
         }
         const uint32_t nhit = (uint32_t)hv[0];
-        RT_TRY(ctx->h_surv.reserve((size_t)nhit * 2 + 2));
-        if (nhit) RT_HIP(hipMemcpyAsync(ctx->h_surv.p, d_hits, (size_t)nhit * 8, hipMemcpyDeviceToHost, st));
-        RT_HIP(hipStreamSynchronize(st));
+        if (nhit > spec || nbig_seen) {                  // more than came along (or the oversize pass appended some): fetch them all
+            RT_TRY(ctx->h_surv.reserve((size_t)nhit * 2 + 2));
+            if (nhit) RT_HIP(hipMemcpyAsync(ctx->h_surv.p, d_hits, (size_t)nhit * 8, hipMemcpyDeviceToHost, st));
+            RT_HIP(hipStreamSynchronize(st));
+        }
         // accepted pairs back to their rectangle
         for (uint32_t q = 0; q < nhit; ++q) {
             const uint32_t a = ctx->h_surv.p[2 * (size_t)q], c = ctx->h_surv.p[2 * (size_t)q + 1];
