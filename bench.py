@@ -190,7 +190,7 @@ def toyset_line(ctx_cls, device):
     same = [((m[0], m[1]), [(x[0], x[1]) for x in mem]) for m, mem in best[2].as_list()] == [((m[0], m[1]), [(x[0], x[1]) for x in mem]) for m, mem in want]
     ctx.close()
     n = len(seqs)
-    return {"reads": n, "cluster_s": best[0], "correct_s": best[1], "cluster_reads_per_s": n / best[0], "correct_reads_per_s": n / best[1],
+    return {"reads": n, "cluster_s": best[0], "correct_s": best[1], "poa_dp_cells": int(best[3][3][0]), "cluster_reads_per_s": n / best[0], "correct_reads_per_s": n / best[1],
             "reads_per_s": n / (best[0] + best[1]), "clusters": int(len(best[2].main_id)), "clusters_equal_reference_fixture": bool(same),
             "consensi": int(best[3][2]), "reference_published": "README.md:400-403: cluster 16 s, correct 76 s on 1 thread (516 / 109 reads/s); correct 759 reads/s on 24 threads",
             "note": "small input: ~550 packs do not fill one MI355X (a pass lasts as long as its largest pack)"}
@@ -215,6 +215,115 @@ def pmc_reference(path=None):
     return d
 
 
+KNAMES = {K_KMER: "kmer_extract", K_FILTER: "bv_filter", K_SCORE: "pair_score", K_POA: "poa_align", K_POST: "post_msa"}
+
+
+def iso_roofline(kst):
+    """kernel B in the `--iso` flow: algorithmic bytes (8 B x (nK_i + nK_j) per comparison) over its HIP-event time"""
+    ms, launches, alg = kst["pair_score"]
+    ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    pmc_iso = pmc_reference(PMC_ISO_FILE)
+    ratio = pmc_iso.get("hbm_bytes_per_algorithmic_byte") if pmc_iso else None
+    return {"bound": "hbm", "kernel": "pair_score", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "traffic": ratio * alg / max(launches, 1) if ratio else None,
+            "hbm_bytes_per_algorithmic_byte": ratio, "pmc_source": PMC_ISO_FILE if pmc_iso else None,
+            "pmc_stale": pmc_iso["stale"] if pmc_iso else None,
+            "alg_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+            "note": "8 B x (nK_i + nK_j) per comparison (SURVEY 8d) / kernel time from HIP events; traffic = FETCH_SIZE(x2) + WRITE_SIZE of "
+                    "kernel B from the committed PMC passes of the same flow (tools/gpu_pmc_iso.sh), per launch"}
+
+
+def poa_roofline(kst, cells, steps, per_gpu=1, copy_gbs=None):
+    """kernel C: exact DP cells over its HIP-event time, priced in wave64 VALU instructions per second (it is bound by VALU issue /
+    per-row latency, not by HBM: SURVEY 8d, profiles/) against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; `cells` = per step"""
+    ms, launches, alg = kst["poa_align"]
+    gcups = cells / per_gpu / (ms / steps * 1e-3) / 1e9 if ms > 0 else 0.0
+    hbm6 = 6.0 * gcups
+    pmc = pmc_reference()
+    ipc = pmc.get("valu_wave_instr_per_cell") if pmc else None
+    ach = gcups * 1e9 * ipc / 1e12 if ipc else None
+    return {
+        "bound": "valu_issue", "kernel": "poa_align", "achieved": ach, "peak": VALU_PEAK_TINSTR, "unit": "Tinstr/s",
+        "frac": ach / VALU_PEAK_TINSTR if ach else None,
+        "valu_wave_instr_per_cell": ipc, "gcups": gcups, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+        "cells_per_launch": cells * steps / max(launches, 1),
+        # HBM view: SURVEY 8(d)'s 6 B per DP cell (three int16 matrices) and what the kernel really stores
+        "hbm": {"achieved_6B_per_cell_gbs": hbm6, "peak_gbs": 8000.0, "frac_6B_per_cell": hbm6 / 8000.0, "measured_copy_gbs": copy_gbs,
+                "stored_bytes_per_cell": pmc.get("hbm_bytes_per_cell") if pmc else None,
+                "achieved_stored_gbs": gcups * pmc["hbm_bytes_per_cell"] if pmc and pmc.get("hbm_bytes_per_cell") else None},
+        "traffic": (pmc["hbm_bytes_per_cell"] * cells * steps / max(launches, 1)) if pmc and pmc.get("hbm_bytes_per_cell") else None,
+        "pmc_source": PMC_FILE if pmc else None,
+        # true: poa.hip / common.h changed after the counter passes were collected -- the per-cell constants (and `frac`,
+        # `traffic`) then describe an older kernel; GCUPS and the timings are always live
+        "pmc_stale": bool(pmc.get("stale")) if pmc else None,
+        "note": "achieved = exact DP cells / kernel time (HIP events on the library's streams) x VALU wave-instructions per cell from the "
+                "committed SQ_INSTS_VALU pass of this tree; traffic = FETCH_SIZE(x2) + WRITE_SIZE per cell from the committed PMC passes x cells per launch"}
+
+
+def side_config(device, n_reads, iso, steps=2):
+    """One of BASELINE's other single-GPU configs, timed beside the headline on the same box and in the same process so that the
+    driver's one default command measures it too: configs[1] (1e5 cDNA reads, gene-level `cluster`; `correct` follows because the
+    under-filled device is what that size probes) and configs[2] (1e6 reads, `cluster --iso`).  Inputs resident in HBM, one
+    warm-up, `steps` timed passes between device synchronisations, digests equal across the passes."""
+    import torch
+    genes = max(5, n_reads // (600 if iso else 200))
+    cat, qcat, off, tid, _ = make_workload(n_reads, genes, seed=20260929, isoforms=3 if iso else 1)
+    n = len(off) - 1
+    ctx = Context(device)
+    ctx.stage_reads(cat, qcat, off)
+    t_cluster = t_correct = 0.0
+
+    def one():
+        nonlocal t_cluster, t_correct
+        t0 = time.time()
+        if iso:
+            cl, gid, ng = ctx.cluster_iso_unsorted_packed(cat, off)
+            t_cluster += time.time() - t0
+            return cl, int(ng), None
+        cl = ctx.cluster_unsorted_packed(cat, off)
+        t1 = time.time()
+        res = ctx.correct_packed(cat, qcat, off, cl, keep=True)
+        t_cluster += t1 - t0
+        t_correct += time.time() - t1
+        return cl, None, res
+
+    w = one()
+    dg_w = (cluster_digest(w[0]), w[2].digest() if w[2] is not None else None)
+    if w[2] is not None:
+        w[2].free()
+    ctx.reset_stats()
+    t_cluster = t_correct = 0.0
+    torch.cuda.synchronize()
+    t0 = time.time()
+    outs = [one() for _ in range(steps)]
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    kst = {KNAMES[k]: ctx.kernel_stats(k) for k in KNAMES}
+    cl, ng, res = outs[-1]
+    rec = {"reads": n, "value": n / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "kernels_ms_per_step": {k: v[0] / steps for k, v in kst.items()},
+           "phases_ms_per_step": {"cluster": t_cluster / steps * 1e3, **({"correct": t_correct / steps * 1e3} if not iso else {})}}
+    if iso:
+        assert len(cl.member_id) == n and np.array_equal(np.sort(cl.member_id), np.arange(n)), "--iso: not a partition of the reads"
+        rec["workload"] = f"{n} synthetic cDNA reads, {genes} genes x 3 isoforms, `rattle cluster --iso` k=10 / k=11 (BASELINE configs[2])"
+        rec["gene_clusters"], rec["transcript_clusters"] = ng, int(len(cl.main_id))
+        rec["roofline"] = iso_roofline(kst)
+        assert cluster_digest(cl) == dg_w[0], "--iso: result differs between passes"
+    else:
+        n_cor, n_unc, n_cons, counters = res.counts()
+        assert n_cor + n_unc == n and n_cons == expected_consensi(cl)
+        assert (cluster_digest(cl), res.digest()) == dg_w, "result differs between passes"
+        rec["workload"] = f"{n} synthetic cDNA reads, {genes} transcripts, `rattle cluster` k=10 gene level + `rattle correct` (BASELINE configs[1] size)"
+        rec["clusters"], rec["packs"], rec["cluster_reads_per_s"] = int(len(cl.main_id)), int(counters[2]), n / (t_cluster / steps)
+        rec["roofline"] = poa_roofline(kst, int(counters[0]), steps)
+    rec["digest_equal_across_steps"] = True
+    for o in outs:
+        if o[2] is not None:
+            o[2].free()
+    ctx.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +335,7 @@ def main():
     ap.add_argument("--iso", action="store_true", help="config 3: two-level `cluster --iso` (k=10, then k=11 per gene cluster) instead of cluster+correct")
     ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl", help="exchange of the sharded job: RCCL on device buffers, or host buffers through gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of BASELINE configs[1] and configs[2]")
     ap.add_argument("--no-reference-digest", action="store_true", help="several ranks: skip the unsharded reference run the result is checked against")
     ap.add_argument("--no-stage", action="store_true", help="hand the reads over as host buffers every step (PCIe-inclusive rate)")
     a = ap.parse_args()
@@ -341,15 +451,32 @@ def main():
         warm = step()
     ctx.reset_stats()
     PHASES["cluster"] = PHASES["correct"] = 0.0
+    # A step returns the corrected reads as ~2 GB of host buffers the CALLER frees (the reference returns std::vectors).  Giving
+    # them back to the OS costs ~0.18 s per step of pure harness time (round 3's verdict), so the results of the timed steps are
+    # kept and freed after the timed region when the host has the memory for it (psutil), else freed between steps as before.
+    held = []
+    hold = False
+    if not a.iso and warm is not None:
+        try:
+            import psutil
+            per = warm[1].host_bytes()
+            hold = psutil.virtual_memory().available > 3 * per * (a.steps + 2)
+        except Exception:
+            hold = False
     barrier()
     t0 = time.time()
     last = None
     for _ in range(a.steps):
         if last is not None and not a.iso:
-            last[1].free()
+            if hold:
+                held.append(last[1])
+            else:
+                last[1].free()
         last = step()
     barrier()
     dt = time.time() - t0
+    for h in held:
+        h.free()
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -386,8 +513,7 @@ def main():
                 checks["digest_equal_to_single_gpu"] = True
 
     if rank == 0:
-        names = {K_KMER: "kmer_extract", K_FILTER: "bv_filter", K_SCORE: "pair_score", K_POA: "poa_align", K_POST: "post_msa"}
-        kst = {names[k]: ctx.kernel_stats(k) for k in names}
+        kst = {KNAMES[k]: ctx.kernel_stats(k) for k in KNAMES}
         # what this GPU sustains on a plain device-to-device copy (read + write bytes), SURVEY 8(d)
         buf = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(buf)
@@ -418,56 +544,30 @@ def main():
             out["config"] = {"workload": f"{n_reads} synthetic cDNA reads (mean 1 kb, 10% err, both strands, {genes} genes x 3 isoforms, Zipf abundance), "
                                          "`rattle cluster --iso` k=10 / iso k=11 (BASELINE configs[2])",
                              "reads": n_reads, "gene_clusters": checks["gene_clusters"], "transcript_clusters": checks["transcript_clusters"], "parallelism": par}
-            ms, launches, alg = kst["pair_score"]
-            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            pmc_iso = pmc_reference(PMC_ISO_FILE)
-            ratio = pmc_iso.get("hbm_bytes_per_algorithmic_byte") if pmc_iso else None
-            out["roofline"] = {"bound": "hbm", "kernel": "pair_score", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                               "traffic": ratio * alg / max(launches, 1) if ratio else None,
-                               "hbm_bytes_per_algorithmic_byte": ratio, "pmc_source": PMC_ISO_FILE if pmc_iso else None,
-                               "pmc_stale": pmc_iso["stale"] if pmc_iso else None,
-                               "alg_bytes_per_launch": alg / max(launches, 1), "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-                               "note": "8 B x (nK_i + nK_j) per comparison (SURVEY 8d) / kernel time from HIP events; traffic = FETCH_SIZE(x2) + WRITE_SIZE of "
-                                       "kernel B from the committed PMC passes of the same flow (tools/gpu_pmc_iso.sh), per launch"}
+            out["roofline"] = iso_roofline(kst)
         else:
             n_cor, n_unc, n_cons, counters = res.counts()
             cells = int(counters[0])
-            ms, launches, alg = kst["poa_align"]
-            # several ranks on one job: `cells` is the job's total, `ms` this GPU's kernel time -> per-GPU rate
-            per_gpu = world if sharded else 1
-            gcups = cells / per_gpu / (ms / a.steps * 1e-3) / 1e9 if ms > 0 else 0.0
-            hbm6 = 6.0 * gcups
-            pmc = pmc_reference()
-            ipc = pmc.get("valu_wave_instr_per_cell") if pmc else None
-            ach = gcups * 1e9 * ipc / 1e12 if ipc else None
+            per_gpu = world if sharded else 1      # several ranks on one job: `cells` is the job's total, the kernel time this GPU's
             out["config"] = {"workload": f"{n_reads} synthetic cDNA reads (mean 1 kb, 10% err, both strands, {genes} transcripts, Zipf abundance), "
                                          "`rattle cluster` k=10 gene level + `rattle correct` (BASELINE metric size; configs[1]/[3] shape)"
                                          + (" per GPU" if a.weak else ", ONE job over all GPUs"),
                              "reads": n_reads, "clusters": int(len(cl.main_id)), "poa_dp_cells_per_step": cells, "poa_alignments_per_step": int(counters[1]),
                              "packs": int(counters[2]), "parallelism": par}
-            out["roofline"] = {
-                # kernel C is bound by VALU issue / per-row latency, not by HBM (profiles/round2_*): priced in wave64 VALU
-                # instructions per second against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
-                "bound": "valu_issue", "kernel": "poa_align", "achieved": ach, "peak": VALU_PEAK_TINSTR, "unit": "Tinstr/s",
-                "frac": ach / VALU_PEAK_TINSTR if ach else None,
-                "valu_wave_instr_per_cell": ipc, "gcups": gcups, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-                "cells_per_launch": cells * a.steps / max(launches, 1),
-                # HBM view: SURVEY 8(d)'s 6 B per DP cell (three int16 matrices) and what the kernel really stores
-                "hbm": {"achieved_6B_per_cell_gbs": hbm6, "peak_gbs": 8000.0, "frac_6B_per_cell": hbm6 / 8000.0, "measured_copy_gbs": copy_gbs,
-                        "stored_bytes_per_cell": pmc.get("hbm_bytes_per_cell") if pmc else None,
-                        "achieved_stored_gbs": gcups * pmc["hbm_bytes_per_cell"] if pmc and pmc.get("hbm_bytes_per_cell") else None},
-                "traffic": (pmc["hbm_bytes_per_cell"] * cells * a.steps / max(launches, 1)) if pmc and pmc.get("hbm_bytes_per_cell") else None,
-                "pmc_source": PMC_FILE if pmc else None,
-                # true: poa.hip / common.h changed after the counter passes were collected -- the per-cell constants (and `frac`,
-                # `traffic`) then describe an older kernel; GCUPS and the timings are always live
-                "pmc_stale": bool(pmc.get("stale")) if pmc else None,
-                "note": "achieved = exact DP cells / kernel time (HIP events on the library's streams) x VALU wave-instructions per cell from the "
-                        "committed SQ_INSTS_VALU pass of this tree; traffic = FETCH_SIZE(x2) + WRITE_SIZE per cell from the committed PMC passes x cells per launch"}
+            out["roofline"] = poa_roofline(kst, cells, a.steps, per_gpu, copy_gbs)
             if not a.no_cpu_baseline:
                 try:
                     out["toyset"] = toyset_line(Context, local)
                 except Exception as e:       # the headline must not depend on the side measurement
                     out["toyset"] = {"error": str(e)[:300]}
+                if world == 1 and not a.no_configs:
+                    # BASELINE's other single-GPU configs on the same box, same process (each with its own kernel's roofline)
+                    out["configs"] = {}
+                    for name, nr, iso in (("config2_100k_cluster_correct", 100000, False), ("config3_1M_cluster_iso", 1000000, True)):
+                        try:
+                            out["configs"][name] = side_config(local, nr, iso)
+                        except Exception as e:
+                            out["configs"][name] = {"error": str(e)[:300]}
                 out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cat, qcat, off, tid)
         print(json.dumps(out))

@@ -126,6 +126,17 @@ class CorrectionHandle:
     def digest(self):
         return None if self.ptr is None else correction_digest(self.ptr.contents)
 
+    def host_bytes(self):
+        """bases + qualities held by the three read sets (what free() gives back to the OS)"""
+        if self.ptr is None:
+            return 0
+        R = self.ptr.contents
+        tot = 0
+        for S in (R.corrected, R.uncorrected, R.consensi):
+            if S.n:
+                tot += 2 * int(np.ctypeslib.as_array(S.off, (S.n + 1,))[S.n])
+        return tot
+
     def free(self):
         if self.ptr is not None:
             self.lib.rattle_hip_correction_free(self.ptr)

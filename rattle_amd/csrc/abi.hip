@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unistd.h>
 
 #include <memory>
 
@@ -21,6 +22,25 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
 int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, const uint64_t *off, uint32_t n_reads,
                    uint32_t n_clusters, const uint32_t *coff, const int32_t *mid, const uint8_t *mrev,
                    const rattle_correct_params *P, rattle_correction **out);
+
+// Hardware queues the HIP runtime of this process hands out (kernel C runs one stream per POA column class and wants a queue
+// for each: classes sharing a queue run one after the other, poa.hip).  The runtime reads GPU_MAX_HW_QUEUES once, when it
+// starts -- the first HIP call of the process -- so the value is settled when this library is LOADED, not when kernel C runs:
+// if the variable is set by then it is taken at its word; if it is not and the runtime has not started yet (no /dev/kfd
+// descriptor in the process), the library sets it to 12 itself; otherwise the runtime is already running with its default of 4.
+static int g_hw_queues = 4;
+__attribute__((constructor)) static void settle_hw_queues() {
+    if (const char *v = getenv("GPU_MAX_HW_QUEUES")) { g_hw_queues = std::max(1, atoi(v)); return; }
+    bool runtime_up = false;
+    char link[64], target[256];
+    for (int fd = 0; fd < 1024 && !runtime_up; ++fd) {
+        snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+        const ssize_t n = readlink(link, target, sizeof target - 1);
+        if (n > 0) { target[n] = 0; runtime_up = strcmp(target, "/dev/kfd") == 0; }
+    }
+    if (!runtime_up) { setenv("GPU_MAX_HW_QUEUES", "12", 0); g_hw_queues = 12; }
+}
+int hw_queues() { return g_hw_queues; }
 
 }  // namespace rattle
 

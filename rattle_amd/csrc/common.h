@@ -245,6 +245,8 @@ struct post_args {
     double min_occ, gap_occ, err_ratio;
 };
 
+int hw_queues();      // hardware queues the HIP runtime of this process hands out (settled when the library is loaded, abi.hip)
+
 }  // namespace rattle
 
 struct rattle_ctx {

@@ -220,19 +220,21 @@ __global__ __launch_bounds__(64) void pair_score_kernel(ps_args A) {
     ps_sync<BIG>();
     if (swp && total > 1) {
         // matches of the swapped walk come in j's hash order: back into the reference's (pos1, pos2) order (kmer.cpp:65, a
-        // lexicographic sort of distinct pairs) with a bitonic network over the two arrays
+        // lexicographic sort of distinct pairs) with a bitonic network over the two arrays.  The network is the all-ascending
+        // form (a merge starts with the flip t ^ (k2 - 1), then halves t ^ j2): every comparator moves the smaller pair to the
+        // lower index, so the entries beyond `total` behave as +infinity WITHOUT existing -- a comparator whose partner lies
+        // beyond `total` is skipped.  Nothing outside [0, total) is read or written (the arrays hold `cap` entries back to back:
+        // padding to the next power of two ran into pos2 / tv for 256 < total <= 400).
         uint32_t P2 = 2;
         while (P2 < total) P2 <<= 1;
-        for (uint32_t t = total + lane; t < P2; t += 64) { pos1[t] = 0xFFFFFFFFu; pos2[t] = 0xFFFFFFFFu; }
-        ps_sync<BIG>();
         for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
             for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                for (uint32_t t = lane; t < P2; t += 64) {
-                    const uint32_t u = t ^ j2;
-                    if (u > t) {
+                const uint32_t flip = j2 == (k2 >> 1) ? k2 - 1u : j2;
+                for (uint32_t t = lane; t < total; t += 64) {
+                    const uint32_t u = t ^ flip;
+                    if (u > t && u < total) {
                         const uint32_t a1 = pos1[t], a2 = pos2[t], b1 = pos1[u], b2 = pos2[u];
-                        const bool gt = a1 > b1 || (a1 == b1 && a2 > b2);
-                        if (gt == ((t & k2) == 0)) { pos1[t] = b1; pos2[t] = b2; pos1[u] = a1; pos2[u] = a2; }
+                        if (a1 > b1 || (a1 == b1 && a2 > b2)) { pos1[t] = b1; pos2[t] = b2; pos1[u] = a1; pos2[u] = a2; }
                     }
                 }
                 ps_sync<BIG>();

@@ -1293,6 +1293,357 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     multi = best > 0;
 }
 
+// ---- the packed row recurrence as a SKEWED PIPELINE of wavefronts (round 4; classes up to 2560 columns) -------------------
+// dp_rows_v3 ends every row with a block-wide rendezvous: all wavefronts write their prefix totals, `s_barrier`, all read them
+// back.  A pack that has the CU to itself then spends ~2400 cycles per row against ~700 of issue (round 3's verdict: the toyset,
+// config 2, every rank of an 8-GPU job, stages 2a / 3a / 3b and the POA #3 of the largest cluster all run like that), and even
+// with seven packs per CU the wavefronts wait 60 % of their cycles.
+//
+// Here no row ends in a barrier.  Wavefront w owns the columns [w * 64 * CPL, (w + 1) * 64 * CPL) of EVERY row and runs the rows
+// on its own clock; what couples it to its neighbours is a mailbox in LDS:
+//   * to finish row r it needs from wavefront w-1 the prefix maximum of u over all columns to its left (T) and, for the
+//     diagonal terms, the H of the column to its left (Hl) -- both are final as soon as w-1 is one row ahead;
+//   * wavefront w-1 publishes {T, Hl} of row r in slot r % SK_D of its mailbox and then the counter cnt = r (LDS operations of
+//     one wavefront complete in issue order, so a reader that sees cnt >= r sees the slot); a reader takes cnt first, the slot
+//     second;
+//   * the writer must not overwrite a slot the reader still needs: it waits (rarely) for the reader's own counter.
+// In the steady state wavefront w trails w-1 by a row or two and never waits; the time of a row is one wavefront's own path,
+// not the slowest wavefront's plus a rendezvous, and the waves of a pack are independent instruction streams for the SIMDs.
+//
+// FMT == 0: the ring holds the record words (as dp_rows_v3: 2 bytes per cell, decoded per reader).
+// FMT == 1: the ring holds the predecessor terms READY-MADE, two words per column pair: A = H[p][j-1] (the diagonal source,
+//   already shifted by a column: the producer shifts once, not every reader) and B = max(H[p][j] + g - e, F[p][j]) (so that
+//   F of the reader = max over predecessors of B, + e).  A reader then spends 2 instructions per pair and predecessor instead
+//   of 7-8 (2.18 in-edges per row: the predecessors were 40 % of the row's VALU work); 4 bytes per cell in LDS.
+// Rows older than the ring come from the record in HBM in both formats.
+#ifndef SK_D
+#define SK_D 16                                   // mailbox slots per wavefront (rows a producer may run ahead of its reader)
+#endif
+template <int NW> struct sk_mail {
+    uint32_t cnt[NW];                             // cnt[w]: last row whose {T} wavefront w has published; n + 1: all its rows are final
+    int2 ent[NW][SK_D];                           // slot r % SK_D: {x: prefix max of u over columns 1 .. last column of w (both halves), y: H of its last column << 16}
+};
+__device__ __forceinline__ uint32_t sk_ld(const uint32_t *p) { return *(const volatile uint32_t *)p; }
+__device__ __forceinline__ void sk_st(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
+// inclusive prefix max over the lanes of a word whose two halves are EQUAL: as a signed 32-bit number such a word orders like
+// its halves, so the 32-bit DPP scan works on it directly and the result is again a duplicated word
+__device__ __forceinline__ uint32_t wave_scan_max_dup(uint32_t v) { return (uint32_t)wave_scan_max_fused((int32_t)v); }
+
+template <int CPL, int RING, int NW, int FMT>
+__device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
+    constexpr int NT = 64 * NW, NP = CPL / 2;
+    constexpr int RW = FMT ? 2 * NP : NP;         // ring dwords per thread and row
+    constexpr uint32_t D = SK_D, KEEP = FMT ? 0u : (uint32_t)RING;      // FMT 0: a reader takes the Hl of its ring predecessors from the mailbox
+    static_assert(RING > 0 && (RING & (RING - 1)) == 0 && (uint32_t)RING + 2 <= D, "ring slot = row & (RING - 1); the mailbox outlives the ring");
+    static_assert(NT * CPL <= 2560 && CPL % 2 == 0, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
+    __shared__ sk_mail<NW> M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t c0 = (uint32_t)tid * CPL;
+    const bool act = c0 < Lp;
+    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
+    {
+        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
+#pragma unroll
+        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
+#pragma unroll
+        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
+    }
+    uint32_t SEL[NP];                            // score table selectors (see dp_rows_pk)
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
+        const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
+        const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
+        SEL[u] = sa | (sb << 16);
+    }
+    const bool plain = S.plain != 0;
+    s16x2 JE[NP], UC[NP];                        // per column: j*e and g - (j+1)*e
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int j0 = (int)c0 + 2 * u + 1, j1 = j0 + 1;
+        const s16x2 je = {(short)(j0 * POA_E), (short)(j1 * POA_E)};
+        const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
+        JE[u] = je; UC[u] = act ? uc : pk_splat(-30000);      // threads beyond the row: u = Hn - 30000 < 0 < every valid u, no select before the scan
+    }
+    s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
+    const uint32_t n_act = min((uint32_t)NW, (Lp + 64u * CPL - 1u) / (64u * CPL));      // wavefronts that own columns of this sequence
+    const bool wave_act = (uint32_t)wave < n_act, has_left = wave > 0, has_right = (uint32_t)wave + 1u < n_act;
+    uint32_t *const ring_thr = S.ring + (size_t)tid * RW;              // slot s of this thread: ring_thr + s * NT * RW
+    uint32_t *const Hrec = (uint32_t *)S.H;                            // the record, a dword per column pair
+    uint32_t *const my_cnt = &M.cnt[wave], *const left_cnt = &M.cnt[has_left ? wave - 1 : 0], *const right_cnt = &M.cnt[has_right ? wave + 1 : 0];
+    uint32_t *const my_ent = (uint32_t *)&M.ent[wave][0], *const left_ent = (uint32_t *)&M.ent[has_left ? wave - 1 : 0][0];
+
+    if (tid < NW) M.cnt[tid] = 0;
+    // the plan through the scalar cache (see dp_rows_v3)
+    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc;
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc) : : "memory");
+    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
+    __syncthreads();                             // the counters are zero before anybody looks at them
+
+    auto step = [&](const uint32_t row, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));                      // lane tests are redone per row (see dp_rows_v3)
+        const uint32_t info = pa.x;
+        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+        const uint32_t mslot = row % D;
+        // ---- what the neighbours say (requested first, looked at when needed) ----
+        uint32_t cl = 0, cr = 0, leT = 0, leH = 0;
+        if (has_left) { cl = sk_ld(left_cnt); leT = sk_ld(left_ent + 2 * mslot); leH = sk_ld(left_ent + 2 * mslot + 1); }
+        if (has_right) cr = sk_ld(right_cnt);
+        auto wait_left = [&](const uint32_t need) __attribute__((always_inline)) {
+            cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl);
+            while ((int32_t)(cl - need) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sk_ld(left_cnt));
+                leT = sk_ld(left_ent + 2 * mslot); leH = sk_ld(left_ent + 2 * mslot + 1);
+            }
+        };
+        // FMT 0 reads the Hl of its ring predecessors (row - 1 among them) from the left mailbox: the left wavefront must have
+        // published row `row` (its row - 1 is then final).  FMT 1 needs the left wavefront only when the prefix is combined.
+        if (FMT == 0 && has_left) wait_left(row);
+        s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
+        uint32_t raw[4][RW], rawl[4];
+        auto fetch = [&](const int k, const uint32_t prow) __attribute__((always_inline)) {
+            if (row - prow <= (uint32_t)RING) {
+                const uint32_t slot = prow & (uint32_t)(RING - 1);
+                const uint32_t *rp = ring_thr + slot * (uint32_t)(NT * RW);
+                if constexpr (RW == 2) { const uint2 a2 = *(const uint2 *)rp; raw[k][0] = a2.x; raw[k][1] = a2.y; }
+                else if constexpr (RW == 4) { const uint4 a4 = *(const uint4 *)rp; raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; }
+                else if constexpr (RW == 8) {
+                    const uint4 a4 = *(const uint4 *)rp, b4 = *(const uint4 *)(rp + 4);
+                    raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; raw[k][4] = b4.x; raw[k][5] = b4.y; raw[k][6] = b4.z; raw[k][7] = b4.w;
+                } else if constexpr (RW % 2 == 0) {
+#pragma unroll
+                    for (int u = 0; u < RW / 2; ++u) { const uint2 a2 = ((const uint2 *)rp)[u]; raw[k][2 * u] = a2.x; raw[k][2 * u + 1] = a2.y; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RW; ++u) raw[k][u] = rp[u];
+                }
+                rawl[k] = 0;
+                if (FMT == 0 && has_left) rawl[k] = sk_ld(left_ent + 2 * (prow % D) + 1);
+            } else {
+                // beyond the ring (a few per cent of the fetches): the record words from HBM, decoded into the ring's format
+                uint32_t w[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) w[u] = 0x80008000u;               // H = 0, H - F = 2: what a column beyond the row decodes to
+                uint32_t wl = 0;
+                if (act) {
+                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) w[u] = hq[u];
+                    if (lane == 0 && wave > 0) wl = ((uint32_t)((const uint16_t *)S.H)[(uint64_t)prow * Lp + c0 - 1] & 0x3FFFu) << 16;
+                }
+                drain_vector_loads();            // rare path: nothing stays pending past it
+                if constexpr (FMT == 0) {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) raw[k][u] = w[u];
+                    rawl[k] = wl;
+                } else {
+                    uint32_t hp[NP];
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        hp[u] = w[u] & 0x3FFF3FFFu;
+                        u16x2 wu;
+                        __builtin_memcpy(&wu, &w[u], 4);
+                        const u16x2 d = __builtin_elementwise_min(wu >> (u16x2){14, 14}, (u16x2){2, 2});
+                        s16x2 ds;
+                        __builtin_memcpy(&ds, &d, 4);
+                        raw[k][NP + u] = as_u(as_pk(hp[u]) - ds);                                  // B = H - min(H - F, 2)
+                    }
+                    const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) raw[k][u] = as_u(pk_left(hp[u], u == 0 ? left : hp[u - 1]));      // A = H shifted by a column
+                    rawl[k] = 0;
+                }
+            }
+        };
+        auto combine = [&](auto first_tag, const uint32_t (&w)[RW], const uint32_t wl) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            if constexpr (FMT == 1) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    HM[u] = FIRST ? as_pk(w[u]) : pk_max(HM[u], as_pk(w[u]));
+                    FM[u] = FIRST ? as_pk(w[NP + u]) : pk_max(FM[u], as_pk(w[NP + u]));
+                }
+            } else {
+                uint32_t hp[NP];
+                s16x2 FD[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    hp[u] = w[u] & 0x3FFF3FFFu;
+                    u16x2 wu;
+                    __builtin_memcpy(&wu, &w[u], 4);
+                    const u16x2 d = __builtin_elementwise_min(wu >> (u16x2){14, 14}, (u16x2){2, 2});      // min(H - F, 2)
+                    s16x2 ds;
+                    __builtin_memcpy(&ds, &d, 4);
+                    FD[u] = as_pk(hp[u]) - ds;                                                            // max(H + g - e, F)
+                }
+                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const s16x2 HD = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
+                    HM[u] = FIRST ? HD : pk_max(HM[u], HD);
+                    FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
+                }
+            }
+        };
+        if (n_in == 0) {                         // virtual start row: H = 0, F = -inf
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
+        } else {
+            fetch(0, pb.x);
+            if (n_in > 1) fetch(1, pb.y);
+            if (n_in > 2) fetch(2, pb.z);
+            if (n_in > 3) fetch(3, pb.w);
+            combine(std::true_type{}, raw[0], rawl[0]);
+            if (n_in > 1) combine(std::false_type{}, raw[1], rawl[1]);
+            if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
+            if (n_in > 3) {
+                combine(std::false_type{}, raw[3], rawl[3]);
+                if (n_in > 4) {
+                    fetch(0, pc.x);
+                    if (n_in > 5) fetch(1, pc.y);
+                    if (n_in > 6) fetch(2, pc.z);
+                    if (n_in > 7) fetch(3, pc.w);
+                    combine(std::false_type{}, raw[0], rawl[0]);
+                    if (n_in > 5) combine(std::false_type{}, raw[1], rawl[1]);
+                    if (n_in > 6) combine(std::false_type{}, raw[2], rawl[2]);
+                    if (n_in > 7) combine(std::false_type{}, raw[3], rawl[3]);
+                    if (n_in > 8) {
+                        uint32_t e = pa.w;
+                        for (uint32_t k = 8; k < n_in; ++k) {
+                            const uint2 ed = S.edges[e]; e = ed.y;
+                            const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
+                            drain_vector_loads();
+                            fetch(0, prow);
+                            combine(std::false_type{}, raw[0], rawl[0]);
+                        }
+                    }
+                }
+            }
+        }
+        // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
+        s16x2 HNp[NP], EX[NP], SC[NP], FN[NP];
+        s16x2 RUN = pk_splat(-32768);
+        if (plain) {
+            const uint32_t li = (letter >> 1) & 3u;
+            const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));      // low / high bytes of {-4, -4, -4, -4} with 5 at li
+#pragma unroll
+            for (int u = 0; u < NP; ++u) SC[u] = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                SC[u] = as_pk(pack16(s0, s1));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            FN[u] = FM[u] + pk_splat(POA_E);
+            HNp[u] = pk_max(pk_max(HM[u] + SC[u], FN[u]), pk_splat(0));
+            const s16x2 v = pk_max(RUN, HNp[u] + UC[u]);                                   // (max(run, u_a), max(run, u_b))
+            EX[u] = as_pk(__builtin_amdgcn_alignbit(as_u(v), as_u(RUN), 16));              // (run, max(run, u_a)): both halves of RUN are equal
+            RUN = pk_max(v, __builtin_shufflevector(v, v, 1, 0));                          // max(run, u_a, u_b) in both halves
+        }
+        // the scan runs on the duplicated word itself: no extraction before, no packing after
+        const uint32_t wincl = wave_scan_max_dup(as_u(RUN));
+        const uint32_t texcl = (uint32_t)wave_shr1((int32_t)wincl, (int32_t)0x80008000u);
+        // ---- the prefix over the wavefronts to the left, and ours to the right ----
+        uint32_t sbase = as_u(pk_splat(POA_G - POA_E));        // u_0
+        uint32_t hl = 0;
+        if (has_left) {
+            if (FMT == 1) wait_left(row + 1);
+            const uint32_t Tl = (uint32_t)__builtin_amdgcn_readfirstlane((int)leT);
+            hl = (uint32_t)__builtin_amdgcn_readfirstlane((int)leH);
+            sbase = (uint32_t)max((int32_t)sbase, (int32_t)Tl);
+        }
+        if (has_right) {
+            const uint32_t tc = (uint32_t)max((int32_t)sbase, __builtin_amdgcn_readlane((int32_t)wincl, 63));
+            cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)cr);
+            while ((int32_t)(cr + (D - KEEP) - row) < 0) {         // the slot still holds row - D, which the reader may need until it has published row - D + KEEP
+                __builtin_amdgcn_s_sleep(1);
+                cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sk_ld(right_cnt));
+            }
+            if (lane_o == 0) { sk_st(my_ent + 2 * mslot, tc); sk_st(my_cnt, row); }
+        }
+        const s16x2 BASE = pk_max(as_pk(texcl), as_pk(sbase));
+        uint32_t W[NP];
+        s16x2 HN[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const s16x2 EV = pk_max(BASE, EX[u]) + JE[u];
+            HN[u] = pk_max(HNp[u], EV);
+            MXA = pk_max(MXA, HN[u]);
+            W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14);       // H (14 bits) | min(H - F, 3) << 14: record (traceback, far rows)
+        }
+        {
+            const uint32_t slot = row & (uint32_t)(RING - 1);
+            uint32_t *rp = ring_thr + slot * (uint32_t)(NT * RW);
+            uint32_t R[RW];
+            if constexpr (FMT == 1) {
+                const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HN[NP - 1]), (int32_t)hl);       // lane 0: the H the left wavefront published
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    R[u] = as_u(pk_left(as_u(HN[u]), u == 0 ? left : as_u(HN[u - 1])));
+                    R[NP + u] = as_u(pk_max(HN[u] - pk_splat(2), FN[u]));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) R[u] = W[u];
+            }
+            if constexpr (RW == 2) *(uint2 *)rp = make_uint2(R[0], R[1]);
+            else if constexpr (RW == 4) *(uint4 *)rp = make_uint4(R[0], R[1], R[2], R[3]);
+            else if constexpr (RW == 8) { *(uint4 *)rp = make_uint4(R[0], R[1], R[2], R[3]); *(uint4 *)(rp + 4) = make_uint4(R[4], R[5], R[6], R[7]); }
+            else if constexpr (RW % 2 == 0) {
+#pragma unroll
+                for (int u = 0; u < RW / 2; ++u) ((uint2 *)rp)[u] = make_uint2(R[2 * u], R[2 * u + 1]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < RW; ++u) rp[u] = R[u];
+            }
+            if (has_right && lane_o == 63) sk_st(my_ent + 2 * mslot + 1, as_u(HN[NP - 1]));      // the high half is the H of this wavefront's last column
+            if (act) {
+                uint32_t *hq = Hrec + ((uint64_t)row * Lp >> 1) + (c0 >> 1);
+                if (NP % 2 == 0) {
+#pragma unroll
+                    for (int u = 0; u < NP / 2; ++u) ((uint2 *)hq)[u] = make_uint2(W[2 * u], W[2 * u + 1]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) hq[u] = W[u];
+                }
+            }
+        }
+    };
+
+    if (wave_act) {
+        u32x4 na = cpa[0], nb = cpb[0], nc = cpc[0];      // plan of the next row, one row ahead
+        for (uint32_t row = 1; row <= n; ++row) {
+            const u32x4 pa = na, pb = nb, pc = nc;
+            if (row < n) { na = cpa[row]; nb = cpb[row]; nc = cpc[row]; }
+            step(row, pa, pb, pc);
+        }
+        if (has_right && lane == 0) sk_st(my_cnt, n + 1);          // every row of this wavefront is final (its last Hl is in the mailbox)
+    }
+    // block-wide best score and the threads whose columns reach it (the first row that reaches it comes from a rescan of
+    // those threads' columns in the record, kernel body)
+    const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wave] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
+    __syncthreads();
+    best = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
+    if (best > 0 && lbest == best) {
+        const uint32_t slot = atomicAdd(&X.ntl, 1u);
+        if (slot < 16) X.tl[slot] = (uint32_t)tid;
+    }
+    __syncthreads();
+    best_row = 0;
+    multi = best > 0;
+}
+
 // ---- rows of 2561 .. 8192 columns (PK == 3): 32-bit cells, up to SIXTEEN wavefronts per pack ------------------
 // A pack of long reads used to be one workgroup of four wavefronts with 16-32 columns per lane in 250-410 registers: one
 // wavefront per SIMD, one pack per CU, tens of seconds per pack while most of the device idled (config 5).  Here the row is
@@ -2890,9 +3241,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 order[n_run++] = c;
             }
             std::sort(order, order + n_run, [&](int a, int b) { return est[a] != est[b] ? est[a] > est[b] : a > b; });
-            // (the drivers -- rattle, bench.py, rattle_amd -- raise GPU_MAX_HW_QUEUES to 12 before the HIP runtime starts, so that
-            // every class gets a queue of its own; a host application that did not is dealt four streams)
-            const int hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+            // (hw_queues(), abi.hip: what the HIP runtime of this process was started with -- the library raises GPU_MAX_HW_QUEUES to
+            // 12 when it is loaded before the runtime starts, so that every class gets a queue of its own; an application whose
+            // runtime was already running with the default is dealt four streams)
+            const int hwq = hw_queues();
             const int n_streams = std::max(1, std::min(POA_GROUPS, getenv("RATTLE_POA_STREAMS") ? atoi(getenv("RATTLE_POA_STREAMS")) : hwq));
             double load[16] = {0};
             bool used[16] = {false};

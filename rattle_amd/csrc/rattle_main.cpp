@@ -790,7 +790,7 @@ int mode_correct(int argc, char **argv) {
     };
     // corrected.fq / uncorrected.fq (fasta.cpp:436-445 record layout) straight from the library's buffers: the text of each
     // file is laid out by record offsets and filled in parallel
-    auto write_set = [&](const rattle_read_set &S, bool corrected, const std::string &path) {
+    auto write_set = [&](const rattle_read_set &S, bool corrected, const std::string &path) -> bool {
         std::vector<std::string> tags(clusters.size());
         std::vector<uint64_t> at((size_t)S.n + 1, 0);
         for (uint32_t i = 0; i < S.n; ++i) {
@@ -816,28 +816,39 @@ int mode_correct(int argc, char **argv) {
                 put(S.qual + S.off[i], S.off[i + 1] - S.off[i]); *o++ = '\n';
             }
         });
-        if (!text.finish()) die("Error: cannot write " + path);
+        return text.finish();
     };
     const std::string outdir = a.str("output", ".");
     // corrected.fq is formatted and written from the library's corrected_ready callback, while POA #2 / #3 still run on the
-    // device (one device: the sharded job reassembles its reads at the end)
-    struct early_out { std::function<void(const rattle_read_set &)> write; std::atomic<bool> done{false}; } early;
-    early.write = [&](const rattle_read_set &S) { cli_timer t("corrected.fq (behind the consensus stages)"); write_set(S, true, outdir + "/corrected.fq"); };
+    // device (one device: the sharded job reassembles its reads at the end).  The callback runs on a library thread with kernels
+    // in flight, so it never exits the process: it writes corrected.fq.tmp and records the outcome; the main thread renames the
+    // file once correct_reads has returned 0 (the reference writes its three files only after correct_reads, main.cpp:405-411: a
+    // failed run must not leave a complete-looking corrected.fq) or removes it and reports the failure.
+    struct early_out { std::function<bool(const rattle_read_set &)> write; std::atomic<bool> done{false}, failed{false}; } early;
+    const std::string corrected_path = outdir + "/corrected.fq", corrected_tmp = corrected_path + ".tmp";
+    early.write = [&](const rattle_read_set &S) { cli_timer t("corrected.fq (behind the consensus stages)"); return write_set(S, true, corrected_tmp); };
     rattle_correction *R = nullptr;
     std::unique_ptr<cli_timer> t_lib(new cli_timer("library: correct_reads"));
     if (team.n() == 1) {
-        P.corrected_ready = [](void *u, const rattle_read_set_s *S, const uint32_t *) { early_out *E = (early_out *)u; E->write(*S); E->done = true; };
+        P.corrected_ready = [](void *u, const rattle_read_set_s *S, const uint32_t *) {
+            early_out *E = (early_out *)u;
+            if (E->write(*S)) E->done = true; else E->failed = true;
+        };
         P.corrected_ready_user = &early;
     }
     team.run([&](int r, rattle_ctx *ctx) {                                      // packs sharded over the ranks, result reassembled on rank 0
         rattle_correction *mine = nullptr, *merged = nullptr;
-        chk(rattle_hip_correct_reads(ctx, cat.data(), qcat.data(), off.data(), n_reads, (uint32_t)clusters.size(), coff.data(), mid.data(),
-                                     mrev.data(), &P, &mine));
+        const int rc = rattle_hip_correct_reads(ctx, cat.data(), qcat.data(), off.data(), n_reads, (uint32_t)clusters.size(), coff.data(), mid.data(),
+                                                mrev.data(), &P, &mine);
+        if (rc != 0 && team.n() == 1) unlink(corrected_tmp.c_str());           // no half of a result stays behind
+        chk(rc);
         if (team.n() == 1) { R = mine; return; }
         chk(rattle_hip_correction_gather(ctx, mine, 0, &merged));
         rattle_hip_correction_free(mine);
         if (r == 0) R = merged;
     });
+    if (early.failed) { unlink(corrected_tmp.c_str()); die("Error: cannot write " + corrected_path); }
+    if (early.done && rename(corrected_tmp.c_str(), corrected_path.c_str()) != 0) die("Error: cannot write " + corrected_path);
     t_lib.reset();
     cli_timer t_out("format + write outputs");
     read_set_t consensi;
@@ -885,8 +896,8 @@ int mode_correct(int argc, char **argv) {
         consensi.push_back(r);
     }
     std::cerr << std::endl << "Generating consensi..." << std::endl;
-    if (!early.done) write_set(R->corrected, true, outdir + "/corrected.fq");
-    write_set(R->uncorrected, false, outdir + "/uncorrected.fq");
+    if (!early.done && !write_set(R->corrected, true, corrected_path)) die("Error: cannot write " + corrected_path);
+    if (!write_set(R->uncorrected, false, outdir + "/uncorrected.fq")) die("Error: cannot write " + outdir + "/uncorrected.fq");
     write_fastq_file(consensi, outdir + "/consensi.fq");
     if (R->skipped.n) {
         // packs whose POA did not fit the device (or the --max-pack-cells budget): their reads are in uncorrected.fq

@@ -1,0 +1,50 @@
+"""Build-time checks on the generated gfx950 code (no GPU: hipcc cross-compiles).
+
+Kernel A streams the seed vector through the scalar cache with hand double-buffered `s_load_dwordx8` / `s_waitcnt lgkmcnt(0)`
+pairs written as SEPARATE inline-asm statements (rattle_amd/csrc/bv_filter.hip: BVF_SLOAD / BVF_SWAIT).  Between the two the
+compiler sees the bank as an ordinary defined SGPR value; nothing in the language stops it from copying, spilling or reading
+it there, before the scalar load has delivered.  Correctness therefore rests on the code one compiler version emits -- so the
+emitted code is what this test checks: no instruction between a bank's s_load and the next full lgkmcnt(0) wait touches a
+register of that bank."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _device_asm(src, tmp_path):
+    out = tmp_path / (os.path.basename(src) + ".s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
+                           "-o", str(out), os.path.join(ROOT, "rattle_amd", "csrc", src)], stderr=subprocess.DEVNULL)
+    return out.read_text().splitlines()
+
+
+def _sgprs(line):
+    regs = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", line):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(x) for x in re.findall(r"\bs(\d+)\b", line))
+    return regs
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_bv_filter_scalar_banks_are_not_touched_before_their_wait(tmp_path):
+    lines = [l.strip() for l in _device_asm("bv_filter.hip", tmp_path)]
+    loads = [i for i, l in enumerate(lines) if l.startswith("s_load_dwordx8")]
+    assert len(loads) >= 32                       # sixteen per strand variant of the kernel: the hand-written loads are there
+    for i in loads:
+        m = re.match(r"s_load_dwordx8 s\[(\d+):(\d+)\]", lines[i])
+        bank = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        j = i + 1
+        while j < len(lines) and not (lines[j].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[j]):
+            l = lines[j]
+            if l and not l.startswith((";", ".", "//")) and not l.endswith(":"):
+                body = l.split(";")[0]
+                assert not (bank & _sgprs(body)), f"line {j + 1}: `{l}` touches s[{min(bank)}:{max(bank)}] before the wait for its load (line {i + 1})"
+                assert not body.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")), f"control flow between a load (line {i + 1}) and its wait"
+            j += 1
+        assert j < len(lines), "an s_load_dwordx8 without a following s_waitcnt lgkmcnt(0)"

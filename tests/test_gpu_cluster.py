@@ -137,6 +137,49 @@ def test_pair_score_on_rearranged_reads(gpu_ctx, oracle, k):
     assert searched > 200 and kept_gap > 50
 
 
+@pytest.mark.parametrize("k", [10, 11])
+def test_pair_score_long_seed_against_a_fragment_of_it(gpu_ctx, oracle, k):
+    """The swapped walk of kernel B (pair_score.hip: nA > 4 nB + 256 -- a long seed against a short candidate walks the SHORT list
+    and sorts the matches back into (pos1, pos2) order).  A 300-450 nt fragment of a > 2 kb read shares 257..400 k-mers with it:
+    the sort then works on more than 256 entries in arrays of 400 (round 3's advisor finding: the padded network ran past them).
+    Both strands, clean and noisy fragments, fragments with an internal repeat; every pair against the oracle."""
+    rng = np.random.default_rng(900 + k)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for _ in range(6):
+        reads.append(acgt[rng.integers(0, 4, int(rng.integers(3000, 3900)))].tobytes())
+    n_long = len(reads)
+    for li in range(n_long):
+        L = reads[li]
+        for flen in (300, 340, 395, 430, 450):
+            a = int(rng.integers(0, len(L) - flen))
+            for err in (0.0, 0.02):
+                f = np.frombuffer(L[a:a + flen], np.uint8).copy()
+                r = rng.random(flen)
+                f[r < err] = acgt[rng.integers(0, 4, int((r < err).sum()))]
+                b = f.tobytes()
+                if len(reads) % 4 == 1:
+                    b = b[:150] + b[60:150] + b[150:]                    # an internal repeat: cross products of equal hashes
+                reads.append(b if len(reads) % 2 else b.translate(comp)[::-1])
+    gpu_ctx.load_reads(reads, k, True)
+    n = len(reads)
+    ii = np.repeat(np.arange(n_long), n - n_long); jj = np.tile(np.arange(n_long, n), n_long)
+    ii = np.concatenate([ii, ii]); jj = np.concatenate([jj, jj])
+    ss = np.concatenate([np.zeros(len(ii) // 2, np.int64), np.ones(len(ii) // 2, np.int64)])
+    bases, hc, nd, var, nm = gpu_ctx.pair_score(ii, jj, ss)
+    big = 0
+    for t in range(len(ii)):
+        assert len(reads[ii[t]]) - k > 4 * (len(reads[jj[t]]) - k) + 256       # the swapped walk is what runs
+        b, h, d, v, m, _ = oracle.pair_score(reads[ii[t]], reads[jj[t]], k, int(ss[t]), dist_cap=1)
+        assert (bases[t], nd[t], nm[t]) == (b, d, m), (t, ii[t], jj[t], ss[t], (bases[t], nd[t], nm[t]), (b, d, m))
+        if m > 0:
+            assert hc[t] == h, t
+        assert _same_float(var[t], v), (t, var[t], v)
+        big += 256 < m <= 400
+    assert big >= 20
+
+
 def _as_oracle_list(cl):
     return cl.as_list()
 

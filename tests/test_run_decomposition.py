@@ -118,3 +118,36 @@ def test_runs_equal_the_reference_walks(oracle, k):
             searched += wm > 0 and wn + 1 < wm
             dropped += any(abs(d) >= k for d in dists)
     assert searched > 50 and dropped > 20
+
+
+def _swapped_walk_network(n):
+    """Comparator schedule of the sort behind kernel B's swapped walk (pair_score.hip: a long seed against a short candidate
+    walks the SHORT list, the matches come in the candidate's hash order and go back into (pos1, pos2) order): the all-ascending
+    bitonic form, comparators whose partner lies beyond n skipped -- so nothing beyond n is ever touched."""
+    p2 = 2
+    while p2 < n:
+        p2 <<= 1
+    k2 = 2
+    while k2 <= p2:
+        j2 = k2 >> 1
+        while j2 > 0:
+            yield k2 - 1 if j2 == (k2 >> 1) else j2
+            j2 >>= 1
+        k2 <<= 1
+
+
+@pytest.mark.parametrize("n", list(range(2, 70)) + [127, 128, 129, 255, 256, 257, 300, 399, 400])
+def test_swapped_walk_sort_network_sorts_any_length(n):
+    """The advisor's round-3 finding: the power-of-two padded network wrote past the `cap` = 400 entries of pos1 / pos2 for
+    256 < n <= 400.  The network the kernel runs now is restated here and must sort every length without padding."""
+    rng = np.random.default_rng(n)
+    key = rng.integers(0, 40, n) * 100000 + rng.permutation(n)          # distinct (pos1, pos2) pairs as one key
+    a = key.copy()
+    for flip in _swapped_walk_network(n):
+        t = np.arange(n)
+        u = t ^ flip
+        sel = (u > t) & (u < n)
+        lo, hi = t[sel], u[sel]
+        sw = a[lo] > a[hi]
+        a[lo[sw]], a[hi[sw]] = a[hi[sw]].copy(), a[lo[sw]].copy()
+    assert np.array_equal(a, np.sort(key))
