@@ -73,6 +73,12 @@ namespace rattle {
 #ifndef POA_MW_1x16
 #define POA_MW_1x16 3
 #endif
+#ifndef POA_SK_BLOCKS
+#define POA_SK_BLOCKS 7                    // skewed pipeline, record words in the ring: workgroups per CU the registers are budgeted for
+#endif
+#ifndef POA_SK_BLOCKS_RM
+#define POA_SK_BLOCKS_RM 4                 // ... ready-made terms in the ring (4 bytes per cell: LDS holds four 1024-column packs per CU)
+#endif
 #define POA_MAX_LEN (1u << 20)           // H <= 5 * length must stay far below 2^28 (POA_NEG)
 
 // node record (uint4): x = letter | n_al << 8 | n_in << 16, y = first in-edge's begin node,
@@ -1565,8 +1571,12 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 __builtin_amdgcn_s_sleep(1);
                 cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sk_ld(right_cnt));
             }
-            if (lane_o == 0) { sk_st(my_ent + 2 * mslot, tc); sk_st(my_cnt, row); }
+            if (lane_o == 0) sk_st(my_ent + 2 * mslot, tc);
         }
+        // the counter says two things: to the right, "my prefix of this row is in its slot (and every earlier row of mine is
+        // final)"; to the left, "I have taken your slot of this row" -- so the LAST wavefront keeps it too (its left
+        // neighbour's back-pressure reads it)
+        if (n_act > 1 && lane_o == 0) sk_st(my_cnt, row);
         const s16x2 BASE = pk_max(as_pk(texcl), as_pk(sbase));
         uint32_t W[NP];
         s16x2 HN[NP];
@@ -1623,7 +1633,7 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             if (row < n) { na = cpa[row]; nb = cpb[row]; nc = cpc[row]; }
             step(row, pa, pb, pc);
         }
-        if (has_right && lane == 0) sk_st(my_cnt, n + 1);          // every row of this wavefront is final (its last Hl is in the mailbox)
+        if (n_act > 1 && lane == 0) sk_st(my_cnt, n + 1);          // every row of this wavefront is final (its last Hl is in the mailbox)
     }
     // block-wide best score and the threads whose columns reach it (the first row that reaches it comes from a rescan of
     // those threads' columns in the record, kernel body)
@@ -2233,10 +2243,17 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
+// PK: 0 = 32-bit registers + int16 record + nibbles (dp_rows), 1 = packed int16 pairs, record word H | min(H-F,3) << 14 (dp_rows_v3 / dp_rows_pk),
+// 2 = int32 segments (dp_rows_long / _longr), 3 = 32-bit cells on up to 16 wavefronts (dp_rows_wide),
+// 5 / 6 = the packed record of PK 1 written by the skewed wavefront pipeline (dp_rows_sk), ring format 0 (record words) / 1 (ready-made terms)
+__host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 5 || PK == 6; }
+__host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 6; }
+
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
 constexpr int poa_min_waves(int CPL, int NW, int PK) {
-    return PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
+    return PK == 5 || PK == 6 ? (((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4 > 8 ? 8 : ((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4)
+         : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
            : PK == 1 && NW == 1 && CPL == 16 ? POA_MW_1x16 : 1;
 }
 template <int CPL, int RING, int NW, int PK>
@@ -2264,7 +2281,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (PK != 1 && NT * CPL > 2048 ? CPL : CPL / 2));
+        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (pk_readymade(PK) ? CPL : !pk_packed(PK) && NT * CPL > 2048 ? CPL : CPL / 2));
     }
 
     while (true) {
@@ -2289,7 +2306,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
             const uint8_t *s = A.seq + so;
             uint32_t *path = A.out_col + so;
             if (L == 0) continue;                                   // Graph::add_alignment ignores an empty sequence
-            if (PK == 1) {
+            if (pk_packed(PK)) {
                 // alphabet of the pack (this sequence included): decides whether the packed rows may take the score table
                 uint32_t fl = 0;
                 for (uint32_t t = tid; t < L; t += NT) {
@@ -2333,7 +2350,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     if (n_in <= 4) e5 = e;
                     S.plan[r] = make_uint4(rec.x, v, e5, e);        // .z: 5th in-edge (general code paths), .w: 9th (packed rows)
                     S.planb[r] = pr;
-                    if (PK == 1) S.planc[r] = pr2;
+                    if (pk_packed(PK)) S.planc[r] = pr2;
                 }
 #ifdef POA_PREDSTAT
                 atomicAdd(&A.counters[4], ps_in); atomicAdd(&A.counters[5], ps_far); atomicAdd(&A.counters[6], ps_prev);
@@ -2348,6 +2365,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                 if constexpr (PK == 2 && RING > 0) dp_rows_longr<CPL, RING, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 3) dp_rows_wide<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
+                else if constexpr (PK == 5 || PK == 6) dp_rows_sk<CPL, RING, NW, PK == 6 ? 1 : 0>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1 && POA_V3) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
@@ -2371,15 +2389,15 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                                 load_block<CPL>(S.H + (uint64_t)r * Lp + t * CPL, v);
                                 bool hit = false;
 #pragma unroll
-                                for (int u = 0; u < CPL; ++u) hit |= (PK == 1 ? (v[u] & 0x3FFF) : v[u]) == best;
-                                if (hit) { S.rowmax[r] = 1; if (PK == 1 || PK == 3) atomicMin(&X.brow, r); }
+                                for (int u = 0; u < CPL; ++u) hit |= (pk_packed(PK) ? (v[u] & 0x3FFF) : v[u]) == best;
+                                if (hit) { S.rowmax[r] = 1; if (pk_packed(PK) || PK == 3) atomicMin(&X.brow, r); }
                             }
                         } else {
                             for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NW) {
                                 const cell_t *Hr = (const cell_t *)S.H + (uint64_t)r * Lp;
                                 bool hit = false;
-                                for (uint32_t c = tid & 63; c < L; c += 64) hit |= (PK == 1 ? (int32_t)(Hr[c] & 0x3FFF) : (int32_t)Hr[c]) == best;
-                                if (hit) { S.rowmax[r] = 1; if (PK == 1 || PK == 3) atomicMin(&X.brow, r); }
+                                for (uint32_t c = tid & 63; c < L; c += 64) hit |= (pk_packed(PK) ? (int32_t)(Hr[c] & 0x3FFF) : (int32_t)Hr[c]) == best;
+                                if (hit) { S.rowmax[r] = 1; if (pk_packed(PK) || PK == 3) atomicMin(&X.brow, r); }
                             }
                         }
                         __syncthreads();
@@ -2388,7 +2406,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         if (cnt) atomicAdd(&s_bc[5], cnt);
                     }
                     __syncthreads();
-                    if (PK == 1 || PK == 3) best_row = X.brow;  // packed and wide rows: the rescan is where the first row comes from
+                    if (pk_packed(PK) || PK == 3) best_row = X.brow;  // packed and wide rows: the rescan is where the first row comes from
                     // cheap exit: if every tied row except the first has a tied direct predecessor, all of
                     // them descend from the first one, which then precedes them in ANY topological order
                     bool need_sort = s_bc[5] > 1;
@@ -2495,7 +2513,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     const cell_t *Hb = (const cell_t *)S.H + (uint64_t)best_row * Lp;
                     if (tid == 0) s_bc[5] = 0xFFFFFFFFu;
                     __syncthreads();
-                    for (uint32_t c = tid; c < L; c += NT) if ((PK == 1 ? (int32_t)(Hb[c] & 0x3FFF) : (int32_t)Hb[c]) == best) { atomicMin(&s_bc[5], c + 1); break; }
+                    for (uint32_t c = tid; c < L; c += NT) if ((pk_packed(PK) ? (int32_t)(Hb[c] & 0x3FFF) : (int32_t)Hb[c]) == best) { atomicMin(&s_bc[5], c + 1); break; }
                     __syncthreads();
                     const uint32_t bj = s_bc[5];
                     // Traceback by wave 0, in spoa's order of tests: diagonal (predecessors in in-edge order),
@@ -2534,16 +2552,16 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         auto Hat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return 0;
                             const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1];
-                            return PK == 1 ? (w & 0x3FFF) : w;
+                            return pk_packed(PK) ? (w & 0x3FFF) : w;
                         };
                         auto Fat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return POA_NEG;
-                            if (PK == 1) { const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1]; return (w & 0x3FFF) - ((w >> 14) & 3); }
+                            if (pk_packed(PK)) { const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1]; return (w & 0x3FFF) - ((w >> 14) & 3); }
                             return (int32_t)H[(uint64_t)r * Lp + c - 1] - (int32_t)(nib(r, c) & 3u);
                         };
                         auto Eat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return POA_NEG;
-                            if (PK == 1) {
+                            if (pk_packed(PK)) {
                                 // The packed rows keep no E record: E[r][c] = max over k < c of H[r][k] + g + (c-1-k) e (H[r][0] = 0) is
                                 // rebuilt from the row's H cells by the whole wavefront when the traceback asks for it -- only at
                                 // horizontal moves, a few dozen times per alignment, against a store per thread and row in the DP.
@@ -2581,7 +2599,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                                 // the row plan of my step travels with the cell: the step that fails is replayed by the general
                                 // code below, which then has its plan in lane m's registers instead of a second round trip
                                 if (in && my_i != 0) { fpl = S.plan[my_i - 1]; fplb = S.planb[my_i - 1]; }
-                                if (in && my_next != 0 && my_j > 1) { c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2]; if (PK == 1) c &= 0x3FFF; }
+                                if (in && my_next != 0 && my_j > 1) { c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2]; if (pk_packed(PK)) c &= 0x3FFF; }
                                 const int32_t hcur = wave_shr1(c, Hij);     // H of my step's own cell = the cell lane-1 fetched
                                 const int32_t mc = tlet[my_i] == (PK == 2 ? s[my_j - 1] : S.sq[my_j - 1]) ? POA_M : POA_N;
                                 const bool ok = in && my_i != 0 && hcur != 0 && hcur == c + mc;
@@ -2938,14 +2956,15 @@ static const poa_variant k_long_noring = POA_VARIANT(8, 0, 16, 2);      // ... r
 static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
 static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
-// experiments (RATTLE_POA_EXP=<a>,<b>: index into this table for the 1024- and the 1536-column class): fewer, fatter wavefronts
-// per pack -- the per-row fixed cost (scan, exchange, scalar bookkeeping) is paid per wavefront
-// (measured round 2, profiles/README.md: 16 columns x 1 wavefront and 8 / 12 columns x 2 wavefronts are within noise of the
-// defaults in the full benchmark; two of them are kept selectable)
-#ifndef POA_EXP_RING
-#define POA_EXP_RING 8
-#endif
-static const poa_variant k_exp[] = {POA_VARIANT(16, 4, 1, 1), POA_VARIANT(8, POA_EXP_RING, 2, 1), POA_VARIANT(12, POA_EXP_RING, 2, 1)};
+// experiments (RATTLE_POA_EXP=<a>,<b>,<c>,<d>: index into the candidate table of the 1024- / 1536- / 2048- / 2560-column class; -1 or
+// absent: the default): the skewed wavefront pipeline (dp_rows_sk) with the record words (PK 5) or the ready-made terms (PK 6) in
+// its ring, on 2 / 4 / 8 wavefronts
+#define POA_EXP_MAX 6
+static const poa_variant k_exp[4][POA_EXP_MAX] = {
+    {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(2, 8, 8, 5), POA_VARIANT(8, 8, 2, 6)},
+    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 8, 4, 5)},
+    {POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5)},
+    {POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 6), POA_VARIANT(10, 4, 4, 6), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5)}};
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -3044,11 +3063,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         C[c].todo = by_class[c];
         C[c].V = &k_latency[poa_group_class(c)];
         if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
-        if (c < 2 && getenv("RATTLE_POA_EXP")) {
-            int a = -1, b = -1;
-            sscanf(getenv("RATTLE_POA_EXP"), "%d,%d", &a, &b);
-            const int pick = c == 0 ? a : b;
-            if (pick >= 0 && pick < (int)(sizeof(k_exp) / sizeof(k_exp[0])) && 64u * k_exp[pick].nw * k_exp[pick].cpl >= k_class_cols[c]) C[c].V = &k_exp[pick];
+        if (c < 4 && getenv("RATTLE_POA_EXP")) {
+            int pick[4] = {-1, -1, -1, -1};
+            sscanf(getenv("RATTLE_POA_EXP"), "%d,%d,%d,%d", &pick[0], &pick[1], &pick[2], &pick[3]);
+            if (pick[c] >= 0 && pick[c] < POA_EXP_MAX) C[c].V = &k_exp[c][pick[c]];
         }
         if (c < 3 && getenv("RATTLE_POA_UNPACKED")) C[c].V = &k_unpacked[c];
     }
@@ -3077,7 +3095,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
         A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16);
         const uint64_t cell_bytes = long_rows ? 4 : 2;
-        if (P.V->pk == 1) {                // H words carry F's two bits, E's two bits per column sit in a per-thread array
+        if (pk_packed(P.V->pk)) {          // H words carry F's two bits, E's two bits per column sit in a per-thread array
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(0);      // E is rebuilt on demand by the traceback
         } else if (P.V->pk == 0 || P.V->pk == 3) {   // H int16 plus a nibble per column (min(H-F,3), min(H-E,3))
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(((uint64_t)ncap + 2) * 64 * P.V->nw * ((cpl + 7) / 8) * 4);
@@ -3089,7 +3107,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         auto lds_bytes = [&](const poa_variant *V) {
-            const size_t cell = V->pk != 1 && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE)
+            const size_t cell = pk_readymade(V->pk) ? 4 : !pk_packed(V->pk) && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE; ready-made terms)
             return (size_t)lds_seq + ((size_t)poa_bit_words(ncap) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 4 * std::max<uint32_t>(4, V->nw) + 64;
         };
         if ((gc == 4 || gc == 5 || gc == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[gc - 4];

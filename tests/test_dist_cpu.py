@@ -195,8 +195,9 @@ def stub_correction(plan, seqs, rank):
     return R, keep
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_correct_reassembles_to_the_unsharded_result(tmp_path, world):
+    """world 8 = the node the BASELINE metric is quoted on: the LPT partition with 8 bins, pack_owner, and the gather order"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, RATTLE_ROOT=ROOT, MASTER_ADDR="127.0.0.1")

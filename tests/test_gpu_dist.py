@@ -1,4 +1,4 @@
-"""ONE job over several ranks with the real kernels: two (and three) processes share the box's single GPU, the
+"""ONE job over several ranks with the real kernels: two, three and eight processes share the box's single GPU, the
 exchange goes through host buffers (gloo) or through exchange.hip's RCCL call path over a file-backed double of
 librccl.so (RCCL wants one GPU per rank, which only the driver's 8-GPU run provides), and every sharded result must equal the unsharded one bit for bit: gene-level clusters (candidate axis),
 `--iso` transcript clusters (gene axis), and the three outputs of `correct` (pack axis, reassembled on rank 0).
@@ -71,7 +71,7 @@ def fake_rccl(tmp_path):
     return {"RATTLE_RCCL_LIB": str(so), "FAKE_RCCL_DIR": str(box)}
 
 
-@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (2, "device"), (3, "device")])
+@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (2, "device"), (3, "device"), (8, "host"), (8, "device")])
 def test_sharded_job_equals_single_gpu(tmp_path, world, transport):
     """transport "host": the caller's all-gather-v on host buffers (gloo); "device": the RCCL code path of exchange.hip
     (sizes all-gather, grouped broadcasts, grouped send / recv to the root) with the file-backed double standing in
@@ -132,6 +132,24 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     assert line["checks"]["digest_equal_to_single_gpu"] and line["checks"]["n_corrected"] + line["checks"]["n_uncorrected"] == 20000
 
 
+def test_bench_eight_ranks_on_one_device():
+    """The driver's 8-GPU command shape (`python bench.py --gpus 8`, BASELINE configs[3]) run once with the eight ranks sharing the
+    box's one GPU: the LPT partition with eight bins, pack_owner, the all-gathers of every greedy round and consensus stage and
+    the gather order all execute, and the sharded result must carry the single-GPU digest.  (No scaling figure: the ranks
+    compete for one device.)"""
+    import json
+    env = dict(os.environ, RATTLE_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--reads", "100000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=1800, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["exchange"]["ranks"] == 8 and line["exchange"]["collectives"] > 0
+    assert line["checks"]["digest_equal_to_single_gpu"] and line["checks"]["digest_equal_across_steps"]
+    assert line["checks"]["n_corrected"] + line["checks"]["n_uncorrected"] == 100000
+
+
 FAIL_WORKER = textwrap.dedent('''
     import os, sys
     import numpy as np
@@ -168,7 +186,7 @@ FAIL_WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_local_failure_reaches_every_rank_instead_of_hanging(tmp_path, world):
     """A bad base in a read that only the last rank's packs hold: that rank must keep joining the exchanges
     (correct_driver.hip: failure record) so that every rank returns an error -- none is left in an all-gather."""
