@@ -284,6 +284,12 @@ struct rattle_ctx {
     hipStream_t poa_st[16] = {};     // one per column class: classes run concurrently
     hipEvent_t poa_ev[16] = {};
     hipEvent_t poa_go = nullptr;
+    // two correction flows on one device (correct_driver.hip): the helper context of the side flow (own streams and arena),
+    // a flag kernel C's host side raises once the kernels of its first pass are launched, and a request to leave a few
+    // workgroup places of the device free (the side flow's POA #3 groups arrive while this flow's persistent workgroups run)
+    rattle_ctx *helper = nullptr;
+    std::atomic<int> *poa_launched = nullptr;
+    int poa_reserve = 0;
     rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns
     // reads staged in HBM by rattle_hip_stage_reads (keys: the host buffers they were copied from)
     const uint8_t *staged_seq_key = nullptr, *staged_qual_key = nullptr;
@@ -305,6 +311,7 @@ struct rattle_ctx {
         if (device < 0) return;                 // host-only context: nothing on a device
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
+        if (helper) { delete helper; helper = nullptr; }
         if (poa_arena) (void)hipFree(poa_arena);
         for (int i = 0; i < 16; ++i) { if (poa_st[i]) (void)hipStreamDestroy(poa_st[i]); if (poa_ev[i]) (void)hipEventDestroy(poa_ev[i]); }
         if (poa_go) (void)hipEventDestroy(poa_go);

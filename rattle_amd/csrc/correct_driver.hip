@@ -320,14 +320,50 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     std::vector<uint32_t> mine;
     for (uint32_t p = 0; p < n_packs; ++p) if ((int)PL.pk_owner[p] == rank) mine.push_back(p);
     const uint32_t nm = (uint32_t)mine.size();
-    stage S1;
-    S1.first.assign(1, 0);
-    std::vector<sref> S1r;
-    for (uint32_t p : mine) {
-        for (uint32_t q = PL.first[p]; q < PL.first[p + 1]; ++q) S1r.push_back(PL.members[q]);
-        S1.first.push_back((uint32_t)S1r.size());
+
+    // ---- POA #2 over the corrected reads of a pack, stably sorted by length desc (:427-445), + consensus vote;
+    // per-cluster consensus (:489-556) with POA #3 for clusters of more than one pack.
+    // A POA #3 group is sequential in its number of packs, so the clusters with many packs would leave the
+    // device to one workgroup each at the end.  When there are enough of them, their packs go through
+    // POA #2 first (stage 2a) and their POA #3 (stage 3a) runs beside other work; the remaining small POA #3 groups
+    // follow (stage 3b).  With several ranks each stage covers this rank's packs / groups and ends with an all-gather of
+    // its consensi.
+    // (RATTLE_BIG_CLUSTER_PACKS / RATTLE_BIG_MIN_PACKS override the two thresholds: tests force the split on small inputs)
+    const uint32_t BIG = std::max(2, getenv("RATTLE_BIG_CLUSTER_PACKS") ? atoi(getenv("RATTLE_BIG_CLUSTER_PACKS")) : 48);
+    const uint64_t big_min = getenv("RATTLE_BIG_MIN_PACKS") ? (uint64_t)atoll(getenv("RATTLE_BIG_MIN_PACKS")) : 1024;
+    std::vector<uint8_t> big(n_clusters, 0);
+    bool any_big = false;
+    {
+        uint64_t big_packs = 0;
+        for (uint32_t c = 0; c < n_clusters; ++c) if (PL.cl_np[c] >= BIG) big_packs += PL.cl_np[c];
+        if (big_packs >= big_min) for (uint32_t c = 0; c < n_clusters; ++c) { big[c] = PL.cl_np[c] >= BIG; any_big |= big[c] != 0; }
     }
-    const uint32_t n1 = (uint32_t)S1r.size();
+    // Round 4: the chain of the big clusters -- POA #1 of their packs, POA #2 of their packs (2a), POA #3 (3a: hundreds of pack
+    // consensi aligned one after the other by ONE workgroup) -- is 1.3 s of mostly idle device at 1e6 reads when the stages
+    // follow each other.  So stage 1 runs in two groups: group 0 = the packs of the big clusters, first and alone; then their
+    // 2a -> 3a chain runs on a helper context (own streams, own arena, a second host thread) BESIDE the POA #1 of group 1
+    // (everything else), which is long enough to hide it.  2a is launched before group 1's POA #1 so that its many short
+    // workgroups take the device first and hand their places over as they finish; group 1's persistent workgroups leave a few
+    // places free (poa_reserve) for the handful of workgroups 3a needs later.  One rank only: with several ranks the stages end in
+    // collectives and keep their order.  RATTLE_CORRECT_OVERLAP=0 restores the sequential flow (same results: tests compare).
+    const bool overlap = any_big && nranks == 1 && !(getenv("RATTLE_CORRECT_OVERLAP") && atoi(getenv("RATTLE_CORRECT_OVERLAP")) == 0);
+    struct s1group {
+        stage S;
+        std::vector<sref> r;                         // the group's pack members, pack after pack
+        std::vector<uint32_t> ks;                    // index in `mine` of each of its packs
+        std::vector<uint32_t> olen, tfront, tback;   // per member
+    } G[2];
+    std::vector<uint8_t> g_of(nm, 1);
+    std::vector<uint32_t> k_in(nm, 0);
+    for (int g = 0; g < 2; ++g) G[g].S.first.assign(1, 0);
+    for (uint32_t k = 0; k < nm; ++k) {
+        const uint32_t p = mine[k];
+        const int g = overlap && big[PL.pk_cid[p]] ? 0 : 1;
+        g_of[k] = (uint8_t)g; k_in[k] = (uint32_t)G[g].ks.size();
+        G[g].ks.push_back(k);
+        for (uint32_t q = PL.first[p]; q < PL.first[p + 1]; ++q) G[g].r.push_back(PL.members[q]);
+        G[g].S.first.push_back((uint32_t)G[g].r.size());
+    }
 
     // Several ranks: everything up to here depends on the arguments alone (the same on every rank).  From here on a rank
     // works on its own packs, and a failure of its own (a bad base in one of ITS reads, a HIP error, an allocation) must not
@@ -348,11 +384,15 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         ok['A'] = ok['C'] = ok['G'] = ok['T'] = ok['U'] = true;
         std::atomic<int> bad(0);
         const size_t chunk = 4096;
-        parallel_for((n1 + chunk - 1) / chunk, P->n_threads, [&](size_t c) {
-            for (size_t q = c * chunk; q < std::min<size_t>(n1, (c + 1) * chunk); ++q)
-                for (uint64_t b = off[S1r[q].rid]; b < off[S1r[q].rid + 1]; ++b)
-                    if (!ok[seq[b]]) { bad = 1; return; }
-        });
+        for (int g = 0; g < 2; ++g) {
+            const std::vector<sref> &R1 = G[g].r;
+            const size_t n1g = R1.size();
+            parallel_for((n1g + chunk - 1) / chunk, P->n_threads, [&](size_t c) {
+                for (size_t q = c * chunk; q < std::min<size_t>(n1g, (c + 1) * chunk); ++q)
+                    for (uint64_t b = off[R1[q].rid]; b < off[R1[q].rid + 1]; ++b)
+                        if (!ok[seq[b]]) { bad = 1; return; }
+            });
+        }
         if (bad) {
             set_error("correct: read contains a base other than A, C, G, T, U");
             if (nranks == 1) return RATTLE_ERR_ARG;
@@ -379,7 +419,6 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
     }
 
-    std::vector<uint32_t> olen(n1 + 1, 0), tfront(n1 + 1, 0), tback(n1 + 1, 0);
     std::vector<uint8_t> pk_dead(n_packs, 0);       // stage at which a pack was given up (this rank's packs: exact; others: from the exchange)
     std::vector<std::string> pk_cons(n_packs);       // pack consensus (POA #2), filled for every pack by the exchanges
     std::vector<uint8_t> pk_has(n_packs, 0);
@@ -391,11 +430,11 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     struct joiner { std::thread &t; ~joiner() { if (t.joinable()) t.join(); } } d2h_join{d2h};      // also on error returns
     std::vector<uint32_t> cor_pack;
 
-    auto stage1 = [&]() -> int {
-        // ---- reads -> HBM, oriented pack members gathered into stage 1 (:343-346)
+    // ---- reads -> HBM once (both groups gather from them)
+    dbuf<uint8_t> d_rseq, d_rqual;
+    const uint8_t *dev_seq = nullptr, *dev_qual = nullptr;
+    auto upload_reads = [&]() -> int {
         const uint64_t total_in = off[n_reads];
-        dbuf<uint8_t> d_rseq, d_rqual;
-        const uint8_t *dev_seq, *dev_qual;
         if (ctx->staged_seq_key == seq && ctx->staged_qual_key == qual && ctx->staged_n == n_reads && ctx->staged_total == total_in && off[0] == 0) {
             dev_seq = ctx->d_staged_seq.p; dev_qual = ctx->d_staged_qual.p;       // resident (rattle_hip_stage_reads)
         } else {
@@ -405,66 +444,91 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             RT_HIP(hipMemcpyAsync(d_rqual.p, qual, total_in, hipMemcpyHostToDevice, st));
             dev_seq = d_rseq.p; dev_qual = d_rqual.p;
         }
+        return 0;
+    };
+    // ---- stage 1 of one group: oriented pack members gathered (:343-346), POA #1 (correct.cpp:398-405) + fix ends +
+    // correction (:407-409); lengths back to the host
+    auto stage1_group = [&](int g, uint64_t *cnt) -> int {
+        s1group &X = G[g];
+        const uint32_t n1 = (uint32_t)X.r.size();
+        X.olen.assign(n1 + 1, 0); X.tfront.assign(n1 + 1, 0); X.tback.assign(n1 + 1, 0);
+        if (X.ks.empty()) return 0;
         std::vector<gather_desc> desc(n1);
-        S1.off.assign(n1 + 1, 0);
+        X.S.off.assign(n1 + 1, 0);
         for (uint32_t q = 0; q < n1; ++q) {
-            const uint32_t len = (uint32_t)(off[S1r[q].rid + 1] - off[S1r[q].rid]);
-            desc[q] = gather_desc{off[S1r[q].rid], S1.off[q], len, S1r[q].rev};
-            S1.off[q + 1] = S1.off[q] + len;
+            const uint32_t len = (uint32_t)(off[X.r[q].rid + 1] - off[X.r[q].rid]);
+            desc[q] = gather_desc{off[X.r[q].rid], X.S.off[q], len, X.r[q].rev};
+            X.S.off[q + 1] = X.S.off[q] + len;
         }
-        // ---- POA #1 (correct.cpp:398-405) + fix ends + correction (:407-409)
-        {
-            phase_timer T("correct: stage 1");
-            RT_TRY(run_stage(ctx, S1, desc, {gather_part{0, n1, dev_seq, dev_qual}}, 1, P, order, counters));
-            RT_HIP(hipMemcpyAsync(olen.data(), S1.olen.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipMemcpyAsync(tfront.data(), S1.tfront.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipMemcpyAsync(tback.data(), S1.tback.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
-            RT_HIP(hipStreamSynchronize(st));
-        }
-        d_rseq.release(); d_rqual.release();
-        S1.seq.release(); S1.qual.release(); S1.col.release();
-        for (uint32_t k = 0; k < nm; ++k)
-            if (S1.skipped[k]) {                      // POA #1 did not fit: the pack's reads stay as they are
-                pk_dead[mine[k]] = 1;
-                skips.push_back(skip_t{PL.pk_cid[mine[k]], PL.pk_local[mine[k]], 1u, {}});
-                for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) { skips.back().rids.push_back(S1r[q].rid); olen[q] = 0; tfront[q] = 0; tback[q] = 0; }
+        phase_timer T(g == 0 ? "correct: stage 1 (big clusters)" : "correct: stage 1");
+        RT_TRY(run_stage(ctx, X.S, desc, {gather_part{0, n1, dev_seq, dev_qual}}, 1, P, order, cnt));
+        RT_HIP(hipMemcpyAsync(X.olen.data(), X.S.olen.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipMemcpyAsync(X.tfront.data(), X.S.tfront.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipMemcpyAsync(X.tback.data(), X.S.tback.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+        RT_HIP(hipStreamSynchronize(st));
+        X.S.seq.release(); X.S.qual.release(); X.S.col.release();
+        for (uint32_t kk = 0; kk < X.ks.size(); ++kk)
+            if (X.S.skipped[kk]) {                    // POA #1 did not fit: the pack's reads stay as they are
+                pk_dead[mine[X.ks[kk]]] = 1;
+                for (uint32_t q = X.S.first[kk]; q < X.S.first[kk + 1]; ++q) { X.olen[q] = 0; X.tfront[q] = 0; X.tback[q] = 0; }
             }
-
-        // ---- corrected reads in pack order (:413-425): compacted on the device, one download
+        return 0;
+    };
+    // ---- after both groups: skip entries, corrected reads in pack order (:413-425) compacted on the device and downloaded
+    // behind the later stages, reads whose corrected sequence came out empty
+    auto stage1_finish = [&]() -> int {
+        for (uint32_t k = 0; k < nm; ++k) {
+            const s1group &X = G[g_of[k]];
+            const uint32_t kk = k_in[k];
+            if (!X.S.skipped[kk]) continue;
+            skips.push_back(skip_t{PL.pk_cid[mine[k]], PL.pk_local[mine[k]], 1u, {}});
+            for (uint32_t q = X.S.first[kk]; q < X.S.first[kk + 1]; ++q) skips.back().rids.push_back(X.r[q].rid);
+        }
         {
             phase_timer T("correct: corrected reads D2H");
-            std::vector<gather_desc> od;
-            std::vector<uint32_t> oq;
+            std::vector<gather_desc> od[2];
+            std::vector<int32_t> o_rid, o_cid;
             uint64_t tot = 0;
-            for (uint32_t k = 0; k < nm; ++k)
-                for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) {
-                    if (olen[q] == 0) continue;
-                    od.push_back(gather_desc{S1.moff[k] + (uint64_t)(q - S1.first[k]) * S1.width[k], tot, olen[q], 0u});
-                    oq.push_back(q);
-                    tot += olen[q];
+            for (uint32_t k = 0; k < nm; ++k) {
+                const int g = g_of[k];
+                const s1group &X = G[g];
+                const uint32_t kk = k_in[k];
+                for (uint32_t q = X.S.first[kk]; q < X.S.first[kk + 1]; ++q) {
+                    if (X.olen[q] == 0) continue;
+                    od[g].push_back(gather_desc{X.S.moff[kk] + (uint64_t)(q - X.S.first[kk]) * X.S.width[kk], tot, X.olen[q], 0u});
+                    o_rid.push_back(X.r[q].rid); o_cid.push_back(PL.pk_cid[mine[k]]);
+                    cor_pack.push_back(mine[k]);
+                    tot += X.olen[q];
                 }
+            }
             rattle_read_set &C = R->corrected;
-            const size_t nc = od.size();
+            const size_t nc = o_rid.size();
             C.n = (uint32_t)nc;
             C.read_id = (int32_t *)malloc(std::max<size_t>(1, nc) * 4); C.cluster_id = (int32_t *)malloc(std::max<size_t>(1, nc) * 4);
             C.n_reads = (int32_t *)malloc(std::max<size_t>(1, nc) * 4); C.off = (uint64_t *)malloc((nc + 1) * 8);
             C.seq = (char *)malloc(tot + 1); C.qual = (char *)malloc(tot + 1);
             C.seq[tot] = 0; C.qual[tot] = 0;
-            cor_pack.resize(nc);
-            uint32_t k = 0;
-            for (size_t i = 0; i < nc; ++i) {
-                while (oq[i] >= S1.first[k + 1]) ++k;
-                C.read_id[i] = S1r[oq[i]].rid; C.cluster_id[i] = PL.pk_cid[mine[k]]; C.n_reads[i] = 0; C.off[i] = od[i].dst;
-                cor_pack[i] = mine[k];
+            {
+                // offsets in output order: the two groups' descriptors interleave by pack, so walk them by destination
+                size_t ia = 0, ib = 0;
+                for (size_t i = 0; i < nc; ++i) {
+                    const bool from_a = ia < od[0].size() && (ib >= od[1].size() || od[0][ia].dst < od[1][ib].dst);
+                    C.off[i] = from_a ? od[0][ia++].dst : od[1][ib++].dst;
+                    C.read_id[i] = o_rid[i]; C.cluster_id[i] = o_cid[i]; C.n_reads[i] = 0;
+                }
             }
             C.off[nc] = tot;
             if (nc) {
-                dbuf<gather_desc> d_od;
-                RT_TRY(d_od.reserve(nc)); RT_TRY(d_os.reserve(tot + 64)); RT_TRY(d_oq.reserve(tot + 64));
-                RT_HIP(hipMemcpyAsync(d_od.p, od.data(), nc * sizeof(gather_desc), hipMemcpyHostToDevice, st));
-                RT_TRY(launch_gather(ctx, d_od.p, (uint32_t)nc, S1.rowc.p, S1.rowq.p, d_os.p, d_oq.p));
-                RT_HIP(hipStreamSynchronize(st));
-                d_od.release();
+                RT_TRY(d_os.reserve(tot + 64)); RT_TRY(d_oq.reserve(tot + 64));
+                for (int g = 0; g < 2; ++g) {
+                    if (od[g].empty()) continue;
+                    dbuf<gather_desc> d_od;
+                    RT_TRY(d_od.reserve(od[g].size()));
+                    RT_HIP(hipMemcpyAsync(d_od.p, od[g].data(), od[g].size() * sizeof(gather_desc), hipMemcpyHostToDevice, st));
+                    RT_TRY(launch_gather(ctx, d_od.p, (uint32_t)od[g].size(), G[g].S.rowc.p, G[g].S.rowq.p, d_os.p, d_oq.p));
+                    RT_HIP(hipStreamSynchronize(st));
+                    d_od.release();
+                }
                 // the download (2 GB at 1e6 reads, pageable destination) runs on a helper thread and the
                 // copy engine while the following POA stages compute
                 char *dst_s = C.seq, *dst_q = C.qual;
@@ -485,52 +549,21 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             }
         }
         // reads whose corrected sequence came out empty: uncorrected, as fix_msa_ends left them (:289-293)
-        for (uint32_t k = 0; k < nm; ++k)
-            for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q)
-                if (olen[q] == 0) {
-                    uncorrected.push_back(oriented_read(seq, qual, off, S1r[q], tfront[q], tback[q]));
+        for (uint32_t k = 0; k < nm; ++k) {
+            const s1group &X = G[g_of[k]];
+            const uint32_t kk = k_in[k];
+            for (uint32_t q = X.S.first[kk]; q < X.S.first[kk + 1]; ++q)
+                if (X.olen[q] == 0) {
+                    uncorrected.push_back(oriented_read(seq, qual, off, X.r[q], X.tfront[q], X.tback[q]));
                     unc_cid.push_back(PL.pk_cid[mine[k]]); unc_pack.push_back(mine[k]);
                 }
+        }
         return 0;
     };
-    if (nm) LOCAL_TRY(stage1());
-    if (!nm || local_rc) {
-        if (d2h.joinable()) d2h.join();
-        if (R->corrected.off) { rattle_read_set &C = R->corrected; free(C.read_id); free(C.cluster_id); free(C.n_reads); free(C.off); free(C.seq); free(C.qual); C = rattle_read_set(); }
-        fill_set(R->corrected, {}, {}, {});
-        cor_pack.clear();
-    }
 
-    // ---- POA #2 over the corrected reads of a pack, stably sorted by length desc (:427-445), + consensus vote;
-    // per-cluster consensus (:489-556) with POA #3 for clusters of more than one pack.
-    // A POA #3 group is sequential in its number of packs, so the clusters with many packs would leave the
-    // device to one workgroup each at the end.  When there are enough of them, their packs go through
-    // POA #2 first (stage 2a) and their POA #3 shares a pass with the POA #2 of everything else
-    // (stage 2b+3a); the remaining small POA #3 groups follow (stage 3b).  With several ranks each stage
-    // covers this rank's packs / groups and ends with an all-gather of its consensi.
-    // (RATTLE_BIG_CLUSTER_PACKS / RATTLE_BIG_MIN_PACKS override the two thresholds: tests force the split on small inputs)
-    const uint32_t BIG = std::max(2, getenv("RATTLE_BIG_CLUSTER_PACKS") ? atoi(getenv("RATTLE_BIG_CLUSTER_PACKS")) : 48);
-    const uint64_t big_min = getenv("RATTLE_BIG_MIN_PACKS") ? (uint64_t)atoll(getenv("RATTLE_BIG_MIN_PACKS")) : 1024;
-    std::vector<uint8_t> big(n_clusters, 0);
-    {
-        uint64_t big_packs = 0;
-        for (uint32_t c = 0; c < n_clusters; ++c) if (PL.cl_np[c] >= BIG) big_packs += PL.cl_np[c];
-        if (big_packs >= big_min) for (uint32_t c = 0; c < n_clusters; ++c) big[c] = PL.cl_np[c] >= BIG;
-    }
     std::vector<uint32_t> slot_of(n_packs, 0xFFFFFFFFu);   // my pack -> index in `mine`
     for (uint32_t k = 0; k < nm; ++k) slot_of[mine[k]] = k;
 
-    std::vector<uint32_t> rows;
-    auto add_pack2 = [&](stage &S, std::vector<gather_desc> &d, uint32_t k) {       // my pack k's corrected reads, length-sorted
-        rows.clear();
-        for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) if (olen[q]) rows.push_back(q);
-        std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return olen[a] > olen[b]; });
-        for (uint32_t q : rows) {
-            d.push_back(gather_desc{S1.moff[k] + (uint64_t)(q - S1.first[k]) * S1.width[k], S.off.back(), olen[q], 0u});
-            S.off.push_back(S.off.back() + olen[q]);
-        }
-        S.first.push_back((uint32_t)S.off.size() - 1);
-    };
     // the live packs of a cluster in the order their consensi enter POA #3
     auto group_of = [&](uint32_t c, std::vector<uint32_t> &g) {
         g.clear();
@@ -566,16 +599,17 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
         return 0;
     };
-    // POA #2 over a list of my packs (slots in `mine`) + POA #3 over a list of clusters (groups of pack consensi
-    // from the host) in one device pass; results into `bytes`
-    auto cons_pass = [&](const char *name, const std::vector<uint32_t> &slots2, const std::vector<uint32_t> &clusters3, std::vector<uint8_t> &bytes) -> int {
+    // POA #2 over a list of my packs (indices in `mine`, all of ONE stage-1 group) + POA #3 over a list of clusters (groups of pack
+    // consensi from the host) in one device pass on context `cx`; results into `bytes`, skipped packs into `sk`, work counters into `cnt`
+    auto cons_pass = [&](rattle_ctx *cx, const char *name, const std::vector<uint32_t> &slots2, const std::vector<uint32_t> &clusters3,
+                         std::vector<uint8_t> &bytes, std::vector<skip_t> &sk, uint64_t *cnt) -> int {
         if (slots2.empty() && clusters3.empty()) return 0;
         phase_timer T(name);
         cons_stage C;
         stage &S = C.S;
         std::vector<gather_desc> d;
         S.first.assign(1, 0); S.off.assign(1, 0);
-        std::vector<uint32_t> g;
+        std::vector<uint32_t> g, rows;
         for (uint32_t c : clusters3) {
             group_of(c, g);
             for (uint32_t p : g) {
@@ -586,47 +620,46 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             S.first.push_back((uint32_t)S.off.size() - 1);
         }
         const uint32_t n3 = (uint32_t)d.size();
-        for (uint32_t k : slots2) add_pack2(S, d, k);
+        const s1group *X = slots2.empty() ? nullptr : &G[g_of[slots2[0]]];
+        for (uint32_t k : slots2) {                  // my pack k's corrected reads, length-sorted
+            const uint32_t kk = k_in[k];
+            rows.clear();
+            for (uint32_t q = X->S.first[kk]; q < X->S.first[kk + 1]; ++q) if (X->olen[q]) rows.push_back(q);
+            std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return X->olen[a] > X->olen[b]; });
+            for (uint32_t q : rows) {
+                d.push_back(gather_desc{X->S.moff[kk] + (uint64_t)(q - X->S.first[kk]) * X->S.width[kk], S.off.back(), X->olen[q], 0u});
+                S.off.push_back(S.off.back() + X->olen[q]);
+            }
+            S.first.push_back((uint32_t)S.off.size() - 1);
+        }
         dbuf<uint8_t> d_in;
         RT_TRY(d_in.reserve(C.h_in.size() + 64));
-        if (!C.h_in.empty()) RT_HIP(hipMemcpyAsync(d_in.p, C.h_in.data(), C.h_in.size(), hipMemcpyHostToDevice, st));
-        RT_TRY(run_stage(ctx, S, d, {gather_part{0, n3, d_in.p, nullptr}, gather_part{n3, (uint32_t)d.size() - n3, S1.rowc.p, nullptr}}, 2, P, order, counters));
-        RT_TRY(fetch_consensi(ctx, C));
+        if (!C.h_in.empty()) RT_HIP(hipMemcpyAsync(d_in.p, C.h_in.data(), C.h_in.size(), hipMemcpyHostToDevice, cx->stream));
+        RT_TRY(run_stage(cx, S, d, {gather_part{0, n3, d_in.p, nullptr}, gather_part{n3, (uint32_t)d.size() - n3, X ? X->S.rowc.p : nullptr, nullptr}}, 2, P, order, cnt));
+        RT_TRY(fetch_consensi(cx, C));
         uint32_t slot = 0;
         for (uint32_t c : clusters3) {
             if (S.skipped[slot]) {
-                skips.push_back(skip_t{(int32_t)c, 0u, 3u, {}});
+                sk.push_back(skip_t{(int32_t)c, 0u, 3u, {}});
                 put_rec(bytes, c, 1u | (3u << 1), nullptr, 0);
             } else put_rec(bytes, c, 1u, (const char *)C.cons.data() + S.coff[slot], C.len[slot]);
             ++slot;
         }
         for (uint32_t k : slots2) {
-            const uint32_t p = mine[k];
+            const uint32_t p = mine[k], kk = k_in[k];
             if (S.skipped[slot]) {
-                skips.push_back(skip_t{PL.pk_cid[p], PL.pk_local[p], 2u, {}});
-                for (uint32_t q = S1.first[k]; q < S1.first[k + 1]; ++q) skips.back().rids.push_back(S1r[q].rid);
+                sk.push_back(skip_t{PL.pk_cid[p], PL.pk_local[p], 2u, {}});
+                for (uint32_t q = X->S.first[kk]; q < X->S.first[kk + 1]; ++q) sk.back().rids.push_back(X->r[q].rid);
                 put_rec(bytes, p, 2u << 1, nullptr, 0);
             } else put_rec(bytes, p, 0u, (const char *)C.cons.data() + S.coff[slot], C.len[slot]);
             ++slot;
         }
         return 0;
     };
-
-    {
-        std::vector<uint8_t> bytes;
-        // packs given up in stage 1 are announced with the first exchange
-        for (uint32_t k = 0; k < nm; ++k) if (pk_dead[mine[k]] == 1) put_rec(bytes, mine[k], 1u << 1, nullptr, 0);
-        // stage 2a: my packs of the big clusters
-        std::vector<uint32_t> s2a, s2b;
-        for (uint32_t k = 0; k < nm; ++k) if (!pk_dead[mine[k]]) (big[PL.pk_cid[mine[k]]] ? s2a : s2b).push_back(k);
-        LOCAL_TRY(cons_pass("correct: stage 2a", s2a, {}, bytes));
-        bool any_big = false;
-        for (uint32_t c = 0; c < n_clusters; ++c) any_big |= big[c] != 0;
-        if (any_big) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
-        // stage 2b+3a: POA #3 groups of the big clusters (LPT over ranks), then my packs of all other clusters
-        std::vector<uint32_t> g3a_all, g3a;
+    // the POA #3 groups of the big clusters that fall to this rank (LPT over ranks), once their pack consensi are in
+    auto big_groups = [&](std::vector<uint32_t> &g3a) {
+        std::vector<uint32_t> g3a_all, own, g;
         std::vector<uint64_t> cost;
-        std::vector<uint32_t> own, g;
         for (uint32_t c = 0; c < n_clusters; ++c) {
             if (!big[c]) continue;
             group_of(c, g);
@@ -635,18 +668,100 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
         lpt_assign(cost, nranks, own);
         for (size_t i = 0; i < g3a_all.size(); ++i) if ((int)own[i] == rank) g3a.push_back(g3a_all[i]);
-        LOCAL_TRY(cons_pass("correct: stage 2b+3a", s2b, g3a, bytes));
-        RT_TRY(exchange_stage(bytes)); bytes.clear();
-        if (d2h.joinable()) d2h.join();                  // S1.rowc is no longer needed once the download is done
+    };
+
+    uint64_t cnt_main[8] = {0}, cnt_side[8] = {0};
+    std::vector<skip_t> sk_2a, sk_3a, sk_2b, sk_3b;
+    std::vector<uint8_t> bytes_2a, bytes_3a, bytes_2b, bytes_3b;
+    if (nm) LOCAL_TRY(upload_reads());
+    if (overlap) {
+        // ---- group 0 alone, then its chain on the helper context beside group 1
+        if (nm) LOCAL_TRY(stage1_group(0, cnt_main));
+        std::vector<uint32_t> s2a;
+        for (uint32_t k : G[0].ks) if (!pk_dead[mine[k]]) s2a.push_back(k);
+        int side_rc = 0;
+        std::string side_msg;
+        std::thread side;
+        std::atomic<int> side_launched(0);
+        if (local_rc == 0 && !s2a.empty()) {
+            if (!ctx->helper) LOCAL_TRY(rattle_hip_ctx_create(ctx->device, &ctx->helper));
+            rattle_ctx *hx = ctx->helper;
+            if (local_rc == 0) {
+                hx->timing = ctx->timing;
+                hx->poa_launched = &side_launched;
+                side = std::thread([&, hx]() {
+                    auto fail = [&](int r) { side_rc = r; side_msg = rattle_hip_last_error(); side_launched = 1; };
+                    if (hipSetDevice(hx->device) != hipSuccess) { set_error("helper flow: hipSetDevice failed"); fail(RATTLE_ERR_HIP); return; }
+                    int r = ensure_post_constants(hx);
+                    if (r == 0) r = cons_pass(hx, "correct: stage 2a (beside stage 1)", s2a, {}, bytes_2a, sk_2a, cnt_side);
+                    side_launched = 1;               // (also when 2a had nothing to launch)
+                    if (r) { fail(r); return; }
+                    std::vector<uint8_t> b2a = bytes_2a;
+                    r = exchange_stage(b2a);         // one rank: takes the pack consensi in
+                    std::vector<uint32_t> g3a;
+                    if (r == 0) { big_groups(g3a); r = cons_pass(hx, "correct: stage 3a (beside stage 1)", {}, g3a, bytes_3a, sk_3a, cnt_side); }
+                    if (r) fail(r);
+                });
+                // group 1's persistent workgroups would take every place of the device: 2a's launches go first
+                while (!side_launched) std::this_thread::yield();
+                hx->poa_launched = nullptr;
+            }
+        }
+        struct side_joiner { std::thread &t; ~side_joiner() { if (t.joinable()) t.join(); } } sj{side};
+        ctx->poa_reserve = side.joinable() ? 1 : 0;      // leave a few places for 3a's workgroups
+        if (nm) LOCAL_TRY(stage1_group(1, cnt_main));
+        ctx->poa_reserve = 0;
+        if (side.joinable()) side.join();
+        if (ctx->helper) {                           // the helper's kernel times belong to this call
+            for (int i = 0; i < K_COUNT; ++i) {
+                ctx->stats[i].ms += ctx->helper->stats[i].ms; ctx->stats[i].launches += ctx->helper->stats[i].launches; ctx->stats[i].bytes += ctx->helper->stats[i].bytes;
+                ctx->helper->stats[i] = kstat();
+            }
+        }
+        if (side_rc) { set_error(side_msg); return side_rc; }      // one rank (overlap is off otherwise)
+        if (nm) LOCAL_TRY(stage1_finish());
+        d_rseq.release(); d_rqual.release();
+        std::vector<uint32_t> s2b;
+        for (uint32_t k : G[1].ks) if (!pk_dead[mine[k]]) s2b.push_back(k);
+        LOCAL_TRY(cons_pass(ctx, "correct: stage 2b", s2b, {}, bytes_2b, sk_2b, cnt_main));
+        std::vector<uint8_t> bytes(bytes_3a);
+        bytes.insert(bytes.end(), bytes_2b.begin(), bytes_2b.end());
+        RT_TRY(exchange_stage(bytes));
+    } else {
+        if (nm) LOCAL_TRY(stage1_group(1, cnt_main));
+        if (nm && local_rc == 0) LOCAL_TRY(stage1_finish());
+        d_rseq.release(); d_rqual.release();
+        std::vector<uint8_t> bytes;
+        // packs given up in stage 1 are announced with the first exchange
+        for (uint32_t k = 0; k < nm; ++k) if (pk_dead[mine[k]] == 1) put_rec(bytes, mine[k], 1u << 1, nullptr, 0);
+        // stage 2a: my packs of the big clusters
+        std::vector<uint32_t> s2a, s2b;
+        for (uint32_t k = 0; k < nm; ++k) if (!pk_dead[mine[k]]) (big[PL.pk_cid[mine[k]]] ? s2a : s2b).push_back(k);
+        LOCAL_TRY(cons_pass(ctx, "correct: stage 2a", s2a, {}, bytes, sk_2a, cnt_main));
+        if (any_big) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
+        // stage 2b+3a: POA #3 groups of the big clusters (LPT over ranks), then my packs of all other clusters
+        std::vector<uint32_t> g3a;
+        big_groups(g3a);
+        LOCAL_TRY(cons_pass(ctx, "correct: stage 2b+3a", s2b, g3a, bytes, sk_3a, cnt_main));
+        RT_TRY(exchange_stage(bytes));
+    }
+    if (!nm || local_rc) {
+        if (d2h.joinable()) d2h.join();
+        if (R->corrected.off) { rattle_read_set &C = R->corrected; free(C.read_id); free(C.cluster_id); free(C.n_reads); free(C.off); free(C.seq); free(C.qual); C = rattle_read_set(); }
+        fill_set(R->corrected, {}, {}, {});
+        cor_pack.clear();
+    }
+    {
+        if (d2h.joinable()) d2h.join();                  // the stage-1 rows are no longer needed once the download is done
         if (d2h_err != hipSuccess) {
             set_error(std::string("corrected reads download: ") + hipGetErrorString(d2h_err));
             if (nranks == 1) return RATTLE_ERR_HIP;
             local_step(RATTLE_ERR_HIP);
         }
-        S1.release();
+        G[0].S.release(); G[1].S.release();
         // stage 3b: POA #3 of the other clusters with more than one live pack
-        std::vector<uint32_t> g3b_all, g3b;
-        cost.clear();
+        std::vector<uint32_t> g3b_all, g3b, own, g;
+        std::vector<uint64_t> cost;
         for (uint32_t c = 0; c < n_clusters; ++c) {
             if (big[c] || PL.cl_np[c] == 0) continue;
             group_of(c, g);
@@ -655,11 +770,15 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
         lpt_assign(cost, nranks, own);
         for (size_t i = 0; i < g3b_all.size(); ++i) if ((int)own[i] == rank) g3b.push_back(g3b_all[i]);
-        LOCAL_TRY(cons_pass("correct: stage 3b", {}, g3b, bytes));
+        LOCAL_TRY(cons_pass(ctx, "correct: stage 3b", {}, g3b, bytes_3b, sk_3b, cnt_main));
         // several ranks: this exchange always takes place, so that every rank leaves with the same verdict (the caller's
         // next collective is the gather of the corrected reads)
-        if (!g3b_all.empty() || nranks > 1) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
+        if (!g3b_all.empty() || nranks > 1) RT_TRY(exchange_stage(bytes_3b));
     }
+    // skipped packs of the consensus stages in the order the sequential flow meets them: 2a, then 3a before 2b (one pass), then 3b
+    for (std::vector<skip_t> *v : {&sk_2a, &sk_3a, &sk_2b, &sk_3b}) for (skip_t &x : *v) skips.push_back(std::move(x));
+    counters[0] += cnt_main[0] + cnt_side[0];
+    counters[1] += cnt_main[1] + cnt_side[1];
     if (d2h.joinable()) d2h.join();
     d_os.release(); d_oq.release();
 #undef LOCAL_TRY

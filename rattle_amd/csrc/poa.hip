@@ -1340,7 +1340,8 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     constexpr int NT = 64 * NW, NP = CPL / 2;
     constexpr int RW = FMT ? 2 * NP : NP;         // ring dwords per thread and row
     constexpr uint32_t D = SK_D, KEEP = FMT ? 0u : (uint32_t)RING;      // FMT 0: a reader takes the Hl of its ring predecessors from the mailbox
-    static_assert(RING > 0 && (RING & (RING - 1)) == 0 && (uint32_t)RING + 2 <= D, "ring slot = row & (RING - 1); the mailbox outlives the ring");
+    static_assert(RING > 0 && (uint32_t)RING + 2 <= D, "the mailbox outlives the ring");
+    constexpr bool RPOW2 = (RING & (RING - 1)) == 0;      // ring slot of a row: row & (RING - 1), or a counter carried from row to row (no division)
     static_assert(NT * CPL <= 2560 && CPL % 2 == 0, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
     __shared__ sk_mail<NW> M;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1386,7 +1387,7 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
     __syncthreads();                             // the counters are zero before anybody looks at them
 
-    auto step = [&](const uint32_t row, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
+    auto step = [&](const uint32_t row, const uint32_t rslot, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));                      // lane tests are redone per row (see dp_rows_v3)
         const uint32_t info = pa.x;
@@ -1411,7 +1412,9 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         uint32_t raw[4][RW], rawl[4];
         auto fetch = [&](const int k, const uint32_t prow) __attribute__((always_inline)) {
             if (row - prow <= (uint32_t)RING) {
-                const uint32_t slot = prow & (uint32_t)(RING - 1);
+                uint32_t slot;
+                if constexpr (RPOW2) slot = prow & (uint32_t)(RING - 1);
+                else { const int32_t t = (int32_t)rslot - (int32_t)(row - prow); slot = (uint32_t)(t + ((t >> 31) & RING)); }
                 const uint32_t *rp = ring_thr + slot * (uint32_t)(NT * RW);
                 if constexpr (RW == 2) { const uint2 a2 = *(const uint2 *)rp; raw[k][0] = a2.x; raw[k][1] = a2.y; }
                 else if constexpr (RW == 4) { const uint4 a4 = *(const uint4 *)rp; raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; }
@@ -1588,8 +1591,7 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14);       // H (14 bits) | min(H - F, 3) << 14: record (traceback, far rows)
         }
         {
-            const uint32_t slot = row & (uint32_t)(RING - 1);
-            uint32_t *rp = ring_thr + slot * (uint32_t)(NT * RW);
+            uint32_t *rp = ring_thr + rslot * (uint32_t)(NT * RW);
             uint32_t R[RW];
             if constexpr (FMT == 1) {
                 const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HN[NP - 1]), (int32_t)hl);       // lane 0: the H the left wavefront published
@@ -1628,10 +1630,12 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 
     if (wave_act) {
         u32x4 na = cpa[0], nb = cpb[0], nc = cpc[0];      // plan of the next row, one row ahead
+        uint32_t rslot = 1u % (uint32_t)RING;            // ring slot of the current row
         for (uint32_t row = 1; row <= n; ++row) {
             const u32x4 pa = na, pb = nb, pc = nc;
             if (row < n) { na = cpa[row]; nb = cpb[row]; nc = cpc[row]; }
-            step(row, pa, pb, pc);
+            step(row, RPOW2 ? (row & (uint32_t)(RING - 1)) : rslot, pa, pb, pc);
+            rslot = rslot + 1u == (uint32_t)RING ? 0u : rslot + 1u;
         }
         if (n_act > 1 && lane == 0) sk_st(my_cnt, n + 1);          // every row of this wavefront is final (its last Hl is in the mailbox)
     }
@@ -2962,7 +2966,7 @@ static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIAN
 #define POA_EXP_MAX 6
 static const poa_variant k_exp[4][POA_EXP_MAX] = {
     {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(2, 8, 8, 5), POA_VARIANT(8, 8, 2, 6)},
-    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 8, 4, 5)},
+    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 6, 4, 6)},
     {POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5)},
     {POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 6), POA_VARIANT(10, 4, 4, 6), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5)}};
 
@@ -3167,7 +3171,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             }
             any = true;
             P.bpc = P.V->max_blocks(P.shm);
-            P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), n_cu * (uint32_t)P.bpc);
+            uint32_t places = n_cu * (uint32_t)P.bpc;
+            if (ctx->poa_reserve) places -= std::max<uint32_t>(places / 24, 8);      // ~4 % of the device's places stay free for another flow's late, few workgroups
+            P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), places);
             want_bytes += P.per_slot * P.n_slots;
         }
         if (rc || !any) break;
@@ -3281,6 +3287,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 e = hipEventRecord(ctx->poa_ev[t], ctx->poa_st[t]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[t], 0);
             }
+            if (ctx->poa_launched) *ctx->poa_launched = 1;       // another flow was waiting for these launches to go first
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);

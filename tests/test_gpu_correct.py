@@ -41,9 +41,13 @@ def test_correct_big_cluster_stage_split_matches_oracle(gpu_ctx, oracle, monkeyp
     assert sizes[-1] > 75 and sizes[0] < 50                     # clusters with >= 3 packs and with < 3 packs exist
     monkeypatch.setenv("RATTLE_BIG_CLUSTER_PACKS", "3")
     monkeypatch.setenv("RATTLE_BIG_MIN_PACKS", "0")
-    got = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=25)
-    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
-    assert int(got[3][0]) == int(want[3][0])
+    # round 4: on one rank the chain of the big clusters (2a -> 3a) runs on a helper context beside the POA #1 of all other packs
+    # (stage 1 in two groups); RATTLE_CORRECT_OVERLAP=0 keeps the stages one after the other -- both must give the oracle's bytes
+    for ov in ("1", "0", "1"):
+        monkeypatch.setenv("RATTLE_CORRECT_OVERLAP", ov)
+        got = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=25)
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2], ov
+        assert int(got[3][0]) == int(want[3][0])
 
 
 def test_correct_toyset_subset_matches_reference_fixture(gpu_ctx, toyset, toyset_clusters):
@@ -257,3 +261,53 @@ def test_fix_msa_ends_trims_through_the_hip_path(gpu_ctx, oracle):
     unc = got[1].split(b"\n")
     k = [i for i, l in enumerate(unc) if l.startswith(b"@t%d," % (len(seqs) - 1))]
     assert k and unc[k[0] + 1] == b""                                                            # blanked whole: empty read
+
+
+def test_correct_outputs_do_not_depend_on_scheduling(gpu_ctx, monkeypatch):
+    """Round 3's two-flow experiment (never merged) once showed ONE differing quality symbol between two schedules of the same job.
+    Byte-exactness must not depend on how the device happens to run the packs: the same `correct` job is repeated with one POA
+    stream and with twelve, with the big-cluster stage split forced and not, with the skewed-pipeline variants of kernel C, and
+    while a second context on a second host thread keeps the device busy with another job (its kernels interleave with this
+    job's, its allocations move this job's buffers) -- every output byte, the skip list and the work counters must stay the
+    same."""
+    import threading
+    from rattle_amd.api import Context
+    seqs, quals, _, _ = synth.reads(2500, 9, 1, True, seed=33)
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    assert max(len(mem) for _, mem in clusters) > 120
+
+    def run():
+        out = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=30, with_skipped=True)
+        return out[0], out[1], out[2], [int(x) for x in out[3][:5]], out[4]
+
+    base = run()
+    variants = [{"RATTLE_POA_STREAMS": "1"}, {"RATTLE_POA_STREAMS": "12"}, {"RATTLE_BIG_CLUSTER_PACKS": "3", "RATTLE_BIG_MIN_PACKS": "0"},
+                {"RATTLE_BIG_CLUSTER_PACKS": "3", "RATTLE_BIG_MIN_PACKS": "0", "RATTLE_CORRECT_OVERLAP": "0"},
+                {"RATTLE_POA_EXP": "1,1,1,1"}, {"RATTLE_POA_EXP": "3,3,2,2", "RATTLE_POA_STREAMS": "2"}, {"RATTLE_POA_EXP": "0,0,0,0"}]
+    for env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert run() == base, env
+        for k in env:
+            monkeypatch.delenv(k)
+    # a noisy neighbour on the same device
+    stop = threading.Event()
+    s2, q2, _, _ = synth.reads(1200, 4, 1, True, seed=34)
+
+    def neighbour():
+        c2 = Context(0)
+        h2 = [b"@n%d" % i for i in range(len(s2))]
+        cl2, _ = cluster_command(c2, s2, list(range(len(s2))))
+        while not stop.is_set():
+            correct_command(c2, h2, s2, q2, cl2, split=50)
+        c2.close()
+
+    t = threading.Thread(target=neighbour)
+    t.start()
+    try:
+        for _ in range(3):
+            assert run() == base, "result changed with a second job on the device"
+    finally:
+        stop.set()
+        t.join()

@@ -16,11 +16,11 @@ for exp in "0,0,0,0" "1,1,1,1" "3,3,2,2" "4,4,1,2" "5,2,0,1" "2,0,0,0"; do
 done 2>&1 | tee $O/parity.log
 for packs in 2560 256 1; do
   for exp in "-1" "0" "1" "2" "3" "4" "5"; do
-    echo "== 1024 class, packs $packs, EXP=$exp: $(RATTLE_POA_EXP=$exp,-1,-1,-1 timeout 240 python tools/bench_poa_class.py 980 $packs 200 0.10 2 2>&1 | tail -1)"
+    echo "== 1024 class, packs $packs, EXP=$exp: $(RATTLE_POA_EXP=$exp,-1,-1,-1 RATTLE_TIMING=1 timeout 240 python tools/bench_poa_class.py 980 $packs 200 0.10 2 2>&1 | grep -E "blocks/CU|^iter" | tail -2 | tr "\n" " ")"
   done
 done 2>&1 | tee $O/micro_1024.log
 for packs in 2560 256; do
-  for exp in "-1" "0" "1" "2" "3" "4"; do
-    echo "== 1536 class, packs $packs, EXP=$exp: $(RATTLE_POA_EXP=-1,$exp,-1,-1 timeout 240 python tools/bench_poa_class.py 1450 $packs 200 0.10 2 2>&1 | tail -1)"
+  for exp in "-1" "0" "1" "2" "3" "4" "5"; do
+    echo "== 1536 class, packs $packs, EXP=$exp: $(RATTLE_POA_EXP=-1,$exp,-1,-1 RATTLE_TIMING=1 timeout 240 python tools/bench_poa_class.py 1450 $packs 200 0.10 2 2>&1 | grep -E "blocks/CU|^iter" | tail -2 | tr "\n" " ")"
   done
 done 2>&1 | tee $O/micro_1536.log
