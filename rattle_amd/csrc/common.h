@@ -68,6 +68,12 @@ void parallel_for(size_t n, int n_threads, F f) {
 
 // Growable device buffer (never shrinks; contents are not preserved across grow()).  Owns its
 // allocation and frees it on destruction, so early error returns do not leak HBM; borrow() makes a
+// hipFree waits for the whole device.  While two flows share the device (correct_driver.hip: the big clusters' chain beside
+// stage 1) a buffer release must not make one flow wait for the other's kernels: between park_frees(true) and
+// park_frees(false) releases are only noted, and carried out by the latter (abi.hip).
+void dev_free(void *p);
+void park_frees(bool on);
+
 // non-owning view of another buffer (the child contexts of cluster_subsets share the parent's index).
 template <typename T>
 struct dbuf {
@@ -92,7 +98,7 @@ struct dbuf {
     }
     void swap(dbuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(owned, o.owned); }
     void release() {
-        if (p && owned) (void)hipFree(p);
+        if (p && owned) dev_free(p);
         p = nullptr;
         cap = 0;
         owned = true;

@@ -689,6 +689,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             if (local_rc == 0) {
                 hx->timing = ctx->timing;
                 hx->poa_launched = &side_launched;
+                park_frees(true);                    // hipFree waits for the whole device: no release of either flow may wait for the other's kernels
                 side = std::thread([&, hx]() {
                     auto fail = [&](int r) { side_rc = r; side_msg = rattle_hip_last_error(); side_launched = 1; };
                     if (hipSetDevice(hx->device) != hipSuccess) { set_error("helper flow: hipSetDevice failed"); fail(RATTLE_ERR_HIP); return; }
@@ -707,15 +708,28 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
                 hx->poa_launched = nullptr;
             }
         }
-        struct side_joiner { std::thread &t; ~side_joiner() { if (t.joinable()) t.join(); } } sj{side};
+        // (declared before the thread starts below would be tidier, but the joiner must outlive every early return after it)
+        struct side_joiner { std::thread &t; bool parked; ~side_joiner() { if (t.joinable()) t.join(); if (parked) park_frees(false); } } sj{side, side.joinable()};
         ctx->poa_reserve = side.joinable() ? 1 : 0;      // leave a few places for 3a's workgroups
         if (nm) LOCAL_TRY(stage1_group(1, cnt_main));
         ctx->poa_reserve = 0;
-        if (side.joinable()) side.join();
-        if (ctx->helper) {                           // the helper's kernel times belong to this call
+        const bool had_side = side.joinable();
+        if (had_side && ctx->timing) (void)hipEventRecord(ctx->ev0, st);      // group 1 is done (its stream is idle): the side flow's time beyond this point is not hidden
+        if (had_side) { side.join(); park_frees(false); sj.parked = false; }
+        if (ctx->helper) {
+            // kernel statistics of the call.  The side flow's kernels ran BESIDE group 1's POA #1: adding their durations to this
+            // context's would count that stretch of device time twice (and the cells-per-second figure derived from it would sink
+            // although the call got shorter).  Kernel C's time is therefore the main flow's plus what the side flow needed AFTER
+            // group 1 had finished (events on the two streams); launches, bytes and kernel D's (short) times add up.
+            rattle_ctx *hx = ctx->helper;
+            float beyond = 0;
+            if (had_side && ctx->timing && hipEventRecord(hx->ev1, hx->stream) == hipSuccess && hipEventSynchronize(hx->ev1) == hipSuccess &&
+                hipEventElapsedTime(&beyond, ctx->ev0, hx->ev1) == hipSuccess && beyond > 0)
+                ctx->stats[K_POA].ms += beyond;
             for (int i = 0; i < K_COUNT; ++i) {
-                ctx->stats[i].ms += ctx->helper->stats[i].ms; ctx->stats[i].launches += ctx->helper->stats[i].launches; ctx->stats[i].bytes += ctx->helper->stats[i].bytes;
-                ctx->helper->stats[i] = kstat();
+                if (i != K_POA) ctx->stats[i].ms += hx->stats[i].ms;
+                ctx->stats[i].launches += hx->stats[i].launches; ctx->stats[i].bytes += hx->stats[i].bytes;
+                hx->stats[i] = kstat();
             }
         }
         if (side_rc) { set_error(side_msg); return side_rc; }      // one rank (overlap is off otherwise)

@@ -49,9 +49,6 @@ namespace rattle {
 #ifndef POA_LONG_RING
 #define POA_LONG_RING 3                    // rows of a segment kept in LDS beyond 8192 columns (32 KB per row)
 #endif
-#ifndef POA_V3
-#define POA_V3 1                           // packed classes whose ring is a power of two take dp_rows_v3
-#endif
 #ifndef POA_MW_4x4
 #define POA_MW_4x4 7
 #endif
@@ -63,15 +60,6 @@ namespace rattle {
 #endif
 #ifndef POA_RING_4x6
 #define POA_RING_4x6 4
-#endif
-#ifndef POA_MW_2x8
-#define POA_MW_2x8 4
-#endif
-#ifndef POA_MW_2x12
-#define POA_MW_2x12 3
-#endif
-#ifndef POA_MW_1x16
-#define POA_MW_1x16 3
 #endif
 #ifndef POA_SK_BLOCKS
 #define POA_SK_BLOCKS 7                    // skewed pipeline, record words in the ring: workgroups per CU the registers are budgeted for
@@ -635,7 +623,7 @@ __device__ void dp_rows(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t 
             if (lane == 0) S.lh_ring[slot * 4 + wave] = hl_new;
         }
         if (act) {
-            // the traceback record: H as int16 plus a nibble per column, min(H-F,3) | min(H-E,3) << 2 (exact: see dp_rows_pk)
+            // the traceback record: H as int16 plus a nibble per column, min(H-F,3) | min(H-E,3) << 2 (exact: see dp_rows_v3)
             store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, pkH);
             uint32_t *np = (uint32_t *)S.E + ((uint64_t)row * NT + tid) * NWD;
 #pragma unroll
@@ -694,325 +682,10 @@ __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_ele
 // (prev.hi, cur.lo): the pair one column to the left of `cur`
 __device__ __forceinline__ s16x2 pk_left(uint32_t cur, uint32_t prev) { return as_pk(__builtin_amdgcn_alignbit(cur, prev, 16)); }
 
-template <int CPL, int RINGN, int NW>
-__device__ void dp_rows_pk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
-    constexpr int NT = 64 * NW, NP = CPL / 2;
-    static_assert(RINGN > 0 && NT * CPL <= 2560, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
-    constexpr int NEGF = -16384;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t c0 = (uint32_t)tid * CPL;
-    const bool act = c0 < Lp;
-    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
-    {
-        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
-#pragma unroll
-        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
-#pragma unroll
-        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
-    }
-    // Match scores by table look-up (v_perm_b32) when the pack's alphabet allows it: (c >> 1) & 3 maps A, C, T/U, G to 0, 1, 2, 3,
-    // so a row's letter gives an 8-byte table {5 or -4 as int16 halves} and a per-thread selector word per column pair picks
-    // the two scores in ONE instruction (against two compares, two selects and a pack).  Columns beyond the sequence get -1.
-    // T and U share an index: a pack that mixes them (or holds any other byte) takes the compare path (S.plain == 0).
-    uint32_t SEL[NP];
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
-        const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
-        const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
-        SEL[u] = sa | (sb << 16);
-    }
-    const bool plain = S.plain != 0;
-    s16x2 JE[NP], UC[NP];                        // per column: j*e and g - (j+1)*e
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const int j0 = (int)c0 + 2 * u + 1, j1 = j0 + 1;
-        const s16x2 je = {(short)(j0 * POA_E), (short)(j1 * POA_E)};
-        const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
-        JE[u] = je; UC[u] = uc;
-    }
-    // "the previous row" stays in registers as its record words (H in 14 bits, min(H - F, 3) above them: the same word
-    // the ring and the record in HBM hold, so every predecessor is decoded the same way); two sets alternate
-    uint32_t WA[NP], WB[NP];
-#pragma unroll
-    for (int u = 0; u < NP; ++u) { WA[u] = 0x80008000u; WB[u] = 0x80008000u; }
-    (void)NEGF;
-    uint32_t hlA = 0, hlB = 0;                   // H of the column left of the thread's block, in the HIGH half
-    uint32_t rowA = 0xFFFFFFFFu, rowB = 0xFFFFFFFFu;
-    s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
-    uint4 my = make_uint4(0, 0, 0, 0), myb = make_uint4(0, 0, 0, 0), myc = make_uint4(0, 0, 0, 0);
-    uint32_t r0 = 0;
-    // a wavefront whose columns all lie beyond the sequence only keeps the row barrier company
-    const bool wave_act = (uint32_t)wave * 64u * CPL < Lp;
-#ifdef POA_BARPROF
-    // measurement build: shader-clock cycles of the segments of a row, per wavefront (0: predecessor fetch + combine,
-    // 1: scores / prefix / scan up to the exchange write, 2: waiting at the row barrier, 3: after the barrier to the end)
-    long long bar_cycles = 0, seg0 = 0, seg1 = 0, seg3 = 0, tprev = 0;
-    const long long dp0 = clock64();
-#endif
-
-    auto step = [&](const uint32_t i, const uint32_t (&WP)[NP], const uint32_t hlP, const uint32_t rowP, uint32_t (&WN)[NP], uint32_t &hlN,
-                    uint32_t &rowN) __attribute__((always_inline)) {
-        const uint32_t info = __builtin_amdgcn_readlane(my.x, i);
-        const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane(myb.x, i), (uint32_t)__builtin_amdgcn_readlane(myb.y, i),
-                                (uint32_t)__builtin_amdgcn_readlane(myb.z, i), (uint32_t)__builtin_amdgcn_readlane(myb.w, i)};
-        const uint32_t row = r0 + i + 1;
-        const uint32_t par = row & 1u;
-        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
-        s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
-        s16x2 HN[NP], FN[NP];
-#ifdef POA_BARPROF
-        tprev = clock64();
-#endif
-        // A predecessor row is a set of record words + the H of the column left of the thread's block (high half):
-        // the previous row from registers, one of the last RINGN rows from the LDS ring, older ones from the record in HBM.
-        // The loads of all (up to four) predecessors are issued first and waited for once: a row with three ring
-        // predecessors pays one LDS round trip, not three.
-        uint32_t raw[4][NP], rawl[4];
-        auto fetch = [&](const int k, const uint32_t prow) __attribute__((always_inline)) {
-            if (prow == rowP) {
-#pragma unroll
-                for (int u = 0; u < NP; ++u) raw[k][u] = WP[u];
-                rawl[k] = hlP;
-            } else if (row - prow <= (uint32_t)RINGN) {
-                const uint32_t slot = prow % (uint32_t)RINGN;
-                const uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * NP;
-#pragma unroll
-                for (int u = 0; u < NP; ++u) raw[k][u] = rp[u];
-                rawl[k] = (uint32_t)S.lh_ring[slot * 4 + wave];
-            } else {
-#pragma unroll
-                for (int u = 0; u < NP; ++u) raw[k][u] = 0x80008000u;          // H = 0, H - F = 2: what a column beyond the row decodes to
-                rawl[k] = 0;
-                if (act) {
-                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) raw[k][u] = hq[u];
-                    // H of the column left of the wavefront's first column: the last cell of the previous wavefront's part of the row
-                    if (lane == 0 && wave > 0) rawl[k] = ((uint32_t)((const uint16_t *)S.H)[(uint64_t)prow * Lp + c0 - 1] & 0x3FFFu) << 16;
-                }
-                drain_vector_loads();            // rare path (1-2 % of the fetches): nothing stays pending past it
-            }
-        };
-        auto combine = [&](auto first_tag, const uint32_t (&w)[NP], const uint32_t wl) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            uint32_t hp[NP];
-            s16x2 FD[NP];
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                hp[u] = w[u] & 0x3FFF3FFFu;
-                FD[u] = as_pk(hp[u]) - pk_min(as_pk((w[u] >> 14) & 0x00030003u), pk_splat(2));       // H - min(H-F, 2) = max(H + g - e, F)
-            }
-            const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const s16x2 HD = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
-                HM[u] = FIRST ? HD : pk_max(HM[u], HD);
-                FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
-            }
-        };
-        if (n_in == 0) {                         // virtual start row: H = 0, F = -inf
-#pragma unroll
-            for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
-        } else {
-            fetch(0, pw[0]);
-            if (n_in > 1) fetch(1, pw[1]);
-            if (n_in > 2) fetch(2, pw[2]);
-            if (n_in > 3) fetch(3, pw[3]);
-            combine(std::true_type{}, raw[0], rawl[0]);
-            if (n_in > 1) combine(std::false_type{}, raw[1], rawl[1]);
-            if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
-            if (n_in > 3) {
-                combine(std::false_type{}, raw[3], rawl[3]);
-                if (n_in > 4) {
-                    // predecessors 5-8 also come from the plan (backbone nodes of a 200-read graph collect that many in-edges);
-                    // only beyond eight is the in-edge list walked in memory
-                    const uint32_t pc[4] = {(uint32_t)__builtin_amdgcn_readlane(myc.x, i), (uint32_t)__builtin_amdgcn_readlane(myc.y, i),
-                                            (uint32_t)__builtin_amdgcn_readlane(myc.z, i), (uint32_t)__builtin_amdgcn_readlane(myc.w, i)};
-                    fetch(0, pc[0]);
-                    if (n_in > 5) fetch(1, pc[1]);
-                    if (n_in > 6) fetch(2, pc[2]);
-                    if (n_in > 7) fetch(3, pc[3]);
-                    combine(std::false_type{}, raw[0], rawl[0]);
-                    if (n_in > 5) combine(std::false_type{}, raw[1], rawl[1]);
-                    if (n_in > 6) combine(std::false_type{}, raw[2], rawl[2]);
-                    if (n_in > 7) combine(std::false_type{}, raw[3], rawl[3]);
-                    if (n_in > 8) {
-                        uint32_t e = __builtin_amdgcn_readlane(my.w, i);
-                        for (uint32_t k = 8; k < n_in; ++k) {
-                            const uint2 ed = S.edges[e]; e = ed.y;
-                            const uint32_t prow = (uint32_t)S.rank[ed.x] + 1;
-                            drain_vector_loads();
-                            fetch(0, prow);
-                            combine(std::false_type{}, raw[0], rawl[0]);
-                        }
-                    }
-                }
-            }
-        }
-#ifdef POA_BARPROF
-        { asm volatile("" :: "v"(HM[0]), "v"(FM[NP - 1])); const long long t = clock64(); seg0 += t - tprev; tprev = t; }
-#endif
-        // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
-        s16x2 HNp[NP], EX[NP], SC[NP];
-        s16x2 RUN = pk_splat(-32768);
-        if (plain) {
-            const uint32_t li = (letter >> 1) & 3u;
-            const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));      // low / high bytes of {-4, -4, -4, -4} with 5 at li
-#pragma unroll
-            for (int u = 0; u < NP; ++u) SC[u] = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
-        } else {
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-                const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-                SC[u] = as_pk(pack16(s0, s1));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            FN[u] = FM[u] + pk_splat(POA_E);
-            HNp[u] = pk_max(pk_max(HM[u] + SC[u], FN[u]), pk_splat(0));
-            const uint32_t uu = as_u(HNp[u] + UC[u]);
-            EX[u] = pk_max(RUN, as_pk((uu << 16) | 0x8000u));              // (run, max(run, u_a))
-            RUN = pk_max(RUN, pk_max(as_pk(uu), as_pk(__builtin_amdgcn_alignbit(uu, uu, 16))));
-        }
-        const int32_t run = (int32_t)(int16_t)(as_u(RUN) & 0xFFFFu);
-        const int32_t ex_last = (int32_t)as_u(EX[NP - 1]) >> 16, hn_last = (int32_t)as_u(HNp[NP - 1]) >> 16;
-        const int32_t wincl = wave_scan_max_fused(act ? run : POA_NEG);
-        const int32_t texcl = wave_shr1(wincl, POA_NEG);
-        int32_t base = POA_G - POA_E;            // u_0
-        int32_t hl_new = 0;
-        if (NW > 1) {
-            if (lane == 63) {
-                ((int32_t *)&X.T[par])[wave] = wincl;
-                if (wave < NW - 1) X.Q[par][wave + 1] = make_int2(max(texcl, ex_last), hn_last);
-            }
-#ifdef POA_BARPROF
-            const long long tb0 = clock64();
-            seg1 += tb0 - tprev;
-#endif
-            row_barrier();
-#ifdef POA_BARPROF
-            tprev = clock64();
-            bar_cycles += tprev - tb0;
-#endif
-            // the exchanged numbers are the same for every lane: through the scalar unit (readfirstlane + SALU max / select)
-            // instead of a dozen per-lane selects
-            const int4 T = X.T[par];
-            const int2 q = X.Q[par][wave];
-            const int32_t Tx = __builtin_amdgcn_readfirstlane(T.x), Ty = __builtin_amdgcn_readfirstlane(T.y), Tz = __builtin_amdgcn_readfirstlane(T.z);
-            const int32_t t0 = wave > 0 ? Tx : POA_NEG, t1 = wave > 1 ? Ty : POA_NEG, t2 = wave > 2 ? Tz : POA_NEG;
-            const int32_t b0 = wave > 1 ? Tx : POA_NEG, b1 = wave > 2 ? Ty : POA_NEG;
-            base = max(max(base, t0), max(t1, t2));
-            if (wave > 0) {
-                const int32_t qx = __builtin_amdgcn_readfirstlane(q.x), qy = __builtin_amdgcn_readfirstlane(q.y);
-                const int32_t bp = max(max(POA_G - POA_E, b0), b1);
-                const int32_t c0w = (int32_t)((uint32_t)wave * 64u * CPL);
-                hl_new = max(qy, max(bp, qx) + c0w * POA_E);
-            }
-        }
-        base = max(base, texcl);
-        const s16x2 BASE = as_pk(pack16(base, base));
-        s16x2 EV[NP];
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            EV[u] = pk_max(BASE, EX[u]) + JE[u];
-            HN[u] = pk_max(HNp[u], EV[u]);
-            MXA = pk_max(MXA, HN[u]);
-        }
-        hlN = (uint32_t)hl_new << 16; rowN = row;
-        {
-            // One word per pair serves the ring, later rows and the traceback: H (14 bits) and min(H - F, 3).
-            // The traceback's tests on F and E can only hold where H - F (H - E) <= 2, and a clipped value
-            // H - 3 can never satisfy them (H of the cell above / left is at most 8 higher), so two bits
-            // per cell are an exact record of F.  E is not recorded at all: the traceback rebuilds it from the row (Eat).
-            uint32_t W[NP];
-#pragma unroll
-            for (int u = 0; u < NP; ++u) { W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14); WN[u] = W[u]; }
-            const uint32_t slot = row % (uint32_t)RINGN;
-            uint32_t *rp = S.ring + ((size_t)slot * NT + tid) * NP;
-#pragma unroll
-            for (int u = 0; u < NP; ++u) rp[u] = W[u];
-            if (lane == 0) S.lh_ring[slot * 4 + wave] = (int32_t)((uint32_t)hl_new << 16);
-            if (act) store_packed<CPL>(S.H + (uint64_t)row * Lp + c0, W);
-        }
-#ifdef POA_BARPROF
-        { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); seg3 += clock64() - tprev; }
-#endif
-#ifdef POA_PROBE
-        // cost probes (measurement builds only): extra work that leaves the results alone; the slow-down per unit says what
-        // the row is bound by.  1: 32 independent packed VALU ops, 2: 32 dependent ones, 3: an LDS round trip, 4: a block
-        // barrier, 5: 32 scalar ops, 6: 64 idle cycles on the wave's instruction stream
-        {
-            static_assert(POA_PROBE >= 1 && POA_PROBE <= 6, "");
-            uint32_t p0 = as_u(HN[0]), p1 = hlN, p2 = row, p3 = tid;
-            if (POA_PROBE == 1) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) asm volatile("v_pk_max_i16 %0, %0, %4\n v_pk_max_i16 %1, %1, %4\n v_pk_max_i16 %2, %2, %4\n v_pk_max_i16 %3, %3, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(row));
-            } else if (POA_PROBE == 2) {
-#pragma unroll
-                for (int q = 0; q < 32; ++q) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(p0) : "v"(row));
-            } else if (POA_PROBE == 3) {
-                p0 = S.ring[tid];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            } else if (POA_PROBE == 4) {
-                row_barrier();
-            } else if (POA_PROBE == 5) {
-                uint32_t sc = row;
-#pragma unroll
-                for (int q = 0; q < 32; ++q) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sc));
-                p0 = sc;
-            } else {
-                asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7");
-            }
-            if ((p0 ^ p1 ^ p2 ^ p3) == 0x12345u && row == 0xFFFFFFu) S.lh[0] = 1;      // keep the probe alive
-        }
-#endif
-    };
-
-    if (!wave_act) {
-        if (NW > 1) for (uint32_t r = 0; r < n; ++r) row_barrier();
-    } else
-    for (r0 = 0; r0 < n; r0 += 64) {
-        const uint32_t nb = min(64u, n - r0);
-        my = make_uint4(0, 0, 0, 0); myb = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < nb) { my = S.plan[r0 + lane]; myb = S.planb[r0 + lane]; myc = S.planc[r0 + lane]; }
-        drain_vector_loads();                    // once per 64 rows, so that the rows themselves never wait on vmcnt
-        for (uint32_t i = 0; i < nb; i += 2) {
-            step(i, WA, hlA, rowA, WB, hlB, rowB);
-            if (i + 1 < nb) step(i + 1, WB, hlB, rowB, WA, hlA, rowA);
-        }
-    }
-#ifdef POA_BARPROF
-    if (lane == 0) {
-        atomicAdd(&S.hist[8 + wave], (unsigned long long)bar_cycles); atomicAdd(&S.hist[12 + wave], (unsigned long long)(clock64() - dp0));
-        if (wave == 1) { atomicAdd(&S.hist[16], (unsigned long long)seg0); atomicAdd(&S.hist[17], (unsigned long long)seg1); atomicAdd(&S.hist[18], (unsigned long long)seg3); }
-    }
-#endif
-    // block-wide best score and the threads whose columns reach it; the first row (block order) that reaches it and
-    // whether other rows do too come from a rescan of those threads' columns in the record (kernel body): the row loop
-    // itself only keeps a running maximum
-    const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
-    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
-    if (lane == 0) X.best[wave] = wb;
-    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
-    __syncthreads();
-    best = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
-    if (best > 0 && lbest == best) {
-        const uint32_t slot = atomicAdd(&X.ntl, 1u);
-        if (slot < 16) X.tl[slot] = (uint32_t)tid;
-    }
-    __syncthreads();
-    best_row = 0;
-    multi = best > 0;
-}
-
 // ---- the packed row recurrence, third form (classes up to 2560 columns) ------------------------------
-// Same arithmetic, same record and ring words as dp_rows_pk; what changed is everything around the per-pair work, because the
-// kernel is bound by VALU issue and by the length of a row's instruction stream (profiles/README.md, round 3):
+// Rounds 1-2 ran the same arithmetic with the previous row in registers and the plan in vector registers; round 3 rebuilt
+// everything around the per-pair work, because the kernel is bound by VALU issue and by the length of a row's instruction
+// stream (profiles/README.md, round 3):
 //   * the row plan comes through the scalar cache: three s_load_dwordx4 per row (the plan arrays read as constant address
 //     space after an s_dcache_inv), prefetched one row ahead -- no v_readlane per plan word, no plan registers, no 64-row chunks;
 //   * every predecessor comes from the LDS ring (or, beyond RING rows, from the record): no register copy of the previous
@@ -1044,7 +717,11 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 #pragma unroll
         for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
     }
-    uint32_t SEL[NP];                            // score table selectors (see dp_rows_pk)
+    // Match scores by table look-up (v_perm_b32) when the pack's alphabet allows it: (c >> 1) & 3 maps A, C, T/U, G to 0, 1, 2, 3,
+    // so a row's letter gives an 8-byte table {5 or -4 as int16 halves} and a per-thread selector word per column pair picks
+    // the two scores in ONE instruction (against two compares, two selects and a pack).  Columns beyond the sequence get -1.
+    // T and U share an index: a pack that mixes them (or holds any other byte) takes the compare path (S.plain == 0).
+    uint32_t SEL[NP];
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
@@ -1237,7 +914,11 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             const s16x2 EV = pk_max(BASE, EX[u]) + JE[u];
             const s16x2 HN = pk_max(HNp[u], EV);
             MXA = pk_max(MXA, HN);
-            W[u] = as_u(HN) | (as_u(pk_min(HN - FN[u], pk_splat(3))) << 14);       // H (14 bits) | min(H - F, 3) << 14: ring, later rows, traceback
+            // One word per pair serves the ring, later rows and the traceback: H (14 bits) and min(H - F, 3).  The traceback's tests
+            // on F (and E) can only hold where H - F (H - E) <= 2, and a clipped value H - 3 can never satisfy them (H of the cell
+            // above / left is at most 8 higher), so two bits per cell are an exact record of F.  E is not recorded at all: the
+            // traceback rebuilds it from the row (Eat).
+            W[u] = as_u(HN) | (as_u(pk_min(HN - FN[u], pk_splat(3))) << 14);
         }
         {
             const uint32_t slot = row % (uint32_t)RING;
@@ -1355,7 +1036,7 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 #pragma unroll
         for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
     }
-    uint32_t SEL[NP];                            // score table selectors (see dp_rows_pk)
+    uint32_t SEL[NP];                            // score table selectors (see dp_rows_v3)
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
@@ -1837,7 +1518,7 @@ __device__ void dp_rows_wide(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint
             }
         }
     }
-    // block-wide best score and the threads whose columns reach it (as dp_rows_pk: the rows come from a rescan)
+    // block-wide best score and the threads whose columns reach it (as dp_rows_v3: the rows come from a rescan)
     if (!act) lbest = 0;
     const int32_t wb = wave_last(wave_scan_max(lbest, 0));
     if (lane == 0) X.best[wave] = wb;
@@ -1868,7 +1549,7 @@ __device__ void dp_rows_long(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t n
     constexpr int NT = 64 * NW;
     constexpr uint32_t SEG = (uint32_t)NT * CPL;
     int32_t *H = (int32_t *)S.H;
-    uint32_t *NB = (uint32_t *)S.E;                  // per eight columns: nibbles min(H-F,3) | min(H-E,3) << 2 (exact traceback record, see dp_rows_pk)
+    uint32_t *NB = (uint32_t *)S.E;                  // per eight columns: nibbles min(H-F,3) | min(H-E,3) << 2 (exact traceback record, see dp_rows_v3)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t lbest = 0;
     uint32_t lrow = 0, lcnt = 0, stepc = 0;
@@ -2247,7 +1928,7 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
     return (int32_t)first;
 }
 
-// PK: 0 = 32-bit registers + int16 record + nibbles (dp_rows), 1 = packed int16 pairs, record word H | min(H-F,3) << 14 (dp_rows_v3 / dp_rows_pk),
+// PK: 0 = 32-bit registers + int16 record + nibbles (dp_rows), 1 = packed int16 pairs, record word H | min(H-F,3) << 14 (dp_rows_v3),
 // 2 = int32 segments (dp_rows_long / _longr), 3 = 32-bit cells on up to 16 wavefronts (dp_rows_wide),
 // 5 / 6 = the packed record of PK 1 written by the skewed wavefront pipeline (dp_rows_sk), ring format 0 (record words) / 1 (ready-made terms)
 __host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 5 || PK == 6; }
@@ -2257,8 +1938,7 @@ __host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 6; }
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
 constexpr int poa_min_waves(int CPL, int NW, int PK) {
     return PK == 5 || PK == 6 ? (((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4 > 8 ? 8 : ((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4)
-         : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : PK == 1 && NW == 2 && CPL == 8 ? POA_MW_2x8 : PK == 1 && NW == 2 && CPL == 12 ? POA_MW_2x12
-           : PK == 1 && NW == 1 && CPL == 16 ? POA_MW_1x16 : 1;
+         : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : 1;
 }
 template <int CPL, int RING, int NW, int PK>
 __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kernel(poa_args A) {
@@ -2370,8 +2050,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                 else if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 3) dp_rows_wide<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 5 || PK == 6) dp_rows_sk<CPL, RING, NW, PK == 6 ? 1 : 0>(S, X, n, L, Lp, best, best_row, multi);
-                else if constexpr (PK == 1 && POA_V3) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
-                else if constexpr (PK == 1) dp_rows_pk<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
+                else if constexpr (PK == 1) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 cells += (unsigned long long)n * L;
                 rows += n;
@@ -2545,7 +2224,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         uint32_t i = best_row, j = bj, cnt = 0, err = 0;
                         const cell_t *H = (const cell_t *)S.H;
                         // packed classes (PK == 1): the H word carries min(H - F, 3) in its two top bits and min(H - E, 3)
-                        // sits in the per-thread bit array behind S.E -- exact for every test below (dp_rows_pk)
+                        // sits in the per-thread bit array behind S.E -- exact for every test below (dp_rows_v3)
                         // 32-bit register classes (PK == 0): H int16 plus a nibble per column behind S.E (dp_rows)
                         auto nib = [&](uint32_t r, uint32_t c) -> uint32_t {
                             if (PK == 2) return ((uint32_t)((const uint16_t *)S.E)[((uint64_t)r * Lp + c - 1) >> 2] >> (4 * ((c - 1) & 3u))) & 0xFu;   // segmented rows: per column
@@ -2958,8 +2637,6 @@ static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 
                                                    POA_VARIANT(8, POA_LONG_RING, 16, 2) /* longer than 8192: int32 cells, 8192-column segments one after the other */};
 static const poa_variant k_long_noring = POA_VARIANT(8, 0, 16, 2);      // ... row-major segments without a ring when the graph's bitmaps leave no LDS for it
 static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
-static const poa_variant k_unpacked[3] = {POA_VARIANT(4, 10, 4, 0), POA_VARIANT(6, 10, 4, 0), POA_VARIANT(8, 10, 4, 0)};
-static const poa_variant k_throughput[3] = {POA_VARIANT(8, 10, 2, 1), POA_VARIANT(12, 10, 2, 0), POA_VARIANT(16, 10, 2, 0)};
 // experiments (RATTLE_POA_EXP=<a>,<b>,<c>,<d>: index into the candidate table of the 1024- / 1536- / 2048- / 2560-column class; -1 or
 // absent: the default): the skewed wavefront pipeline (dp_rows_sk) with the record words (PK 5) or the ready-made terms (PK 6) in
 // its ring, on 2 / 4 / 8 wavefronts
@@ -3060,19 +2737,14 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         bool clamped = false;                      // cell_cap was cut to what one slot can get: packs that still fail are skipped
         const poa_variant *V = nullptr;
     } C[POA_GROUPS];
-    // RATTLE_POA_WAVES=1 selects the one/two-wave variants (measured slower than four waves per pack even
-    // with thousands of packs in flight: 353 vs 401 GCUPS at 1 kb, 395 vs 429 at 1.4 kb; kept for experiments)
-    const int force_waves = getenv("RATTLE_POA_WAVES") ? atoi(getenv("RATTLE_POA_WAVES")) : 0;
     for (int c = 0; c < POA_GROUPS; ++c) {
         C[c].todo = by_class[c];
         C[c].V = &k_latency[poa_group_class(c)];
-        if (c < 3 && force_waves == 1) C[c].V = &k_throughput[c];
         if (c < 4 && getenv("RATTLE_POA_EXP")) {
             int pick[4] = {-1, -1, -1, -1};
             sscanf(getenv("RATTLE_POA_EXP"), "%d,%d,%d,%d", &pick[0], &pick[1], &pick[2], &pick[3]);
             if (pick[c] >= 0 && pick[c] < POA_EXP_MAX) C[c].V = &k_exp[c][pick[c]];
         }
-        if (c < 3 && getenv("RATTLE_POA_UNPACKED")) C[c].V = &k_unpacked[c];
     }
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
     // The column classes of one pass run concurrently on their own streams.

@@ -98,11 +98,14 @@ def test_length_classes_match_oracle(gpu_ctx, oracle, length, depth):
 
 
 @pytest.mark.parametrize("env", [{"RATTLE_POA_DEBUG": "1"}, {"RATTLE_POA_DEBUG": "2"}, {"RATTLE_POA_DEBUG": "3"},
-                                 {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_WAVES": "1"}, {"RATTLE_POA_UNPACKED": "1"}])
+                                 {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_EXP": "0,0,0,0"}, {"RATTLE_POA_EXP": "1,1,1,1"},
+                                 {"RATTLE_POA_EXP": "3,3,2,2"}, {"RATTLE_POA_EXP": "5,5,1,2"}, {"RATTLE_POA_EXP": "1,1,1,1", "RATTLE_POA_DEBUG": "3"},
+                                 {"RATTLE_POA_EXP": "4,4,0,0", "RATTLE_POA_NODE_CAP": "700"}])
 def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
     """The slow paths behind the fast ones stay exact: full topological sort for ties (bit 0), traceback without
-    the LDS chain (bit 1), packs re-run with a larger arena after a node-capacity overflow, two-wave and 32-bit
-    row kernels."""
+    the LDS chain (bit 1), packs re-run with a larger arena after a node-capacity overflow; and the candidate row kernels of
+    round 4 (RATTLE_POA_EXP: the skewed wavefront pipeline with record words or ready-made terms in its ring, on 2 / 4 / 8
+    wavefronts, rings of 4 / 6 / 8 rows)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     packs = _packs_from_synth(400, 10, seed=11)
