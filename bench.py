@@ -157,8 +157,15 @@ def cpu_baseline_all_cores(cat, qcat, off, tid):
             "sample": f"{j['reads']} reads = every read of {j['tasks']} transcripts (6..100 reads each), one oracle task per transcript, {j['seconds']:.1f} s"}
 
 
-PMC_FILE = os.path.join("profiles", "round3_pmc_poa.json")
-PMC_ISO_FILE = os.path.join("profiles", "round3_pmc_iso.json")      # kernel B in the --iso flow (tools/gpu_pmc_iso.sh)
+def _latest(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return os.path.join("profiles", n)
+    return os.path.join("profiles", names[-1])
+
+
+PMC_FILE = _latest("round4_pmc_poa.json", "round3_pmc_poa.json")      # kernel C (tools/gpu_pmc_only.sh); `pmc_stale` says whether it matches the tree
+PMC_ISO_FILE = _latest("round4_pmc_iso.json", "round3_pmc_iso.json")      # kernel B in the --iso flow (tools/gpu_pmc_iso.sh)
 
 
 def toyset_line(ctx_cls, device):

@@ -177,6 +177,7 @@ struct exchange {
     void *user = nullptr;
     void *comm = nullptr;               // ncclComm_t
     void *rccl = nullptr;               // dlopen handle of librccl.so
+    hipStream_t side_stream = nullptr;  // set while the side flow of `correct` owns the exchange: its collectives must not queue behind the main stream's kernels
     uint64_t calls = 0, bytes = 0;      // statistics
     // staging of the RCCL all-gather-v, kept between calls: the sharded cluster driver exchanges a few KB per greedy round
     // (119 rounds at 1e6 reads) and three hipMalloc / hipFree pairs per exchange were three device-wide synchronisations each

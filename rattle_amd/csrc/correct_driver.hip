@@ -338,15 +338,19 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         for (uint32_t c = 0; c < n_clusters; ++c) if (PL.cl_np[c] >= BIG) big_packs += PL.cl_np[c];
         if (big_packs >= big_min) for (uint32_t c = 0; c < n_clusters; ++c) { big[c] = PL.cl_np[c] >= BIG; any_big |= big[c] != 0; }
     }
-    // Round 4: the chain of the big clusters -- POA #1 of their packs, POA #2 of their packs (2a), POA #3 (3a: hundreds of pack
-    // consensi aligned one after the other by ONE workgroup) -- is 1.3 s of mostly idle device at 1e6 reads when the stages
-    // follow each other.  So stage 1 runs in two groups: group 0 = the packs of the big clusters, first and alone; then their
-    // 2a -> 3a chain runs on a helper context (own streams, own arena, a second host thread) BESIDE the POA #1 of group 1
-    // (everything else), which is long enough to hide it.  2a is launched before group 1's POA #1 so that its many short
-    // workgroups take the device first and hand their places over as they finish; group 1's persistent workgroups leave a few
-    // places free (poa_reserve) for the handful of workgroups 3a needs later.  One rank only: with several ranks the stages end in
-    // collectives and keep their order.  RATTLE_CORRECT_OVERLAP=0 restores the sequential flow (same results: tests compare).
-    const bool overlap = any_big && nranks == 1 && !(getenv("RATTLE_CORRECT_OVERLAP") && atoi(getenv("RATTLE_CORRECT_OVERLAP")) == 0);
+    // Round 4, measured and NOT the default: the chain of the big clusters -- POA #1 of their packs, POA #2 of their packs (2a),
+    // POA #3 (3a: hundreds of pack consensi aligned one after the other by ONE workgroup) -- is 1.3 s of mostly idle device at 1e6
+    // reads when the stages follow each other.  With RATTLE_CORRECT_OVERLAP=1 stage 1 runs in two groups: group 0 = the packs of the
+    // big clusters, first and alone; then their 2a -> 3a chain runs on a helper context (own streams, own arena, a second host
+    // thread) BESIDE the POA #1 of group 1 (everything else).  2a is launched before group 1's POA #1 so that its many short
+    // workgroups take the device first; group 1's persistent workgroups leave a few places free (poa_reserve) for the handful of
+    // workgroups 3a needs later.  Several ranks: the collectives keep their order (after 2a, after 3a + 2b, after 3b); the first
+    // is issued by the side flow on its own stream (exchange::side_stream).  Results are byte-identical (tests compare) -- but
+    // the step got SLOWER, 5.64 -> 5.99 s (profiles/README.md, round 4): two stage-1 passes have two tails (a pass lasts as long
+    // as a pack that starts in its last wave of places: 1.83 + 2.89 s against 3.83 s for one pass), which costs more than the
+    // hidden chain saves.  What would pay is the pack's POA #2 on the workgroup that just finished its POA #1 (kernel D inside
+    // kernel C): no second pass, no hand-over of places.
+    const bool overlap = any_big && getenv("RATTLE_CORRECT_OVERLAP") && atoi(getenv("RATTLE_CORRECT_OVERLAP")) != 0;
     struct s1group {
         stage S;
         std::vector<sref> r;                         // the group's pack members, pack after pack
@@ -573,12 +577,13 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
     };
     // exchange the results of one stage: pack consensi (kind 0) and cluster consensi (kind 1), dead flags included
-    auto exchange_stage = [&](std::vector<uint8_t> &mine_bytes) -> int {
+    // (my_rc / my_msg: this rank's own failure so far -- the main flow passes local_rc, the side flow its own)
+    auto exchange_stage = [&](std::vector<uint8_t> &mine_bytes, const int my_rc, const std::string &my_msg) -> int {
         std::vector<std::vector<uint8_t>> all;
         if (nranks > 1) {
-            if (local_rc) { mine_bytes.clear(); put_rec(mine_bytes, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr, 0); }      // failure record
+            if (my_rc) { mine_bytes.clear(); put_rec(mine_bytes, 0xFFFFFFFFu, 0xFFFFFFFFu, nullptr, 0); }      // failure record
             RT_TRY(xchg_allgatherv(ctx, mine_bytes, all));
-            if (local_rc) { set_error(local_msg); return local_rc; }
+            if (my_rc) { set_error(my_msg); return my_rc; }
             for (int r = 0; r < nranks; ++r) {
                 uint32_t id = 0, flag = 0;
                 if (all[r].size() >= 12) { memcpy(&id, all[r].data(), 4); memcpy(&flag, all[r].data() + 4, 4); }
@@ -679,51 +684,65 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         if (nm) LOCAL_TRY(stage1_group(0, cnt_main));
         std::vector<uint32_t> s2a;
         for (uint32_t k : G[0].ks) if (!pk_dead[mine[k]]) s2a.push_back(k);
-        int side_rc = 0;
-        std::string side_msg;
+        // packs of group 0 given up in stage 1 are announced with the first exchange
+        for (uint32_t k : G[0].ks) if (pk_dead[mine[k]] == 1) put_rec(bytes_2a, mine[k], 1u << 1, nullptr, 0);
+        // The side flow runs on every rank that takes this path (the choice depends on the arguments alone), whatever it has to
+        // do here: with several ranks its first step that matters is the all-gather after 2a, which every rank must join -- with
+        // its consensi, with nothing, or with a failure record (a failure so far, or no helper context).
+        int side_rc = local_rc;
+        std::string side_msg = local_msg;
+        if (side_rc == 0 && !ctx->helper) {          // (also without packs for 2a: the POA #3 groups are dealt over the ranks afresh)
+            const int r = rattle_hip_ctx_create(ctx->device, &ctx->helper);
+            if (r != 0) { if (nranks == 1) return r; local_step(r); side_rc = local_rc; side_msg = local_msg; }
+        }
+        rattle_ctx *hx = ctx->helper;
         std::thread side;
         std::atomic<int> side_launched(0);
-        if (local_rc == 0 && !s2a.empty()) {
-            if (!ctx->helper) LOCAL_TRY(rattle_hip_ctx_create(ctx->device, &ctx->helper));
-            rattle_ctx *hx = ctx->helper;
-            if (local_rc == 0) {
-                hx->timing = ctx->timing;
-                hx->poa_launched = &side_launched;
-                park_frees(true);                    // hipFree waits for the whole device: no release of either flow may wait for the other's kernels
-                side = std::thread([&, hx]() {
-                    auto fail = [&](int r) { side_rc = r; side_msg = rattle_hip_last_error(); side_launched = 1; };
-                    if (hipSetDevice(hx->device) != hipSuccess) { set_error("helper flow: hipSetDevice failed"); fail(RATTLE_ERR_HIP); return; }
-                    int r = ensure_post_constants(hx);
-                    if (r == 0) r = cons_pass(hx, "correct: stage 2a (beside stage 1)", s2a, {}, bytes_2a, sk_2a, cnt_side);
-                    side_launched = 1;               // (also when 2a had nothing to launch)
-                    if (r) { fail(r); return; }
-                    std::vector<uint8_t> b2a = bytes_2a;
-                    r = exchange_stage(b2a);         // one rank: takes the pack consensi in
-                    std::vector<uint32_t> g3a;
-                    if (r == 0) { big_groups(g3a); r = cons_pass(hx, "correct: stage 3a (beside stage 1)", {}, g3a, bytes_3a, sk_3a, cnt_side); }
-                    if (r) fail(r);
-                });
-                // group 1's persistent workgroups would take every place of the device: 2a's launches go first
-                while (!side_launched) std::this_thread::yield();
-                hx->poa_launched = nullptr;
+        const bool side_poa = side_rc == 0 && !s2a.empty() && hx;
+        if (side_poa) { hx->timing = ctx->timing; hx->poa_launched = &side_launched; }
+        park_frees(true);                            // hipFree waits for the whole device: no release of either flow may wait for the other's kernels
+        ctx->xchg.side_stream = hx ? hx->stream : nullptr;
+        side = std::thread([&, hx, side_poa]() {
+            auto fail = [&](int r) { if (!side_rc) { side_rc = r; side_msg = rattle_hip_last_error(); } side_launched = 1; };
+            int r = 0;
+            if (hx && hipSetDevice(hx->device) != hipSuccess) { set_error("helper flow: hipSetDevice failed"); r = RATTLE_ERR_HIP; }
+            if (r == 0 && side_poa) r = ensure_post_constants(hx);
+            if (r == 0 && side_poa) r = cons_pass(hx, "correct: stage 2a (beside stage 1)", s2a, {}, bytes_2a, sk_2a, cnt_side);
+            side_launched = 1;                       // (also when 2a had nothing to launch)
+            if (r) fail(r);
+            r = exchange_stage(bytes_2a, side_rc, side_msg);
+            if (r) { fail(r); return; }
+            std::vector<uint32_t> g3a;
+            big_groups(g3a);
+            if (!g3a.empty() && !hx) { set_error("helper flow: no helper context"); fail(RATTLE_ERR_STATE); return; }
+            if (!g3a.empty()) {
+                r = ensure_post_constants(hx);
+                if (r == 0) r = cons_pass(hx, "correct: stage 3a (beside stage 1)", {}, g3a, bytes_3a, sk_3a, cnt_side);
             }
+            if (r) fail(r);
+        });
+        // joins the side flow and un-parks the frees on EVERY way out of this block
+        struct side_joiner { std::thread &t; exchange &x; ~side_joiner() { if (t.joinable()) t.join(); x.side_stream = nullptr; park_frees(false); } };
+        {
+            side_joiner sj{side, ctx->xchg};
+            // group 1's persistent workgroups would take every place of the device: 2a's launches go first
+            while (!side_launched) std::this_thread::yield();
+            if (hx) hx->poa_launched = nullptr;
+            ctx->poa_reserve = 1;                    // leave a few places for 3a's workgroups
+            int r1 = 0;
+            if (nm && local_rc == 0) r1 = stage1_group(1, cnt_main);
+            ctx->poa_reserve = 0;
+            if (ctx->timing) (void)hipEventRecord(ctx->ev0, st);      // group 1 is done (its stream is idle): the side flow's time beyond this point is not hidden
+            side.join();
+            if (r1 != 0) { if (nranks == 1) return r1; local_step(r1); }
         }
-        // (declared before the thread starts below would be tidier, but the joiner must outlive every early return after it)
-        struct side_joiner { std::thread &t; bool parked; ~side_joiner() { if (t.joinable()) t.join(); if (parked) park_frees(false); } } sj{side, side.joinable()};
-        ctx->poa_reserve = side.joinable() ? 1 : 0;      // leave a few places for 3a's workgroups
-        if (nm) LOCAL_TRY(stage1_group(1, cnt_main));
-        ctx->poa_reserve = 0;
-        const bool had_side = side.joinable();
-        if (had_side && ctx->timing) (void)hipEventRecord(ctx->ev0, st);      // group 1 is done (its stream is idle): the side flow's time beyond this point is not hidden
-        if (had_side) { side.join(); park_frees(false); sj.parked = false; }
-        if (ctx->helper) {
+        if (hx) {
             // kernel statistics of the call.  The side flow's kernels ran BESIDE group 1's POA #1: adding their durations to this
             // context's would count that stretch of device time twice (and the cells-per-second figure derived from it would sink
             // although the call got shorter).  Kernel C's time is therefore the main flow's plus what the side flow needed AFTER
             // group 1 had finished (events on the two streams); launches, bytes and kernel D's (short) times add up.
-            rattle_ctx *hx = ctx->helper;
             float beyond = 0;
-            if (had_side && ctx->timing && hipEventRecord(hx->ev1, hx->stream) == hipSuccess && hipEventSynchronize(hx->ev1) == hipSuccess &&
+            if (ctx->timing && hx->stats[K_POA].launches && hipEventRecord(hx->ev1, hx->stream) == hipSuccess && hipEventSynchronize(hx->ev1) == hipSuccess &&
                 hipEventElapsedTime(&beyond, ctx->ev0, hx->ev1) == hipSuccess && beyond > 0)
                 ctx->stats[K_POA].ms += beyond;
             for (int i = 0; i < K_COUNT; ++i) {
@@ -732,15 +751,21 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
                 hx->stats[i] = kstat();
             }
         }
-        if (side_rc) { set_error(side_msg); return side_rc; }      // one rank (overlap is off otherwise)
-        if (nm) LOCAL_TRY(stage1_finish());
+        if (side_rc && !local_rc) {                  // the side flow failed (here, or on another rank: the exchange said so)
+            set_error(side_msg);
+            if (nranks == 1) return side_rc;
+            local_rc = side_rc; local_msg = side_msg;
+        }
+        if (nm && local_rc == 0) LOCAL_TRY(stage1_finish());
         d_rseq.release(); d_rqual.release();
         std::vector<uint32_t> s2b;
         for (uint32_t k : G[1].ks) if (!pk_dead[mine[k]]) s2b.push_back(k);
         LOCAL_TRY(cons_pass(ctx, "correct: stage 2b", s2b, {}, bytes_2b, sk_2b, cnt_main));
-        std::vector<uint8_t> bytes(bytes_3a);
+        std::vector<uint8_t> bytes;
+        for (uint32_t k : G[1].ks) if (pk_dead[mine[k]] == 1) put_rec(bytes, mine[k], 1u << 1, nullptr, 0);      // group 1's packs given up in stage 1
+        bytes.insert(bytes.end(), bytes_3a.begin(), bytes_3a.end());
         bytes.insert(bytes.end(), bytes_2b.begin(), bytes_2b.end());
-        RT_TRY(exchange_stage(bytes));
+        RT_TRY(exchange_stage(bytes, local_rc, local_msg));
     } else {
         if (nm) LOCAL_TRY(stage1_group(1, cnt_main));
         if (nm && local_rc == 0) LOCAL_TRY(stage1_finish());
@@ -752,12 +777,12 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         std::vector<uint32_t> s2a, s2b;
         for (uint32_t k = 0; k < nm; ++k) if (!pk_dead[mine[k]]) (big[PL.pk_cid[mine[k]]] ? s2a : s2b).push_back(k);
         LOCAL_TRY(cons_pass(ctx, "correct: stage 2a", s2a, {}, bytes, sk_2a, cnt_main));
-        if (any_big) { RT_TRY(exchange_stage(bytes)); bytes.clear(); }
+        if (any_big) { RT_TRY(exchange_stage(bytes, local_rc, local_msg)); bytes.clear(); }
         // stage 2b+3a: POA #3 groups of the big clusters (LPT over ranks), then my packs of all other clusters
         std::vector<uint32_t> g3a;
         big_groups(g3a);
         LOCAL_TRY(cons_pass(ctx, "correct: stage 2b+3a", s2b, g3a, bytes, sk_3a, cnt_main));
-        RT_TRY(exchange_stage(bytes));
+        RT_TRY(exchange_stage(bytes, local_rc, local_msg));
     }
     if (!nm || local_rc) {
         if (d2h.joinable()) d2h.join();
@@ -787,7 +812,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         LOCAL_TRY(cons_pass(ctx, "correct: stage 3b", {}, g3b, bytes_3b, sk_3b, cnt_main));
         // several ranks: this exchange always takes place, so that every rank leaves with the same verdict (the caller's
         // next collective is the gather of the corrected reads)
-        if (!g3b_all.empty() || nranks > 1) RT_TRY(exchange_stage(bytes_3b));
+        if (!g3b_all.empty() || nranks > 1) RT_TRY(exchange_stage(bytes_3b, local_rc, local_msg));
     }
     // skipped packs of the consensus stages in the order the sequential flow meets them: 2a, then 3a before 2b (one pass), then 3b
     for (std::vector<skip_t> *v : {&sk_2a, &sk_3a, &sk_2b, &sk_3b}) for (skip_t &x : *v) skips.push_back(std::move(x));

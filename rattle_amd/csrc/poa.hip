@@ -295,7 +295,7 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
 // different labels the smaller label comes first.  One backward sweep over the rows (block order:
 // successors and group mates of a row all lie at or after its group) gives every label:
 // label(group) = min over its members, then every predecessor of a member takes min(own, label).
-// lab[] lives in the LDS ring (unused outside the DP), 16 bits per row; wave 0 runs the sweep,
+// lab[] lives in the LDS region of the ring (unused outside the DP) behind the bitmaps and the stack, 16 bits per row; wave 0 runs the sweep,
 // lanes 0..3 updating the first four predecessors in parallel.
 // Sweeps rows hi_start, hi_start-1, ... and returns the first row it did NOT process: it stops below
 // lo_stop (at a group boundary) -- a label is final once the sweep has reached its row, so the
@@ -1010,8 +1010,14 @@ template <int NW> struct sk_mail {
     uint32_t cnt[NW];                             // cnt[w]: last row whose {T} wavefront w has published; n + 1: all its rows are final
     int2 ent[NW][SK_D];                           // slot r % SK_D: {x: prefix max of u over columns 1 .. last column of w (both halves), y: H of its last column << 16}
 };
-__device__ __forceinline__ uint32_t sk_ld(const uint32_t *p) { return *(const volatile uint32_t *)p; }
-__device__ __forceinline__ void sk_st(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
+// The mailbox is read and written through VOLATILE pointers (no access may be dropped, merged or moved across another) that carry
+// the LDS address space in their type: a volatile access through a generic pointer is not narrowed by the compiler and comes out as
+// flat_load / flat_store with system-coherence bits and an s_waitcnt vmcnt(0) behind every store -- which waits for the record
+// stores of the row (a memory round trip per row: the first build of this kernel did exactly that).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef volatile lds_u32 *sk_ptr;
+__device__ __forceinline__ uint32_t sk_ld(sk_ptr p) { return *p; }
+__device__ __forceinline__ void sk_st(sk_ptr p, uint32_t v) { *p = v; }
 // inclusive prefix max over the lanes of a word whose two halves are EQUAL: as a signed 32-bit number such a word orders like
 // its halves, so the 32-bit DPP scan works on it directly and the result is again a duplicated word
 __device__ __forceinline__ uint32_t wave_scan_max_dup(uint32_t v) { return (uint32_t)wave_scan_max_fused((int32_t)v); }
@@ -1058,8 +1064,8 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     const bool wave_act = (uint32_t)wave < n_act, has_left = wave > 0, has_right = (uint32_t)wave + 1u < n_act;
     uint32_t *const ring_thr = S.ring + (size_t)tid * RW;              // slot s of this thread: ring_thr + s * NT * RW
     uint32_t *const Hrec = (uint32_t *)S.H;                            // the record, a dword per column pair
-    uint32_t *const my_cnt = &M.cnt[wave], *const left_cnt = &M.cnt[has_left ? wave - 1 : 0], *const right_cnt = &M.cnt[has_right ? wave + 1 : 0];
-    uint32_t *const my_ent = (uint32_t *)&M.ent[wave][0], *const left_ent = (uint32_t *)&M.ent[has_left ? wave - 1 : 0][0];
+    const sk_ptr my_cnt = (sk_ptr)&M.cnt[wave], left_cnt = (sk_ptr)&M.cnt[has_left ? wave - 1 : 0], right_cnt = (sk_ptr)&M.cnt[has_right ? wave + 1 : 0];
+    const sk_ptr my_ent = (sk_ptr)&M.ent[wave][0], left_ent = (sk_ptr)&M.ent[has_left ? wave - 1 : 0][0];
 
     if (tid < NW) M.cnt[tid] = 0;
     // the plan through the scalar cache (see dp_rows_v3)
@@ -1933,6 +1939,14 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 // 5 / 6 = the packed record of PK 1 written by the skewed wavefront pipeline (dp_rows_sk), ring format 0 (record words) / 1 (ready-made terms)
 __host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 5 || PK == 6; }
 __host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 6; }
+// dwords of LDS ring per thread and row; bytes of the region the ring (+ the left-column values of the barrier forms) shares with
+// the graph walks' two node bitmaps and DFS stack
+__host__ __device__ constexpr uint32_t poa_ring_words(int CPL, int NW, int PK) { return pk_readymade(PK) ? CPL : !pk_packed(PK) && 64 * NW * CPL > 2048 ? CPL : CPL / 2; }
+__host__ __device__ constexpr uint32_t poa_region_bytes(uint32_t node_cap, int CPL, int RING, int NW, int PK) {
+    const uint32_t walk = (2u * poa_bit_words(node_cap) + POA_STACK) * 4u;
+    const uint32_t ring = (uint32_t)RING * 64u * NW * poa_ring_words(CPL, NW, PK) * 4u + (uint32_t)RING * 4u * (NW > 4 ? NW : 4);
+    return walk > ring ? walk : ring;
+}
 
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
@@ -1962,10 +1976,13 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         S.aln = (int32_t *)(base + A.o_aln); S.ainfo = (uint4 *)(base + A.o_ainfo); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = poa_bit_words(A.node_cap);
         S.sq = (uint8_t *)lds;                                   // seq_cap bytes (multiple of 16)
+        // The DP's ring and the graph walks' bitmaps + stack share ONE region of LDS: the walks (topological sorts, tie labels,
+        // add_alignment's kind array, the traceback's chain) only run between two DPs, when the ring holds nothing.  4.6 KB per
+        // workgroup: the difference between six and seven (record words) or four and five (ready-made terms) packs per CU.
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
-        S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * (pk_readymade(PK) ? CPL : !pk_packed(PK) && NT * CPL > 2048 ? CPL : CPL / 2));
+        S.ring = S.done;
+        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * poa_ring_words(CPL, NW, PK));
     }
 
     while (true) {
@@ -2116,9 +2133,10 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         if (tid == 0) { atomicAdd(&A.counters[4], 1ull << 32); if (need_sort) atomicAdd(&A.counters[4], 1ull); }
 #endif
                     }
-                    if (need_sort && RING > 0 && n <= (uint32_t)RING * NT * CPL && S.n_nodes <= 0xFFFFu && !(A.debug & 1u)) {
-                        // labels instead of the full sort (tie_labels)
-                        uint16_t *lab = (uint16_t *)S.ring;
+                    const uint32_t walk_bytes = (2u * poa_bit_words(A.node_cap) + POA_STACK) * 4u, region_bytes = poa_region_bytes(A.node_cap, CPL, RING, NW, PK);
+                    if (need_sort && RING > 0 && 2u * n + walk_bytes <= region_bytes && S.n_nodes <= 0xFFFFu && !(A.debug & 1u)) {
+                        // labels instead of the full sort (tie_labels); they sit behind the bitmaps and the stack, which the replay of one root's DFS uses beside them
+                        uint16_t *lab = (uint16_t *)(S.stack + POA_STACK);
                         for (uint32_t r = tid; r < n; r += NT) lab[r] = (uint16_t)S.order[r];
                         if (tid == 0) { s_bc[7] = 0xFFFFFFFFu; s_bc[5] = 0; s_bc[6] = 0xFFFFFFFFu; }
                         __syncthreads();
@@ -2207,7 +2225,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     // by the general code (all lanes uniformly, lane 0 writes).  aln[] receives (row | -1, pos | -1);
                     // rows become node ids in add_alignment.
                     uint16_t *tq0 = (uint16_t *)S.done;                   // [n+1] row of the first in-edge (0: none / virtual)
-                    const uint32_t tb_bytes = (2u * poa_bit_words(A.node_cap) + POA_STACK) * 4u + (uint32_t)RING * NT * (CPL / 2) * 4u + (uint32_t)RING * 16u;
+                    const uint32_t tb_bytes = poa_region_bytes(A.node_cap, CPL, RING, NW, PK);
                     const bool fast_tb = 3u * (n + 2u) <= tb_bytes && n < 0xFFFFu && !(A.debug & 2u);
                     uint8_t *tlet = (uint8_t *)(tq0 + (n + 2u));          // [n+1] letter of the row's node
                     if (fast_tb) {
@@ -2637,6 +2655,12 @@ static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 
                                                    POA_VARIANT(8, POA_LONG_RING, 16, 2) /* longer than 8192: int32 cells, 8192-column segments one after the other */};
 static const poa_variant k_long_noring = POA_VARIANT(8, 0, 16, 2);      // ... row-major segments without a ring when the graph's bitmaps leave no LDS for it
 static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
+// the packed classes (up to 2560 columns), by load: see choose_variants in poa_device_run
+#ifndef POA_SPARSE_PACKS_PER_CU
+#define POA_SPARSE_PACKS_PER_CU 4
+#endif
+static const poa_variant k_dense[4] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1)};
+static const poa_variant k_sparse[4] = {POA_VARIANT(2, 8, 8, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(10, 8, 4, 6)};
 // experiments (RATTLE_POA_EXP=<a>,<b>,<c>,<d>: index into the candidate table of the 1024- / 1536- / 2048- / 2560-column class; -1 or
 // absent: the default): the skewed wavefront pipeline (dp_rows_sk) with the record words (PK 5) or the ready-made terms (PK 6) in
 // its ring, on 2 / 4 / 8 wavefronts
@@ -2737,15 +2761,28 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         bool clamped = false;                      // cell_cap was cut to what one slot can get: packs that still fail are skipped
         const poa_variant *V = nullptr;
     } C[POA_GROUPS];
-    for (int c = 0; c < POA_GROUPS; ++c) {
-        C[c].todo = by_class[c];
-        C[c].V = &k_latency[poa_group_class(c)];
-        if (c < 4 && getenv("RATTLE_POA_EXP")) {
-            int pick[4] = {-1, -1, -1, -1};
-            sscanf(getenv("RATTLE_POA_EXP"), "%d,%d,%d,%d", &pick[0], &pick[1], &pick[2], &pick[3]);
-            if (pick[c] >= 0 && pick[c] < POA_EXP_MAX) C[c].V = &k_exp[c][pick[c]];
+    for (int c = 0; c < POA_GROUPS; ++c) C[c].todo = by_class[c];
+    // The kernel of a class is chosen per PASS from how full the device will be (round 3's verdict: one wavefront / column split
+    // per class, chosen by read length only, collapsed to 0.08 of the issue roofline whenever fewer packs were resident than the
+    // device has places -- 1e5 reads, the toyset, stages 2a / 3a / 3b, every rank of an 8-GPU job, the re-run of a few packs):
+    // `dense` = the most cells per instruction when every CU holds several packs; `sparse` = the shortest time per row when a
+    // pack has (most of) a CU to itself -- the same row spread over twice the wavefronts, so that the SIMDs still have a
+    // wavefront to issue from while another waits for LDS or its neighbour.
+    int exp_pick[4] = {-1, -1, -1, -1};
+    if (getenv("RATTLE_POA_EXP")) sscanf(getenv("RATTLE_POA_EXP"), "%d,%d,%d,%d", &exp_pick[0], &exp_pick[1], &exp_pick[2], &exp_pick[3]);
+    const int force_mode = getenv("RATTLE_POA_MODE") ? (getenv("RATTLE_POA_MODE")[0] == 's' ? 2 : getenv("RATTLE_POA_MODE")[0] == 'd' ? 1 : 0) : 0;      // tests: "sparse" / "dense"
+    auto choose_variants = [&]() {
+        uint64_t live = 0;
+        for (int c = 0; c < POA_GROUPS; ++c) live += C[c].todo.size();
+        const bool sparse = force_mode ? force_mode == 2 : live < (uint64_t)POA_SPARSE_PACKS_PER_CU * n_cu;
+        for (int c = 0; c < POA_GROUPS; ++c) {
+            C[c].V = &k_latency[poa_group_class(c)];
+            if (c < 4) {
+                C[c].V = sparse ? &k_sparse[c] : &k_dense[c];
+                if (exp_pick[c] >= 0 && exp_pick[c] < POA_EXP_MAX) C[c].V = &k_exp[c][exp_pick[c]];
+            }
         }
-    }
+    };
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
     // The column classes of one pass run concurrently on their own streams.
     // (RATTLE_POA_BUDGET_MB: tests shrink the arena to exercise the skip path)
@@ -2783,8 +2820,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         auto lds_bytes = [&](const poa_variant *V) {
-            const size_t cell = pk_readymade(V->pk) ? 4 : !pk_packed(V->pk) && 64u * V->nw * V->cpl > 2048u ? 4 : 2;      // ring bytes per cell (dp_rows WIDE; ready-made terms)
-            return (size_t)lds_seq + ((size_t)poa_bit_words(ncap) * 2 + POA_STACK) * 4 + (size_t)V->ring * 64 * V->nw * V->cpl * cell + (size_t)V->ring * 4 * std::max<uint32_t>(4, V->nw) + 64;
+            return (size_t)lds_seq + poa_region_bytes(ncap, (int)V->cpl, (int)V->ring, (int)V->nw, (int)V->pk) + 64;      // the ring and the graph walks' bitmaps + stack share a region
         };
         if ((gc == 4 || gc == 5 || gc == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[gc - 4];
         if (gc == POA_CLASSES - 1 && lds_bytes(P.V) > 158u * 1024) P.V = &k_long_noring;
@@ -2801,6 +2837,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     for (int pass = 0; pass < 64 && rc == 0; ++pass) {
         bool any = false;
         uint64_t want_bytes = 0;
+        choose_variants();
         for (int c = 0; c < POA_GROUPS && rc == 0; ++c) {
             cls_plan &P = C[c];
             P.n_slots = 0;

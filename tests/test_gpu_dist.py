@@ -71,8 +71,8 @@ def fake_rccl(tmp_path):
     return {"RATTLE_RCCL_LIB": str(so), "FAKE_RCCL_DIR": str(box)}
 
 
-@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (2, "device"), (3, "device"), (8, "host"), (8, "device")])
-def test_sharded_job_equals_single_gpu(tmp_path, world, transport):
+@pytest.mark.parametrize("world,transport,big", [(2, "host", 0), (3, "host", 1), (2, "device", 1), (3, "device", 0), (8, "host", 1), (8, "device", 0)])
+def test_sharded_job_equals_single_gpu(tmp_path, world, transport, big):
     """transport "host": the caller's all-gather-v on host buffers (gloo); "device": the RCCL code path of exchange.hip
     (sizes all-gather, grouped broadcasts, grouped send / recv to the root) with the file-backed double standing in
     for librccl.so, since RCCL itself refuses two ranks on one device."""
@@ -82,6 +82,10 @@ def test_sharded_job_equals_single_gpu(tmp_path, world, transport):
     env.pop("RATTLE_RCCL_LIB", None)
     if transport == "device":
         env.update(fake_rccl(tmp_path))
+    if big:
+        # the big-cluster flow of `correct` on every rank: stage 1 in two groups, the chain 2a -> all-gather -> 3a on the helper
+        # context and its own stream beside group 1's POA #1 (correct_driver.hip); the unsharded reference takes the same path
+        env.update(RATTLE_BIG_CLUSTER_PACKS="3", RATTLE_BIG_MIN_PACKS="0", RATTLE_CORRECT_OVERLAP="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(29700 + world + (10 if transport == "device" else 0)), str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
