@@ -21,35 +21,46 @@ namespace rattle {
 // seed / candidate arrays): the greedy rounds of many independent clusterings (the gene clusters of `--iso`,
 // main.cpp:281-318) advance in lockstep and share the launch.  Rectangle j owns tiles [tile_base_j, tile_base_{j+1});
 // a workgroup finds its rectangle by bisection.  first_cand[] is in the index space of the candidate array.
-// |candidate AND seed| with the seed's 512 bytes streamed through the scalar cache in sixteen s_load_dwordx8, double-buffered by
-// hand.  Written as plain constant-address-space loads the compiler merges them into eight s_load_dwordx16 on ONE register bank
-// (100 SGPRs are in use, there is no room for a second bank of sixteen), so every 32 VALU instructions waited for a full scalar
-// load: the kernel ran at a third of its and + popcount issue bound (round 2's verdict, item 8).  Here the next eight dwords
-// are requested before the current eight are consumed.  Scalar loads return out of order, so the only safe wait is
-// lgkmcnt(0): wait for bank A, request B, consume A, wait for B, request A, consume B.  The waits carry the accumulator as an
-// operand so that the consumption of one bank cannot sink below the wait for the other.
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-#define BVF_SLOAD(bank, ptr, off) asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(bank) : "s"(ptr), "i"(off))
+// |candidate AND seed| with the seed's 512 bytes streamed through the scalar cache in banks of SGPRs, double-buffered by hand.
+// Written as plain constant-address-space loads the compiler merges them into eight s_load_dwordx16 on ONE register bank, so
+// every 32 VALU instructions waited for a full scalar load: the kernel ran at a third of its and + popcount issue bound (round 2's
+// verdict, item 8).  Here the next bank is requested before the current one is consumed.  Scalar loads return out of order, so
+// the only safe wait is lgkmcnt(0): wait for bank A, request B, consume A, wait for B, request A, consume B.  The waits carry the
+// accumulator as an operand so that the consumption of one bank cannot sink below the wait for the other.  (The load and its wait
+// are separate asm statements: tests/test_build_checks.py follows every path of the GENERATED code from each load to its wait
+// and fails the build check if anything touches the bank in between.)
+// Round 4: the banks are SIXTEEN dwords (eight s_load_dwordx16 per seed).  With eight-dword banks the request for a bank was only one
+// bank's work ahead of its use (~70 cycles of and + popcount issue: less than a scalar-cache round trip, and lgkmcnt(0) being the
+// only safe wait, a deeper queue of requests cannot help); sixteen dwords are ~140 cycles of work.  The first bank of the NEXT seed
+// is requested while the last bank of this one is consumed, so a seed boundary costs no round trip either.  The kernel uses ~80 of
+// the 102 SGPRs (round 2's note of "100 in use" was of an earlier form).
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define BVF_SLOAD(bank, ptr, off) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(bank) : "s"(ptr), "i"(off))
 #define BVF_SWAIT(bank, acc) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bank), "+v"(acc))
 // every popcount is ONE v_bcnt_u32_b32 with its accumulate operand, on four independent chains (written as `a += popc(x)` the
 // compiler re-associates the sum into bcnt(x, 0) pairs joined by v_add3: 2 more instructions per 8 words; inline asm pins it)
 __device__ __forceinline__ void bvf_bcnt_acc(uint32_t &acc, const uint32_t x) { asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x)); }
-__device__ __forceinline__ void bvf_chunk(const uint64_t (&v)[64], const u32x8 S, const int c, uint32_t (&acc)[4]) {
+__device__ __forceinline__ void bvf_chunk(const uint64_t (&v)[64], const u32x16 S, const int c, uint32_t (&acc)[4]) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        bvf_bcnt_acc(acc[(2 * w) & 3], (uint32_t)v[4 * c + w] & S[2 * w]);
-        bvf_bcnt_acc(acc[(2 * w + 1) & 3], (uint32_t)(v[4 * c + w] >> 32) & S[2 * w + 1]);
+    for (int w = 0; w < 8; ++w) {
+        bvf_bcnt_acc(acc[(2 * w) & 3], (uint32_t)v[8 * c + w] & S[2 * w]);
+        bvf_bcnt_acc(acc[(2 * w + 1) & 3], (uint32_t)(v[8 * c + w] >> 32) & S[2 * w + 1]);
     }
 }
-__device__ __forceinline__ uint32_t seed_dot(const uint64_t (&v)[64], const uint64_t *seed_vec) {
+// `A` arrives REQUESTED (the first sixteen dwords of this seed's vector: by seed_first, or by the call for the seed before) and leaves
+// requested for the next seed.
+__device__ __forceinline__ void seed_first(u32x16 &A, const uint64_t *seed_vec) {
     const uint64_t sp = (uint64_t)(uintptr_t)seed_vec;
-    u32x8 A, B;
-    uint32_t acc[4] = {0, 0, 0, 0};
     BVF_SLOAD(A, sp, 0);
+}
+__device__ __forceinline__ uint32_t seed_dot(const uint64_t (&v)[64], u32x16 &A, const uint64_t *seed_vec, const uint64_t *next_seed_vec) {
+    const uint64_t sp = (uint64_t)(uintptr_t)seed_vec, np = (uint64_t)(uintptr_t)next_seed_vec;
+    u32x16 B;
+    uint32_t acc[4] = {0, 0, 0, 0};
 #define BVF_PAIR(c)                                                     \
-    BVF_SWAIT(A, acc[0]); BVF_SLOAD(B, sp, ((c) + 1) * 32); bvf_chunk(v, A, (c), acc);      \
-    BVF_SWAIT(B, acc[0]); if ((c) + 2 < 16) BVF_SLOAD(A, sp, (((c) + 2) & 15) * 32); bvf_chunk(v, B, (c) + 1, acc);
-    BVF_PAIR(0) BVF_PAIR(2) BVF_PAIR(4) BVF_PAIR(6) BVF_PAIR(8) BVF_PAIR(10) BVF_PAIR(12) BVF_PAIR(14)
+    BVF_SWAIT(A, acc[0]); BVF_SLOAD(B, sp, ((c) + 1) * 64); bvf_chunk(v, A, (c), acc);      \
+    BVF_SWAIT(B, acc[0]); if ((c) + 2 < 8) BVF_SLOAD(A, sp, (((c) + 2) & 7) * 64); else BVF_SLOAD(A, np, 0); bvf_chunk(v, B, (c) + 1, acc);
+    BVF_PAIR(0) BVF_PAIR(2) BVF_PAIR(4) BVF_PAIR(6)
 #undef BVF_PAIR
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
@@ -158,26 +169,38 @@ __global__ __launch_bounds__(256) void bv_filter_kernel(const uint64_t *__restri
         uint64_t v[64];
         load_candidate_vectors(v, bvf, cid, s_tr[threadIdx.x >> 6]);
         uint32_t need_nx = BOTH ? 0u : need_of(0);
+        u32x16 bank;
+        const uint64_t *sv = bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[0]) * 64;
+        seed_first(bank, sv);
         for (uint32_t s = 0; s < ns; ++s) {
             // the seed's vector is the same for every lane: it comes through the scalar cache and enters the v_and as an SGPR
             // operand -- no LDS broadcast read per word, the VALU does nothing but and + popcount
             const uint32_t need = need_nx;
             if (!BOTH) need_nx = need_of(s + 1);
-            const uint32_t a = seed_dot(v, bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s]) * 64);
+            const uint64_t *nv = bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s + 1 < ns ? s + 1 : s]) * 64;
+            const uint32_t a = seed_dot(v, bank, sv, nv);
+            sv = nv;
             if (BOTH) s_cf[s][threadIdx.x] = (uint16_t)a;
             else emit(s, a, 0, need);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bank));       // the last prefetch lands before its registers are anybody else's
     }
     if (BOTH) {
         uint64_t v[64];
         load_candidate_vectors(v, bvr, cid, s_tr[threadIdx.x >> 6]);
         uint32_t need_nx = need_of(0);
+        u32x16 bank;
+        const uint64_t *sv = bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[0]) * 64;
+        seed_first(bank, sv);
         for (uint32_t s = 0; s < ns; ++s) {
             const uint32_t need = need_nx;
             need_nx = need_of(s + 1);
-            const uint32_t a = seed_dot(v, bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s]) * 64);
+            const uint64_t *nv = bvf + (uint64_t)__builtin_amdgcn_readfirstlane((int)s_seed[s + 1 < ns ? s + 1 : s]) * 64;
+            const uint32_t a = seed_dot(v, bank, sv, nv);
+            sv = nv;
             emit(s, s_cf[s][threadIdx.x], a, need);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bank));
     }
     if (list) {
         // the tile's survivors of this wavefront: one atomic for all of them, a lane's entries behind those of the lanes below it

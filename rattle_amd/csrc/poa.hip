@@ -295,7 +295,7 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
 // different labels the smaller label comes first.  One backward sweep over the rows (block order:
 // successors and group mates of a row all lie at or after its group) gives every label:
 // label(group) = min over its members, then every predecessor of a member takes min(own, label).
-// lab[] lives in the LDS region of the ring (unused outside the DP) behind the bitmaps and the stack, 16 bits per row; wave 0 runs the sweep,
+// lab[] lives in the LDS ring (unused outside the DP), 16 bits per row; wave 0 runs the sweep,
 // lanes 0..3 updating the first four predecessors in parallel.
 // Sweeps rows hi_start, hi_start-1, ... and returns the first row it did NOT process: it stops below
 // lo_stop (at a group boundary) -- a label is final once the sweep has reached its row, so the
@@ -1004,7 +1004,7 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 //   of 7-8 (2.18 in-edges per row: the predecessors were 40 % of the row's VALU work); 4 bytes per cell in LDS.
 // Rows older than the ring come from the record in HBM in both formats.
 #ifndef SK_D
-#define SK_D 16                                   // mailbox slots per wavefront (rows a producer may run ahead of its reader)
+#define SK_D 12                                   // mailbox slots per wavefront (rows a producer may run ahead of its reader, plus the ring rows a reader still needs); 400 B per pack: 528 cost the record-word form its seventh pack per CU
 #endif
 template <int NW> struct sk_mail {
     uint32_t cnt[NW];                             // cnt[w]: last row whose {T} wavefront w has published; n + 1: all its rows are final
@@ -1254,6 +1254,7 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             hl = (uint32_t)__builtin_amdgcn_readfirstlane((int)leH);
             sbase = (uint32_t)max((int32_t)sbase, (int32_t)Tl);
         }
+        uint32_t sbase_pub = 0;
         if (has_right) {
             const uint32_t tc = (uint32_t)max((int32_t)sbase, __builtin_amdgcn_readlane((int32_t)wincl, 63));
             cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)cr);
@@ -1261,12 +1262,15 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 __builtin_amdgcn_s_sleep(1);
                 cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sk_ld(right_cnt));
             }
-            if (lane_o == 0) sk_st(my_ent + 2 * mslot, tc);
+            sbase_pub = tc;
         }
         // the counter says two things: to the right, "my prefix of this row is in its slot (and every earlier row of mine is
         // final)"; to the left, "I have taken your slot of this row" -- so the LAST wavefront keeps it too (its left
-        // neighbour's back-pressure reads it)
-        if (n_act > 1 && lane_o == 0) sk_st(my_cnt, row);
+        // neighbour's back-pressure reads it).  One lane, one predicate for both writes.
+        if (n_act > 1 && lane_o == 0) {
+            if (has_right) sk_st(my_ent + 2 * mslot, sbase_pub);
+            sk_st(my_cnt, row);
+        }
         const s16x2 BASE = pk_max(as_pk(texcl), as_pk(sbase));
         uint32_t W[NP];
         s16x2 HN[NP];
@@ -1275,7 +1279,8 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             const s16x2 EV = pk_max(BASE, EX[u]) + JE[u];
             HN[u] = pk_max(HNp[u], EV);
             MXA = pk_max(MXA, HN[u]);
-            W[u] = as_u(HN[u]) | (as_u(pk_min(HN[u] - FN[u], pk_splat(3))) << 14);       // H (14 bits) | min(H - F, 3) << 14: record (traceback, far rows)
+            // H (14 bits) | min(H - F, 3) << 14: the record word (traceback, rows beyond the ring), shift and or in one instruction
+            asm("v_lshl_or_b32 %0, %1, 14, %2" : "=v"(W[u]) : "v"(as_u(pk_min(HN[u] - FN[u], pk_splat(3)))), "v"(as_u(HN[u])));
         }
         {
             uint32_t *rp = ring_thr + rslot * (uint32_t)(NT * RW);
@@ -1939,13 +1944,14 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 // 5 / 6 = the packed record of PK 1 written by the skewed wavefront pipeline (dp_rows_sk), ring format 0 (record words) / 1 (ready-made terms)
 __host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 5 || PK == 6; }
 __host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 6; }
-// dwords of LDS ring per thread and row; bytes of the region the ring (+ the left-column values of the barrier forms) shares with
-// the graph walks' two node bitmaps and DFS stack
+// dwords of LDS ring per thread and row; bytes of the ring (+ the left-column values of the barrier forms); bytes of the LDS behind
+// the sequence: the graph walks' two node bitmaps, their DFS stack, the ring
 __host__ __device__ constexpr uint32_t poa_ring_words(int CPL, int NW, int PK) { return pk_readymade(PK) ? CPL : !pk_packed(PK) && 64 * NW * CPL > 2048 ? CPL : CPL / 2; }
+__host__ __device__ constexpr uint32_t poa_ring_bytes(int CPL, int RING, int NW, int PK) {
+    return (uint32_t)RING * 64u * NW * poa_ring_words(CPL, NW, PK) * 4u + (uint32_t)RING * 4u * (NW > 4 ? NW : 4);
+}
 __host__ __device__ constexpr uint32_t poa_region_bytes(uint32_t node_cap, int CPL, int RING, int NW, int PK) {
-    const uint32_t walk = (2u * poa_bit_words(node_cap) + POA_STACK) * 4u;
-    const uint32_t ring = (uint32_t)RING * 64u * NW * poa_ring_words(CPL, NW, PK) * 4u + (uint32_t)RING * 4u * (NW > 4 ? NW : 4);
-    return walk > ring ? walk : ring;
+    return (2u * poa_bit_words(node_cap) + POA_STACK) * 4u + poa_ring_bytes(CPL, RING, NW, PK);      // bitmaps, stack, ring: back to back
 }
 
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
@@ -1976,12 +1982,12 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         S.aln = (int32_t *)(base + A.o_aln); S.ainfo = (uint4 *)(base + A.o_ainfo); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = poa_bit_words(A.node_cap);
         S.sq = (uint8_t *)lds;                                   // seq_cap bytes (multiple of 16)
-        // The DP's ring and the graph walks' bitmaps + stack share ONE region of LDS: the walks (topological sorts, tie labels,
-        // add_alignment's kind array, the traceback's chain) only run between two DPs, when the ring holds nothing.  4.6 KB per
-        // workgroup: the difference between six and seven (record words) or four and five (ready-made terms) packs per CU.
+        // (Sharing ONE region between the ring and the graph walks' bitmaps + stack was tried in round 4: 4.6 KB per workgroup, but the
+        // tie labels and the traceback's chain live in that region too and lost the room they need at 1536 columns with a ring of
+        // four rows -- ties fell back to the full sort, the 1536-column class went from 834 to 584 GCUPS.  Back to back again.)
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
-        S.ring = S.done;
+        S.ring = S.stack + POA_STACK;
         S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * poa_ring_words(CPL, NW, PK));
     }
 
@@ -2133,10 +2139,9 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         if (tid == 0) { atomicAdd(&A.counters[4], 1ull << 32); if (need_sort) atomicAdd(&A.counters[4], 1ull); }
 #endif
                     }
-                    const uint32_t walk_bytes = (2u * poa_bit_words(A.node_cap) + POA_STACK) * 4u, region_bytes = poa_region_bytes(A.node_cap, CPL, RING, NW, PK);
-                    if (need_sort && RING > 0 && 2u * n + walk_bytes <= region_bytes && S.n_nodes <= 0xFFFFu && !(A.debug & 1u)) {
-                        // labels instead of the full sort (tie_labels); they sit behind the bitmaps and the stack, which the replay of one root's DFS uses beside them
-                        uint16_t *lab = (uint16_t *)(S.stack + POA_STACK);
+                    if (need_sort && RING > 0 && 2u * n <= poa_ring_bytes(CPL, RING, NW, PK) && S.n_nodes <= 0xFFFFu && !(A.debug & 1u)) {
+                        // labels instead of the full sort (tie_labels): 16 bits per row in the ring's LDS, which holds nothing between two DPs
+                        uint16_t *lab = (uint16_t *)S.ring;
                         for (uint32_t r = tid; r < n; r += NT) lab[r] = (uint16_t)S.order[r];
                         if (tid == 0) { s_bc[7] = 0xFFFFFFFFu; s_bc[5] = 0; s_bc[6] = 0xFFFFFFFFu; }
                         __syncthreads();
@@ -2660,7 +2665,10 @@ static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24
 #define POA_SPARSE_PACKS_PER_CU 4
 #endif
 static const poa_variant k_dense[4] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1)};
-static const poa_variant k_sparse[4] = {POA_VARIANT(2, 8, 8, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(10, 8, 4, 6)};
+// (measured, one pack per CU, 200 reads of 1 kb / 1.45 kb: barrier form 661 / 1293 ms; skewed pipeline with ready-made terms on four
+// wavefronts 607 / 990 ms, on eight wavefronts 651 / 1046 ms -- a wavefront's own row is what a lone pack waits for, more
+// wavefronts do not shorten it)
+static const poa_variant k_sparse[4] = {POA_VARIANT(4, 8, 4, 6), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(10, 8, 4, 6)};
 // experiments (RATTLE_POA_EXP=<a>,<b>,<c>,<d>: index into the candidate table of the 1024- / 1536- / 2048- / 2560-column class; -1 or
 // absent: the default): the skewed wavefront pipeline (dp_rows_sk) with the record words (PK 5) or the ready-made terms (PK 6) in
 // its ring, on 2 / 4 / 8 wavefronts
@@ -2765,9 +2773,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // The kernel of a class is chosen per PASS from how full the device will be (round 3's verdict: one wavefront / column split
     // per class, chosen by read length only, collapsed to 0.08 of the issue roofline whenever fewer packs were resident than the
     // device has places -- 1e5 reads, the toyset, stages 2a / 3a / 3b, every rank of an 8-GPU job, the re-run of a few packs):
-    // `dense` = the most cells per instruction when every CU holds several packs; `sparse` = the shortest time per row when a
-    // pack has (most of) a CU to itself -- the same row spread over twice the wavefronts, so that the SIMDs still have a
-    // wavefront to issue from while another waits for LDS or its neighbour.
+    // `dense` = the form that keeps the most packs resident (seven or eight per CU: record words in the ring, 2 bytes per cell);
+    // `sparse` = the shortest time per row for a pack that has (most of) a CU to itself: the skewed pipeline with ready-made
+    // predecessor terms (4 bytes per cell of ring: four packs per CU at most, which is all a sparse pass has).
     int exp_pick[4] = {-1, -1, -1, -1};
     if (getenv("RATTLE_POA_EXP")) sscanf(getenv("RATTLE_POA_EXP"), "%d,%d,%d,%d", &exp_pick[0], &exp_pick[1], &exp_pick[2], &exp_pick[3]);
     const int force_mode = getenv("RATTLE_POA_MODE") ? (getenv("RATTLE_POA_MODE")[0] == 's' ? 2 : getenv("RATTLE_POA_MODE")[0] == 'd' ? 1 : 0) : 0;      // tests: "sparse" / "dense"
@@ -2820,7 +2828,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         auto lds_bytes = [&](const poa_variant *V) {
-            return (size_t)lds_seq + poa_region_bytes(ncap, (int)V->cpl, (int)V->ring, (int)V->nw, (int)V->pk) + 64;      // the ring and the graph walks' bitmaps + stack share a region
+            return (size_t)lds_seq + poa_region_bytes(ncap, (int)V->cpl, (int)V->ring, (int)V->nw, (int)V->pk) + 64;
         };
         if ((gc == 4 || gc == 5 || gc == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[gc - 4];
         if (gc == POA_CLASSES - 1 && lds_bytes(P.V) > 158u * 1024) P.V = &k_long_noring;

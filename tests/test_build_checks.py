@@ -1,6 +1,6 @@
 """Build-time checks on the generated gfx950 code (no GPU: hipcc cross-compiles).
 
-Kernel A streams the seed vector through the scalar cache with hand double-buffered `s_load_dwordx8` / `s_waitcnt lgkmcnt(0)`
+Kernel A streams the seed vector through the scalar cache with hand double-buffered `s_load_dwordx16` / `s_waitcnt lgkmcnt(0)`
 pairs written as SEPARATE inline-asm statements (rattle_amd/csrc/bv_filter.hip: BVF_SLOAD / BVF_SWAIT).  Between the two the
 compiler sees the bank as an ordinary defined SGPR value; nothing in the language stops it from copying, spilling or reading
 it there, before the scalar load has delivered.  Correctness therefore rests on the code one compiler version emits -- so the
@@ -34,17 +34,33 @@ def _sgprs(line):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_bv_filter_scalar_banks_are_not_touched_before_their_wait(tmp_path):
     lines = [l.strip() for l in _device_asm("bv_filter.hip", tmp_path)]
-    loads = [i for i, l in enumerate(lines) if l.startswith("s_load_dwordx8")]
-    assert len(loads) >= 32                       # sixteen per strand variant of the kernel: the hand-written loads are there
+    loads = [i for i, l in enumerate(lines) if l.startswith("s_load_dwordx16")]
+    assert len(loads) >= 16                       # eight per strand variant of the kernel (+ the cross-seed prefetch): the hand-written loads are there
+    labels = {re.match(r"^(\.LBB\d+_\d+):", l).group(1): i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
     for i in loads:
-        m = re.match(r"s_load_dwordx8 s\[(\d+):(\d+)\]", lines[i])
+        m = re.match(r"s_load_dwordx16 s\[(\d+):(\d+)\]", lines[i])
         bank = set(range(int(m.group(1)), int(m.group(2)) + 1))
-        j = i + 1
-        while j < len(lines) and not (lines[j].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[j]):
-            l = lines[j]
-            if l and not l.startswith((";", ".", "//")) and not l.endswith(":"):
-                body = l.split(";")[0]
+        # every path from the load to the next full lgkmcnt(0) wait (the prefetch of the next seed's first eight dwords crosses
+        # the loop's back edge): follow fall-through and branch targets
+        todo, seen, waits = [i + 1], set(), 0
+        while todo:
+            j = todo.pop()
+            while j < len(lines) and j not in seen:
+                seen.add(j)
+                l = lines[j]
+                if not l or l.startswith((";", ".", "//")) or l.split(";")[0].strip().endswith(":"):
+                    j += 1
+                    continue
+                body = l.split(";")[0].strip()
+                if body.startswith("s_waitcnt") and "lgkmcnt(0)" in body:
+                    waits += 1
+                    break
                 assert not (bank & _sgprs(body)), f"line {j + 1}: `{l}` touches s[{min(bank)}:{max(bank)}] before the wait for its load (line {i + 1})"
-                assert not body.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")), f"control flow between a load (line {i + 1}) and its wait"
-            j += 1
-        assert j < len(lines), "an s_load_dwordx8 without a following s_waitcnt lgkmcnt(0)"
+                assert not body.startswith(("s_setpc", "s_endpgm", "s_swappc")), f"line {j + 1}: the kernel may end before the load of line {i + 1} has landed"
+                t = re.match(r"(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", body)
+                if t:
+                    todo.append(labels[t.group(2)])
+                    if t.group(1) == "s_branch":
+                        break
+                j += 1
+        assert waits >= 1 and len(seen) < 400, f"the wait for the load of line {i + 1} is {len(seen)} instructions away"
