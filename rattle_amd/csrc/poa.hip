@@ -2674,8 +2674,8 @@ static const poa_variant k_sparse[4] = {POA_VARIANT(4, 8, 4, 6), POA_VARIANT(6, 
 // its ring, on 2 / 4 / 8 wavefronts
 #define POA_EXP_MAX 6
 static const poa_variant k_exp[4][POA_EXP_MAX] = {
-    {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(2, 8, 8, 5), POA_VARIANT(8, 8, 2, 6)},
-    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 6, 4, 6)},
+    {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(16, 8, 1, 6), POA_VARIANT(8, 8, 2, 6)},
+    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(24, 8, 1, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 6, 4, 6)},
     {POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5)},
     {POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 6), POA_VARIANT(10, 4, 4, 6), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5)}};
 
