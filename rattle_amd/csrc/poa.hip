@@ -2666,16 +2666,16 @@ static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24
 #endif
 static const poa_variant k_dense[4] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1)};
 // (measured, one pack per CU, 200 reads of 1 kb / 1.45 kb: barrier form 661 / 1293 ms; skewed pipeline with ready-made terms on four
-// wavefronts 607 / 990 ms, on eight wavefronts 651 / 1046 ms -- a wavefront's own row is what a lone pack waits for, more
-// wavefronts do not shorten it)
+// wavefronts 607 / 990 ms, on eight wavefronts 651 / 1046 ms, on ONE wavefront of 16 / 24 columns per lane (no mailbox at all)
+// 759 / 1333 ms -- a wavefront's own row is what a lone pack waits for: more wavefronts do not shorten it, fewer lengthen it)
 static const poa_variant k_sparse[4] = {POA_VARIANT(4, 8, 4, 6), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(10, 8, 4, 6)};
 // experiments (RATTLE_POA_EXP=<a>,<b>,<c>,<d>: index into the candidate table of the 1024- / 1536- / 2048- / 2560-column class; -1 or
 // absent: the default): the skewed wavefront pipeline (dp_rows_sk) with the record words (PK 5) or the ready-made terms (PK 6) in
 // its ring, on 2 / 4 / 8 wavefronts
 #define POA_EXP_MAX 6
 static const poa_variant k_exp[4][POA_EXP_MAX] = {
-    {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(16, 8, 1, 6), POA_VARIANT(8, 8, 2, 6)},
-    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(24, 8, 1, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 6, 4, 6)},
+    {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(2, 8, 8, 5), POA_VARIANT(8, 8, 2, 6)},
+    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 6, 4, 6)},
     {POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5)},
     {POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 6), POA_VARIANT(10, 4, 4, 6), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5)}};
 

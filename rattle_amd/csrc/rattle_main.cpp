@@ -746,11 +746,11 @@ int mode_correct(int argc, char **argv) {
     const std::vector<std::string> files = split_string(a.str("input", ""), ',');
     device_team team;
     // arena hint: ~440 kB of FASTQ per pack of 200 one-kb reads, at most a device full of resident packs in each of two
-    // column classes, ~28 MB each on average (the library asks for 80 GB at 1e6 one-kb reads; a hint that falls short
-    // costs a second allocation, not the result).  The driver clears what it hands out at ~20 ms per GB, so a generous
-    // hint is seconds of start-up.
-    const uint64_t packs_hint = std::min<uint64_t>(input_bytes(files) / 440000 + 1, 3072);
-    team_opener opener(team, a, packs_hint * (29ull << 20));
+    // column classes (1792 places x 18.4 MB + 2048 x 34.5 MB = 104 GB at 1e6 one-kb reads, round 4; a hint that falls short
+    // costs a second allocation -- 2.7 s in the first end-to-end run of round 4, when the hint was 89 GB -- not the result).  The
+    // driver clears what it hands out at ~20 ms per GB, so a generous hint is seconds of start-up.
+    const uint64_t packs_hint = std::min<uint64_t>(input_bytes(files) / 440000 + 1, 3840);
+    team_opener opener(team, a, packs_hint * (30ull << 20));
     read_table T;
     { cli_timer t("read input"); read_table_inputs(T, files, labels, a.has("write-unzipped")); }
     std::cerr << "Done" << std::endl;

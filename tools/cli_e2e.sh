@@ -15,6 +15,6 @@ with open(d + "/reads.fq", "wb") as f:
 PY
 ls -la $D/reads.fq
 s=$(date +%s%N); ./rattle_amd/csrc/rattle cluster -i $D/reads.fq -o $D -t 32 2>$D/err0.txt; (grep -E "rattle cli\]" $D/err0.txt || true); e=$(date +%s%N); echo "rattle cluster: $(( (e - s) / 1000000 )) ms"
-s=$(date +%s%N); ./rattle_amd/csrc/rattle correct -i $D/reads.fq -c $D/clusters.out -o $D -t 32 2>$D/err.txt; grep -E "rattle( cli)?\]" $D/err.txt | grep -vE "poa class|stage: |poa pass" | head -40 || true; e=$(date +%s%N); echo "rattle correct: $(( (e - s) / 1000000 )) ms"
+s=$(date +%s%N); ./rattle_amd/csrc/rattle correct -i $D/reads.fq -c $D/clusters.out -o $D -t 32 2>$D/err.txt; grep -E "rattle( cli)?\]" $D/err.txt | grep -vE "poa class|stage: " | head -40 || true; e=$(date +%s%N); echo "rattle correct: $(( (e - s) / 1000000 )) ms"
 ls -la $D | tail -5
 rm -rf $D

@@ -22,3 +22,4 @@ for f in ('bench_default','bench_under_rocprof','bench_iso'):
         if d.get('toyset'): print('   toyset', {x: d['toyset'].get(x) for x in ('cluster_s','correct_s','reads_per_s','clusters_equal_reference_fixture')})
     except Exception as e: print(f, 'failed', e)
 "
+RATTLE_TIMING=1 timeout 900 bash tools/cli_e2e.sh 1000000 > $O/cli_e2e.txt 2>&1; tail -32 $O/cli_e2e.txt
