@@ -85,7 +85,7 @@ struct poa_args {
     uint32_t *queue_head;
     uint8_t *arena;                // n_slots * slot_stride bytes
     uint64_t slot_stride;
-    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_order2, o_srank, o_rowmax, o_lh, o_nn, o_plan, o_planb, o_planc, o_H, o_F, o_E, o_aln, o_ainfo, o_spill;
+    uint64_t o_nrec, o_nal, o_edges, o_rank, o_order, o_order2, o_srank, o_rowmax, o_lh, o_nn, o_plan, o_planb, o_planc, o_pland, o_H, o_F, o_E, o_aln, o_ainfo, o_spill;
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
@@ -107,7 +107,7 @@ struct poa_args {
 enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_ERR_ALN = 4, POA_ERR_SPILL = 5, POA_ERR_GRAPH = 6 };
 
 struct poa_ws {                    // per-block workspace: global pointers + LDS + wave-uniform state
-    uint4 *nrec, *nal, *plan, *planb, *planc;
+    uint4 *nrec, *nal, *plan, *planb, *planc, *pland;
     uint2 *edges;
     int32_t *rank;                         // node -> DP row - 1 (block order), MSA column in the final pass
     uint32_t *order, *order2;              // DP row - 1 -> node (double buffer for the incremental merge)
@@ -746,22 +746,29 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 
     // the plan through the scalar cache: invalidate it first (the plan was just rewritten by vector stores, which are in L2
     // once the barrier ahead of this function has been passed); the pointers depend on the invalidate so that no load moves above it
-    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc;
-    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc) : : "memory");
-    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
+    // Round 4: the row's COMPACT plan record (poa_kernel, step 2: letter, in-degree, the distances to the first eight
+    // predecessor rows in a byte each): one s_load_dwordx4 per row instead of three, 4 + 4 plan registers instead of 12 + 12 (the
+    // kernel spills SGPRs: reloads were v_readlane in the row loop), a distance compared with the ring length instead of a
+    // subtraction per predecessor.  A predecessor beyond the ring (a few per cent) takes its row from planb / planc.
+    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc, ppd = (uint64_t)S.pland;
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc), "+s"(ppd) : : "memory");
+    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc, cpd = (cplan_t)ppd;
 
-    auto step = [&](auto w0_tag, auto par_tag, const uint32_t row, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
+    auto step = [&](auto par_tag, const uint32_t row, const u32x4 pd) __attribute__((always_inline)) {
         constexpr uint32_t par = decltype(par_tag)::value;
-        constexpr bool W0 = decltype(w0_tag)::value;          // wavefront 0 of the block: nothing to its left
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));                      // lane tests are redone per row: a hoisted mask ends up in a spilled SGPR pair (two v_readlane per use)
-        const uint32_t info = pa.x;
-        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+        const uint32_t letter = pd.x & 0xFFu;
+        const uint32_t n_in = (pd.x >> 8) & 0xFFu;           // capped at 255: the walk beyond the eighth in-edge reads the real one
+        uint32_t dist[8];                        // distances row - predecessor row, a byte each (255: 255 or more -- far beyond the ring, the row comes from planb / planc)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dist[k] = (pd.y >> (8 * k)) & 0xFFu; dist[4 + k] = (pd.z >> (8 * k)) & 0xFFu; }
         s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
         uint32_t raw[4][NP], rawl[4];
-        auto fetch = [&](const int k, const uint32_t prow) __attribute__((always_inline)) {
-            if (row - prow <= (uint32_t)RING) {
-                const uint32_t slot = prow % (uint32_t)RING;
+        // k: which of the four fetch slots; kp: which in-edge (0..7: the plan holds its row; 8: `far_row` is given)
+        auto fetch = [&](const int k, const int kp, const uint32_t d, const uint32_t far_row) __attribute__((always_inline)) {
+            if (d <= (uint32_t)RING) {
+                const uint32_t slot = (row - d) % (uint32_t)RING;
                 const uint32_t *rp = ring_thr + slot * (uint32_t)(NT * NP);
                 if constexpr (NP == 2) { const uint2 a2 = *(const uint2 *)rp; raw[k][0] = a2.x; raw[k][1] = a2.y; }
                 else if constexpr (NP == 4) { const uint4 a4 = *(const uint4 *)rp; raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; }
@@ -771,6 +778,8 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 }
                 rawl[k] = lhr[4 * slot];
             } else {
+                // beyond the ring (a few per cent of the fetches): the row itself from the full plan (the byte may be saturated)
+                const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kp >= 8 ? far_row : kp >= 4 ? cpc[row - 1][kp - 4] : cpb[row - 1][kp]));
 #pragma unroll
                 for (int u = 0; u < NP; ++u) raw[k][u] = 0x80008000u;          // H = 0, H - F = 2: what a column beyond the row decodes to
                 rawl[k] = 0;
@@ -821,31 +830,32 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 #pragma unroll
             for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
         } else {
-            fetch(0, pb.x);
-            if (n_in > 1) fetch(1, pb.y);
-            if (n_in > 2) fetch(2, pb.z);
-            if (n_in > 3) fetch(3, pb.w);
+            fetch(0, 0, dist[0], 0);
+            if (n_in > 1) fetch(1, 1, dist[1], 0);
+            if (n_in > 2) fetch(2, 2, dist[2], 0);
+            if (n_in > 3) fetch(3, 3, dist[3], 0);
             combine(std::true_type{}, raw[0], rawl[0]);
             if (n_in > 1) combine(std::false_type{}, raw[1], rawl[1]);
             if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
             if (n_in > 3) {
                 combine(std::false_type{}, raw[3], rawl[3]);
                 if (n_in > 4) {
-                    fetch(0, pc.x);
-                    if (n_in > 5) fetch(1, pc.y);
-                    if (n_in > 6) fetch(2, pc.z);
-                    if (n_in > 7) fetch(3, pc.w);
+                    fetch(0, 4, dist[4], 0);
+                    if (n_in > 5) fetch(1, 5, dist[5], 0);
+                    if (n_in > 6) fetch(2, 6, dist[6], 0);
+                    if (n_in > 7) fetch(3, 7, dist[7], 0);
                     combine(std::false_type{}, raw[0], rawl[0]);
                     if (n_in > 5) combine(std::false_type{}, raw[1], rawl[1]);
                     if (n_in > 6) combine(std::false_type{}, raw[2], rawl[2]);
                     if (n_in > 7) combine(std::false_type{}, raw[3], rawl[3]);
                     if (n_in > 8) {
-                        uint32_t e = pa.w;
-                        for (uint32_t k = 8; k < n_in; ++k) {
+                        uint32_t e = pd.w;
+                        const uint32_t n_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)rd_nin(cpa[row - 1].x));         // the record's count stops at 255
+                        for (uint32_t k = 8; k < n_all; ++k) {
                             const uint2 ed = S.edges[e]; e = ed.y;
                             const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
                             drain_vector_loads();
-                            fetch(0, prow);
+                            fetch(0, 8, row - prow, prow);
                             combine(std::false_type{}, raw[0], rawl[0]);
                         }
                     }
@@ -943,24 +953,21 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         }
     };
 
-    auto rows = [&](auto w0_tag) __attribute__((always_inline)) {
-        u32x4 na = cpa[0], nb = cpb[0], nc = cpc[0];      // plan of the next row, one row ahead
-        for (uint32_t row = 1; row <= n; row += 2) {
-            {
-                const u32x4 pa = na, pb = nb, pc = nc;
-                if (row < n) { na = cpa[row]; nb = cpb[row]; nc = cpc[row]; }
-                step(w0_tag, std::integral_constant<uint32_t, 1>{}, row, pa, pb, pc);
-            }
-            if (row + 1 <= n) {
-                const u32x4 pa = na, pb = nb, pc = nc;
-                if (row + 1 < n) { na = cpa[row + 1]; nb = cpb[row + 1]; nc = cpc[row + 1]; }
-                step(w0_tag, std::integral_constant<uint32_t, 0>{}, row + 1, pa, pb, pc);
-            }
-        }
-    };
     if (!wave_act) {
         if (NW > 1) for (uint32_t r = 0; r < n; ++r) row_barrier();
-    } else rows(std::false_type{});
+    } else {
+        // two rows per trip, two register sets for the plan record: the record of the row after next is requested into the set
+        // the row just finished has left (no copies from a "next" set into a "current" one)
+        u32x4 p0 = cpd[0], p1 = p0;
+        for (uint32_t row = 1; row <= n; row += 2) {
+            if (row < n) p1 = cpd[row];
+            step(std::integral_constant<uint32_t, 1>{}, row, p0);
+            if (row + 1 <= n) {
+                if (row + 1 < n) p0 = cpd[row + 1];
+                step(std::integral_constant<uint32_t, 0>{}, row + 1, p1);
+            }
+        }
+    }
     // block-wide best score and the threads whose columns reach it (the first row that reaches it comes from a rescan of
     // those threads' columns in the record, kernel body)
     const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
@@ -1069,16 +1076,19 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 
     if (tid < NW) M.cnt[tid] = 0;
     // the plan through the scalar cache (see dp_rows_v3)
-    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc;
-    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc) : : "memory");
-    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
+    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc, ppd = (uint64_t)S.pland;
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc), "+s"(ppd) : : "memory");
+    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc, cpd = (cplan_t)ppd;
     __syncthreads();                             // the counters are zero before anybody looks at them
 
-    auto step = [&](const uint32_t row, const uint32_t rslot, const u32x4 pa, const u32x4 pb, const u32x4 pc) __attribute__((always_inline)) {
+    auto step = [&](const uint32_t row, const uint32_t rslot, const u32x4 pd) __attribute__((always_inline)) {
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));                      // lane tests are redone per row (see dp_rows_v3)
-        const uint32_t info = pa.x;
-        const uint32_t letter = rd_letter(info), n_in = rd_nin(info);
+        // the compact plan record (see dp_rows_v3): letter, in-degree (capped at 255), the distances to the first eight predecessor rows
+        const uint32_t letter = pd.x & 0xFFu, n_in = (pd.x >> 8) & 0xFFu;
+        uint32_t dist[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dist[k] = (pd.y >> (8 * k)) & 0xFFu; dist[4 + k] = (pd.z >> (8 * k)) & 0xFFu; }
         const uint32_t mslot = row % D;
         // ---- what the neighbours say (requested first, looked at when needed) ----
         uint32_t cl = 0, cr = 0, leT = 0, leH = 0;
@@ -1097,11 +1107,13 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
         if (FMT == 0 && has_left) wait_left(row);
         s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
         uint32_t raw[4][RW], rawl[4];
-        auto fetch = [&](const int k, const uint32_t prow) __attribute__((always_inline)) {
-            if (row - prow <= (uint32_t)RING) {
+        // k: which of the four fetch slots; kp: which in-edge (0..7: the plan holds its row; 8: `far_row` is given)
+        auto fetch = [&](const int k, const int kp, const uint32_t d, const uint32_t far_row) __attribute__((always_inline)) {
+            if (d <= (uint32_t)RING) {
+                const uint32_t prow = row - d;
                 uint32_t slot;
                 if constexpr (RPOW2) slot = prow & (uint32_t)(RING - 1);
-                else { const int32_t t = (int32_t)rslot - (int32_t)(row - prow); slot = (uint32_t)(t + ((t >> 31) & RING)); }
+                else { const int32_t t = (int32_t)rslot - (int32_t)d; slot = (uint32_t)(t + ((t >> 31) & RING)); }
                 const uint32_t *rp = ring_thr + slot * (uint32_t)(NT * RW);
                 if constexpr (RW == 2) { const uint2 a2 = *(const uint2 *)rp; raw[k][0] = a2.x; raw[k][1] = a2.y; }
                 else if constexpr (RW == 4) { const uint4 a4 = *(const uint4 *)rp; raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; }
@@ -1118,7 +1130,9 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 rawl[k] = 0;
                 if (FMT == 0 && has_left) rawl[k] = sk_ld(left_ent + 2 * (prow % D) + 1);
             } else {
-                // beyond the ring (a few per cent of the fetches): the record words from HBM, decoded into the ring's format
+                // beyond the ring (a few per cent of the fetches): the record words from HBM, decoded into the ring's format; the row
+                // itself from the full plan (the distance byte may be saturated)
+                const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kp >= 8 ? far_row : kp >= 4 ? cpc[row - 1][kp - 4] : cpb[row - 1][kp]));
                 uint32_t w[NP];
 #pragma unroll
                 for (int u = 0; u < NP; ++u) w[u] = 0x80008000u;               // H = 0, H - F = 2: what a column beyond the row decodes to
@@ -1187,31 +1201,32 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 #pragma unroll
             for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
         } else {
-            fetch(0, pb.x);
-            if (n_in > 1) fetch(1, pb.y);
-            if (n_in > 2) fetch(2, pb.z);
-            if (n_in > 3) fetch(3, pb.w);
+            fetch(0, 0, dist[0], 0);
+            if (n_in > 1) fetch(1, 1, dist[1], 0);
+            if (n_in > 2) fetch(2, 2, dist[2], 0);
+            if (n_in > 3) fetch(3, 3, dist[3], 0);
             combine(std::true_type{}, raw[0], rawl[0]);
             if (n_in > 1) combine(std::false_type{}, raw[1], rawl[1]);
             if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
             if (n_in > 3) {
                 combine(std::false_type{}, raw[3], rawl[3]);
                 if (n_in > 4) {
-                    fetch(0, pc.x);
-                    if (n_in > 5) fetch(1, pc.y);
-                    if (n_in > 6) fetch(2, pc.z);
-                    if (n_in > 7) fetch(3, pc.w);
+                    fetch(0, 4, dist[4], 0);
+                    if (n_in > 5) fetch(1, 5, dist[5], 0);
+                    if (n_in > 6) fetch(2, 6, dist[6], 0);
+                    if (n_in > 7) fetch(3, 7, dist[7], 0);
                     combine(std::false_type{}, raw[0], rawl[0]);
                     if (n_in > 5) combine(std::false_type{}, raw[1], rawl[1]);
                     if (n_in > 6) combine(std::false_type{}, raw[2], rawl[2]);
                     if (n_in > 7) combine(std::false_type{}, raw[3], rawl[3]);
                     if (n_in > 8) {
-                        uint32_t e = pa.w;
-                        for (uint32_t k = 8; k < n_in; ++k) {
+                        uint32_t e = pd.w;
+                        const uint32_t n_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)rd_nin(cpa[row - 1].x));         // the record's count stops at 255
+                        for (uint32_t k = 8; k < n_all; ++k) {
                             const uint2 ed = S.edges[e]; e = ed.y;
                             const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
                             drain_vector_loads();
-                            fetch(0, prow);
+                            fetch(0, 8, row - prow, prow);
                             combine(std::false_type{}, raw[0], rawl[0]);
                         }
                     }
@@ -1321,12 +1336,12 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     };
 
     if (wave_act) {
-        u32x4 na = cpa[0], nb = cpb[0], nc = cpc[0];      // plan of the next row, one row ahead
+        u32x4 nd = cpd[0];                               // plan record of the next row, one row ahead
         uint32_t rslot = 1u % (uint32_t)RING;            // ring slot of the current row
         for (uint32_t row = 1; row <= n; ++row) {
-            const u32x4 pa = na, pb = nb, pc = nc;
-            if (row < n) { na = cpa[row]; nb = cpb[row]; nc = cpc[row]; }
-            step(row, RPOW2 ? (row & (uint32_t)(RING - 1)) : rslot, pa, pb, pc);
+            const u32x4 pd = nd;
+            if (row < n) nd = cpd[row];
+            step(row, RPOW2 ? (row & (uint32_t)(RING - 1)) : rslot, pd);
             rslot = rslot + 1u == (uint32_t)RING ? 0u : rslot + 1u;
         }
         if (n_act > 1 && lane == 0) sk_st(my_cnt, n + 1);          // every row of this wavefront is final (its last Hl is in the mailbox)
@@ -1977,7 +1992,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         uint8_t *base = A.arena + (uint64_t)blockIdx.x * A.slot_stride;
         S.nrec = (uint4 *)(base + A.o_nrec); S.nal = (uint4 *)(base + A.o_nal); S.edges = (uint2 *)(base + A.o_edges);
         S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.order2 = (uint32_t *)(base + A.o_order2);
-        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb); S.planc = (uint4 *)(base + A.o_planc);
+        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb); S.planc = (uint4 *)(base + A.o_planc); S.pland = (uint4 *)(base + A.o_pland);
         S.H = (int16_t *)(base + A.o_H); S.F = (int16_t *)(base + A.o_F); S.E = (int16_t *)(base + A.o_E);
         S.aln = (int32_t *)(base + A.o_aln); S.ainfo = (uint4 *)(base + A.o_ainfo); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = poa_bit_words(A.node_cap);
@@ -2041,12 +2056,18 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     const uint4 rec = S.nrec[v];
                     const uint32_t n_in = rd_nin(rec.x);
                     uint4 pr = make_uint4(0, 0, 0, 0), pr2 = make_uint4(0, 0, 0, 0);
+                    uint32_t dy = 0, dz = 0;
                     uint32_t e = rec.z, e5 = POA_NONE;
                     for (uint32_t k = 0; k < n_in && k < 8; ++k) {
                         uint32_t b;
                         if (k == 4) e5 = e;
                         if (k == 0) b = rec.y; else { const uint2 ed = S.edges[e]; e = ed.y; b = ed.x; }
-                        if (k < 4) u4_set(pr, k, (uint32_t)S.rank[b] + 1); else u4_set(pr2, k - 4, (uint32_t)S.rank[b] + 1);
+                        const uint32_t prow_k = (uint32_t)S.rank[b] + 1;
+                        if (k < 4) u4_set(pr, k, prow_k); else u4_set(pr2, k - 4, prow_k);
+                        {   // the compact record's distance byte (saturated)
+                            const uint32_t d = min(r + 1 - prow_k, 255u);
+                            if (k < 4) dy |= d << (8 * k); else dz |= d << (8 * (k - 4));
+                        }
 #ifdef POA_PREDSTAT
                         { const uint32_t d = r + 1 - ((uint32_t)S.rank[b] + 1); ++ps_in; if (d > (uint32_t)(RING > 0 ? RING : 1)) ++ps_far; if (d == 1) ++ps_prev; }
 #endif
@@ -2057,7 +2078,14 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     if (n_in <= 4) e5 = e;
                     S.plan[r] = make_uint4(rec.x, v, e5, e);        // .z: 5th in-edge (general code paths), .w: 9th (packed rows)
                     S.planb[r] = pr;
-                    if (pk_packed(PK)) S.planc[r] = pr2;
+                    if (pk_packed(PK)) {
+                        S.planc[r] = pr2;
+                        // the row loop's own, compact record (one s_load_dwordx4 per row instead of three, 4 plan registers instead
+                        // of 12): x = letter | min(n_in, 255) << 8, y / z = distances row - predecessor row of in-edges 1-4 / 5-8 in a
+                        // byte each (saturated at 255: such a predecessor is far beyond the ring, and the row loop takes the rows of
+                        // everything beyond the ring from planb / planc), w = edge index of the 9th in-edge
+                        S.pland[r] = make_uint4(rd_letter(rec.x) | (min(n_in, 255u) << 8), dy, dz, e);
+                    }
                 }
 #ifdef POA_PREDSTAT
                 atomicAdd(&A.counters[4], ps_in); atomicAdd(&A.counters[5], ps_far); atomicAdd(&A.counters[6], ps_prev);
@@ -2814,7 +2842,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_nrec = take((uint64_t)ncap * 16); A.o_nal = take((uint64_t)ncap * 16); A.o_edges = take((uint64_t)ecap * 8);
         A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
         A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
-        A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16);
+        A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16); A.o_pland = take((uint64_t)ncap * 16);
         const uint64_t cell_bytes = long_rows ? 4 : 2;
         if (pk_packed(P.V->pk)) {          // H words carry F's two bits, E's two bits per column sit in a per-thread array
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(0);      // E is rebuilt on demand by the traceback
