@@ -741,7 +741,12 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
     const bool wave_act = (uint32_t)wave * 64u * CPL < Lp;
     uint32_t *const ring_thr = S.ring + (size_t)tid * NP;              // slot s of this thread: ring_thr + s * NT * NP
-    uint32_t *const lhr = (uint32_t *)S.lh_ring + wave;                // slot s of this wavefront: lhr[4 * s]
+    // slot s of this wavefront: lhr[4 * s].  The LDS offset is made opaque in a VECTOR register: as a uniform value its address
+    // arithmetic went through the scalar unit (shift, add, v_mov per predecessor) -- the scalar unit issues as many instructions per
+    // cell as the vector unit in this kernel, one v_lshl_add does the same
+    uint32_t lhr_off = (uint32_t)wave;
+    asm volatile("" : "+v"(lhr_off));
+    uint32_t *const lhr = (uint32_t *)S.lh_ring + lhr_off;
     uint32_t *const Hrec = (uint32_t *)S.H;                            // the record, a dword per column pair
 
     // the plan through the scalar cache: invalidate it first (the plan was just rewritten by vector stores, which are in L2
@@ -779,19 +784,24 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
                 rawl[k] = lhr[4 * slot];
             } else {
                 // beyond the ring (a few per cent of the fetches): the row itself from the full plan (the byte may be saturated)
-                const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kp >= 8 ? far_row : kp >= 4 ? cpc[row - 1][kp - 4] : cpb[row - 1][kp]));
+                uint32_t prow = kp >= 8 ? far_row : kp >= 4 ? cpc[row - 1][kp - 4] : cpb[row - 1][kp];
+                // the scalar load lands HERE: left pending to the end of this (rare) branch, the compiler waits lgkmcnt(0) before the
+                // next predecessor's ring address on the common path too (same scalar register) -- which serialised the LDS reads of
+                // a row's predecessors
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(prow));
+                // No divergent control flow in here (threads beyond the row and the lanes that need no left neighbour load from a valid
+                // address and drop the value): with exec-mask regions inside, the compiler gave the COMMON path a flag, a second test
+                // and a second branch per predecessor.
+                const uint32_t cc = act ? c0 : 0u;
+                const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + cc);
+                const bool need_left = lane == 0 && wave > 0 && act;
+                const uint32_t hl16 = ((const uint16_t *)hq)[need_left ? -1 : 0];
 #pragma unroll
-                for (int u = 0; u < NP; ++u) raw[k][u] = 0x80008000u;          // H = 0, H - F = 2: what a column beyond the row decodes to
-                rawl[k] = 0;
-                if (act) {
-                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) raw[k][u] = hq[u];
-                    if (lane == 0 && wave > 0) rawl[k] = ((uint32_t)((const uint16_t *)S.H)[(uint64_t)prow * Lp + c0 - 1] & 0x3FFFu) << 16;
-                }
+                for (int u = 0; u < NP; ++u) { const uint32_t w = hq[u]; raw[k][u] = act ? w : 0x80008000u; }      // H = 0, H - F = 2: what a column beyond the row decodes to
+                rawl[k] = need_left ? (hl16 & 0x3FFFu) << 16 : 0u;
                 drain_vector_loads();            // rare path (1-2 % of the fetches): nothing stays pending past it
             }
-        };                         // H of the column left of this wavefront (high half), maximum over the predecessors
+        };
         uint32_t WL = 0;                         // H of the column left of this wavefront (high half), maximum over the predecessors
         auto combine = [&](auto first_tag, const uint32_t (&w)[NP], const uint32_t wl) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -1132,17 +1142,20 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
             } else {
                 // beyond the ring (a few per cent of the fetches): the record words from HBM, decoded into the ring's format; the row
                 // itself from the full plan (the distance byte may be saturated)
-                const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kp >= 8 ? far_row : kp >= 4 ? cpc[row - 1][kp - 4] : cpb[row - 1][kp]));
+                uint32_t prow = kp >= 8 ? far_row : kp >= 4 ? cpc[row - 1][kp - 4] : cpb[row - 1][kp];
+                // the scalar load lands HERE: left pending to the end of this (rare) branch, the compiler waits lgkmcnt(0) before the
+                // next predecessor's ring address on the common path too (same scalar register) -- which serialised the LDS reads of
+                // a row's predecessors
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(prow));
+                // (no divergent control flow in here: see dp_rows_v3)
                 uint32_t w[NP];
+                const uint32_t cc = act ? c0 : 0u;
+                const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + cc);
+                const bool need_left = lane == 0 && wave > 0 && act;
+                const uint32_t hl16 = ((const uint16_t *)hq)[need_left ? -1 : 0];
 #pragma unroll
-                for (int u = 0; u < NP; ++u) w[u] = 0x80008000u;               // H = 0, H - F = 2: what a column beyond the row decodes to
-                uint32_t wl = 0;
-                if (act) {
-                    const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + c0);
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) w[u] = hq[u];
-                    if (lane == 0 && wave > 0) wl = ((uint32_t)((const uint16_t *)S.H)[(uint64_t)prow * Lp + c0 - 1] & 0x3FFFu) << 16;
-                }
+                for (int u = 0; u < NP; ++u) { const uint32_t x = hq[u]; w[u] = act ? x : 0x80008000u; }      // H = 0, H - F = 2: what a column beyond the row decodes to
+                const uint32_t wl = need_left ? (hl16 & 0x3FFFu) << 16 : 0u;
                 drain_vector_loads();            // rare path: nothing stays pending past it
                 if constexpr (FMT == 0) {
 #pragma unroll
@@ -2810,7 +2823,8 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     auto choose_variants = [&]() {
         uint64_t live = 0;
         for (int c = 0; c < POA_GROUPS; ++c) live += C[c].todo.size();
-        const bool sparse = force_mode ? force_mode == 2 : live < (uint64_t)POA_SPARSE_PACKS_PER_CU * n_cu;
+        static const int per_cu = getenv("RATTLE_POA_SPARSE_PER_CU") ? atoi(getenv("RATTLE_POA_SPARSE_PER_CU")) : POA_SPARSE_PACKS_PER_CU;      // (measurement aid)
+        const bool sparse = force_mode ? force_mode == 2 : live < (uint64_t)per_cu * n_cu;
         for (int c = 0; c < POA_GROUPS; ++c) {
             C[c].V = &k_latency[poa_group_class(c)];
             if (c < 4) {

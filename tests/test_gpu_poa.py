@@ -113,3 +113,36 @@ def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
     for p, pack in enumerate(packs):
         want, _ = oracle.poa_msa(pack)
         assert rows[p] == want, p
+
+
+@pytest.mark.parametrize("env", [{}, {"RATTLE_POA_MODE": "dense"}, {"RATTLE_POA_EXP": "0,0,0,0"}, {"RATTLE_POA_EXP": "1,5,1,1"}])
+def test_predecessors_hundreds_of_rows_back_and_many_in_edges(gpu_ctx, oracle, monkeypatch, env):
+    """The row loop reads a COMPACT plan record: the distances to a row's first eight predecessor rows in a byte each, saturated
+    at 255, the in-degree capped at 255 (poa.hip, round 4).  Reads that skip 300-600 bases of the others (an exon left out) give
+    nodes whose predecessor lies far more than 255 rows back; reads that resume at many different places give one node more than
+    eight in-edges (the edge-list walk); both next to ordinary rows, in the dense and the sparse forms of the loop."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    tx = acgt[rng.integers(0, 4, 1400)]
+
+    def noisy(a, err=0.06):
+        r = rng.random(len(a))
+        b = a.copy()
+        sub = r < err * 0.4
+        b[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        return b[(r >= err * 0.7) | (r < err * 0.4)]          # a few deletions too
+
+    pack = [noisy(tx).tobytes() for _ in range(10)]
+    # exon skipping: 300 .. 620 bases left out at different places
+    for a, n in ((200, 300), (450, 620), (800, 410), (150, 505)):
+        pack.append(noisy(np.concatenate([tx[:a], tx[a + n:]])).tobytes())
+    # many different resume points into the same downstream node: prefixes of different lengths glued to the common tail from 1000 on
+    for cut in range(300, 960, 55):
+        pack.append(noisy(np.concatenate([tx[:cut], tx[1000:]]), 0.03).tobytes())
+    pack.sort(key=lambda s: -len(s))
+    rows, width, counters = gpu_ctx.poa_msa([pack, pack[::-1]])
+    for got, p in zip(rows, (pack, pack[::-1])):
+        want, _ = oracle.poa_msa(p)
+        assert got == want
