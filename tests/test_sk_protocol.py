@@ -20,7 +20,8 @@ def sim(tmp_path_factory):
 
 
 # NW, wavefronts with columns, rows, mailbox slots, ring rows, ring format
-@pytest.mark.parametrize("cfg", [(4, 4, 3000, 16, 8, 0), (4, 4, 3000, 16, 8, 1), (8, 8, 3000, 16, 8, 1), (8, 5, 3000, 16, 8, 0), (4, 2, 2000, 16, 8, 1),
+@pytest.mark.parametrize("cfg", [(4, 4, 3000, 12, 8, 0), (4, 4, 3000, 12, 8, 1), (4, 4, 3000, 12, 4, 0), (4, 3, 3000, 12, 6, 1), (8, 8, 3000, 12, 8, 1),      # the kernel's own: SK_D = 12
+                                 (4, 4, 3000, 16, 8, 0), (4, 4, 3000, 16, 8, 1), (8, 8, 3000, 16, 8, 1), (8, 5, 3000, 16, 8, 0), (4, 2, 2000, 16, 8, 1),
                                  (4, 1, 500, 16, 8, 1), (4, 4, 3000, 10, 8, 0), (4, 4, 3000, 3, 1, 1), (16, 16, 1500, 16, 4, 1), (4, 3, 40, 16, 8, 0)])
 def test_mailbox_protocol_neither_races_nor_deadlocks(sim, cfg):
     for seed in (1, 2, 3):
