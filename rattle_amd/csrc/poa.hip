@@ -89,6 +89,8 @@ struct poa_args {
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
+    uint64_t o_planm;              // multi-team rows (dp_rows_mt): the row loop's own 64-byte record per row
+    uint32_t ring_slots, ring_reach, ring_slack;      // ... and its ring, sized at launch: slots in LDS (+ one all-zero slot), rows a reader looks back, rows that may be in flight
     uint32_t debug;                // tests: bit 0 = resolve ties with the full sort, bit 1 = traceback without the LDS fast path
     uint32_t *out_col;             // per base: node id during the run, MSA column at the end
     uint32_t *out_width;           // per pack
@@ -104,10 +106,11 @@ struct poa_args {
 #define PT_NOW() 0ull
 #endif
 
-enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_ERR_ALN = 4, POA_ERR_SPILL = 5, POA_ERR_GRAPH = 6 };
+enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_ERR_ALN = 4, POA_ERR_SPILL = 5, POA_ERR_GRAPH = 6, POA_ERR_SYNC = 7 };
 
 struct poa_ws {                    // per-block workspace: global pointers + LDS + wave-uniform state
     uint4 *nrec, *nal, *plan, *planb, *planc, *pland;
+    uint32_t *planm;                       // dp_rows_mt: 16 dwords per row
     uint2 *edges;
     int32_t *rank;                         // node -> DP row - 1 (block order), MSA column in the final pass
     uint32_t *order, *order2;              // DP row - 1 -> node (double buffer for the incremental merge)
@@ -1378,6 +1381,444 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     multi = best > 0;
 }
 
+// ---- the packed row recurrence on TEAMS of wavefronts (round 5; classes up to 2560 columns, under-filled device) ------------
+// Round 4's finding: a pack that has (most of) a CU to itself is bound by ONE wavefront's instruction stream -- ~240 instructions
+// per row, ~100 of them scalar (plan decoding, a distance test and a branch per predecessor, ring-slot arithmetic) -- and by nothing
+// else: every wavefront of the skewed pipeline runs every row.  Two things change here.
+//
+// (1) Rows that do not depend on each other run at the same time.  Measured on the row plans of 200-read packs at 10 % error
+//     (profiles/round5_dag_width.txt): the longest dependency chain of an alignment's rows is 0.45 of its rows (only a third of
+//     the rows have a predecessor in the row right before them), and dealing the rows round-robin, in row order, to four teams
+//     reaches 0.453.  So the workgroup is T teams x NW column blocks: wavefront (t, w) runs the columns of block w of the rows
+//     t+1, t+1+T, ...  It waits for
+//       * its predecessor rows in ITS column block: done[w][t'] = the last row team t' has finished in block w; "every row
+//         <= x is final" is min over t' of done[w][t'] + T > x -- ONE 16-byte LDS read and one comparison with a number the plan
+//         carries (the largest predecessor row, or row - slack: that also makes the ring slot a row overwrites dead);
+//       * the wavefront to its left of the SAME team for the prefix maximum and the H of its last column (a mailbox of MT_MD
+//         entries per wavefront, back-pressure on the right neighbour's done counter, as in dp_rows_sk).
+//     All waits are for smaller rows, or the same row in a smaller block: no cycles (simulated on host threads,
+//     tests/stubs/mt_protocol_sim.cpp).
+// (2) The row is on a scalar diet.  The plan record of a row is 64 bytes (one scalar-cache line, one s_load_dwordx16, fetched a row
+//     ahead behind the row's first LDS wait) and holds everything READY-MADE: the two halves of the score table, the LDS byte
+//     offset of the row's own ring slot and of the ring slots of its first eight predecessors, the row number to wait for.
+//     Missing predecessors (and the ones beyond the ring) point at an all-zero slot (A = 0, B = g - e: the neutral element of
+//     both maxima, and what the virtual start row holds), so the common path -- up to four in-edges, all in the ring: 88 % of the
+//     rows -- has no branch at all and no per-predecessor scalar work; a second group of four takes one uniform branch; in-edges
+//     beyond the ring or beyond the eighth take the slow path.  One-lane LDS writes (counters, mailbox) are 64-lane writes whose
+//     other lanes hit a junk word: no exec-mask games.  The ring (ready-made terms, 4 bytes per cell) is sized at launch from
+//     the LDS a workgroup gets, not at compile time: the kernel only sees offsets.
+#ifndef MT_MD
+#define MT_MD 4                                   // mailbox entries per wavefront (rows of its team it may run ahead of its right neighbour)
+#endif
+#define MT_BIG 0x7FFFFF00
+#define MT_MORE4 1u                               // plan flags: in-edges 5 .. 8 are in use
+#define MT_SLOW 2u                                // ... some in-edge lies beyond the ring, or there are more than eight
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) u32x16 *cplanm_t;
+typedef __attribute__((address_space(3))) uint32_t *lds_p;
+template <int NW, int T> struct alignas(16) mt_sync {
+    int32_t done[NW][4];                          // [w][t]: last row team t has finished in column block w (teams that do not exist: MT_BIG)
+    uint32_t mcnt[NW][4];                         // [w][t]: last row whose mailbox entry (w -> w + 1) team t has published
+    uint32_t mail[NW][T][MT_MD][2];               // {prefix max of u over columns 1 .. last column of w (both halves), H of that column << 16}
+    uint32_t junk[64 * 2 + 8];                    // where the other 63 lanes of a one-lane write go
+    uint32_t abort;                               // a wavefront gave up waiting (MT_SPIN_LIMIT polls): everybody leaves, the pack fails with POA_ERR_SYNC
+};
+#ifndef MT_SPIN_LIMIT
+#define MT_SPIN_LIMIT (1u << 20)                  // polls of one wait (>= 0.1 s): every spin is bounded -- a protocol error must cost a failed call, not a hung device
+#endif
+
+template <int CPL, int NW, int T>
+__device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
+    constexpr int NTC = 64 * NW, NP = CPL / 2, RW = 2 * NP;
+    constexpr uint32_t SLOTB = (uint32_t)NTC * RW * 4u;                 // bytes of one ring slot
+    static_assert(NTC * CPL <= 2560 && CPL % 2 == 0 && T <= 4, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
+    __shared__ mt_sync<NW, T> Y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv % NW, t = wv / NW;                                  // column block, team
+    const uint32_t ct = (uint32_t)w * 64u + (uint32_t)lane;              // the thread's place in a row
+    const uint32_t c0 = ct * CPL;
+    const bool act = c0 < Lp;
+    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
+    {
+        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
+#pragma unroll
+        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
+#pragma unroll
+        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
+    }
+    uint32_t SEL[NP];                            // score table selectors (see dp_rows_v3)
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
+        const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
+        const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
+        SEL[u] = sa | (sb << 16);
+    }
+    const bool plain = S.plain != 0;
+    s16x2 JE[NP], UC[NP];                        // per column: j*e and g - (j+1)*e
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int j0 = (int)c0 + 2 * u + 1, j1 = j0 + 1;
+        const s16x2 je = {(short)(j0 * POA_E), (short)(j1 * POA_E)};
+        const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
+        JE[u] = je; UC[u] = act ? uc : pk_splat(-30000);      // threads beyond the row: u = Hn - 30000 < 0 < every valid u, no select before the scan
+    }
+    s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over this team's rows (pairs)
+    const uint32_t n_act = min((uint32_t)NW, (Lp + 64u * CPL - 1u) / (64u * CPL));      // column blocks this sequence reaches
+    const bool wave_act = (uint32_t)w < n_act, has_left = w > 0, has_right = (uint32_t)w + 1u < n_act;
+    // LDS byte addresses: this thread's entry of ring slot 0; the words a lane really writes when "lane 0" / "lane 63" publishes
+    const uint32_t rb = (uint32_t)(uintptr_t)(lds_p)S.ring + ct * (uint32_t)(RW * 4);
+    const uint32_t junk = (uint32_t)(uintptr_t)(lds_p)&Y.junk[2 * lane];
+    const uint32_t a_done = lane == 0 ? (uint32_t)(uintptr_t)(lds_p)&Y.done[w][t] : junk;
+    const uint32_t a_mcnt = lane == 63 ? (uint32_t)(uintptr_t)(lds_p)&Y.mcnt[w][t] : junk;
+    const uint32_t a_mail = lane == 63 ? (uint32_t)(uintptr_t)(lds_p)&Y.mail[w][t][0][0] : junk;       // + 8 * entry
+    const sk_ptr p_rdone = (sk_ptr)&Y.done[has_right ? w + 1 : w][t];
+    const sk_ptr p_lcnt = (sk_ptr)&Y.mcnt[has_left ? w - 1 : 0][t], p_lmail = (sk_ptr)&Y.mail[has_left ? w - 1 : 0][t][0][0];
+    uint32_t *const Hrec = (uint32_t *)S.H;                            // the record, a dword per column pair
+    const uint32_t zoff = A.ring_slots * SLOTB;                        // the all-zero slot
+    const uint32_t reach = A.ring_reach, slots = A.ring_slots;
+
+    if (tid < NW * 4) { ((int32_t *)Y.done)[tid] = (tid & 3) < T ? (tid & 3) + 1 - T : MT_BIG; ((uint32_t *)Y.mcnt)[tid] = 0; }
+    if (tid == 0) Y.abort = 0;
+    const sk_ptr p_abort = (sk_ptr)&Y.abort;
+    uint32_t dead = 0;                           // this wavefront has given up (or seen somebody who has)
+    // which = 1: predecessor rows, 2: left mailbox, 3: right neighbour's back-pressure
+    auto give_up = [&](const uint32_t which, const uint32_t row, const uint32_t seen, const uint32_t want) __attribute__((always_inline)) {
+        if (lane == 0 && atomicExch((uint32_t *)&Y.abort, 1u) == 0u) {
+            A.counters[8] = which | ((unsigned long long)t << 8) | ((unsigned long long)w << 16) | ((unsigned long long)row << 32);
+            A.counters[9] = seen | ((unsigned long long)want << 32);
+            A.counters[10] = n | ((unsigned long long)Lp << 32);
+        }
+        dead = 1u;
+    };
+    if (t == 0) {                                // the zero slot: A = H[p][j-1] = 0, B = max(H + g - e, F) = g - e
+        lds_p z = (lds_p)(uintptr_t)(rb + zoff);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) { z[u] = 0u; z[NP + u] = as_u(pk_splat(POA_G - POA_E)); }
+    }
+    // the plan through the scalar cache (see dp_rows_v3)
+    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc, ppm = (uint64_t)S.planm;
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc), "+s"(ppm) : : "memory");
+    const cplan_t cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
+    (void)ppa;
+    const cplanm_t cpm = (cplanm_t)ppm;
+    __syncthreads();                             // counters and the zero slot are in place before anybody looks at them
+
+    // ---- LDS reads of a row, issued back to back by hand and waited for ONCE ----
+    // A row used to pay four or five LDS round trips one after the other (counters, ring entries, mailbox, back-pressure: ~150
+    // cycles each for a wavefront that shares its SIMD with three others; measured: ~1400 cycles per row for ~110 instructions).
+    // Now everything a row may need is requested in one burst at its top, IN THIS ORDER (LDS operations of a wavefront complete
+    // in issue order): the done counters before the ring entries (entries at least as new as the counters that vouch for them), the
+    // left mailbox's counter before its entry.  Inline asm, because the order and the single wait are the point; every destination is
+    // tied to the wait below ("+v"), so nothing can be read before it has arrived.
+    constexpr bool Q128 = RW % 4 == 0;           // an entry is read as 16-byte pieces (thread stride a multiple of 16) or as 8-byte pieces
+    constexpr int NCH = Q128 ? RW / 4 : RW / 2;
+    struct slot_regs { u32x4 q[Q128 ? NCH : 1]; u32x2 d[Q128 ? 1 : NCH]; };
+    auto issue_slot = [&](const uint32_t off, slot_regs &r) __attribute__((always_inline)) {
+        const uint32_t va = rb + off;
+        if constexpr (Q128) {
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(r.q[0]) : "v"(va) : "memory");
+            if constexpr (NCH > 1) asm volatile("ds_read_b128 %0, %1 offset:16" : "=&v"(r.q[1]) : "v"(va) : "memory");
+        } else {
+            asm volatile("ds_read_b64 %0, %1" : "=&v"(r.d[0]) : "v"(va) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:8" : "=&v"(r.d[1]) : "v"(va) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:16" : "=&v"(r.d[2]) : "v"(va) : "memory");
+            if constexpr (NCH > 3) {
+                asm volatile("ds_read_b64 %0, %1 offset:24" : "=&v"(r.d[3]) : "v"(va) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:32" : "=&v"(r.d[4]) : "v"(va) : "memory");
+            }
+        }
+    };
+    static_assert(NCH <= 5 && (Q128 ? NCH <= 2 : (NCH == 3 || NCH == 5)), "pieces of a ring entry");
+    auto land_slot = [&](slot_regs &r) __attribute__((always_inline)) {      // (after an s_waitcnt) the values exist from here on
+        if constexpr (Q128) {
+            if constexpr (NCH > 1) asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]));
+            else asm volatile("" : "+v"(r.q[0]));
+        } else {
+            if constexpr (NCH > 3) asm volatile("" : "+v"(r.d[0]), "+v"(r.d[1]), "+v"(r.d[2]), "+v"(r.d[3]), "+v"(r.d[4]));
+            else asm volatile("" : "+v"(r.d[0]), "+v"(r.d[1]), "+v"(r.d[2]));
+        }
+    };
+    auto word = [&](const slot_regs &r, const int i) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (Q128) return r.q[i / 4][i % 4];
+        else return r.d[i / 2][i % 2];
+    };
+    auto ld_slot = [&](const uint32_t off, uint32_t (&r)[RW]) __attribute__((always_inline)) {      // (slow path) one entry, waited for
+        slot_regs x;
+        issue_slot(off, x);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        land_slot(x);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) r[i] = word(x, i);
+    };
+    auto st_slot = [&](const uint32_t off, const uint32_t (&r)[RW]) __attribute__((always_inline)) {
+        const lds_p p = (lds_p)(uintptr_t)(rb + off);
+        if constexpr (RW % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < RW / 4; ++q) { u32x4 a; a.x = r[4 * q]; a.y = r[4 * q + 1]; a.z = r[4 * q + 2]; a.w = r[4 * q + 3]; ((__attribute__((address_space(3))) u32x4 *)p)[q] = a; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < RW / 2; ++q) { u32x2 a; a.x = r[2 * q]; a.y = r[2 * q + 1]; ((__attribute__((address_space(3))) u32x2 *)p)[q] = a; }
+        }
+    };
+
+    uint32_t *hrow = Hrec + (((uint64_t)(uint32_t)(t + 1) * Lp) >> 1);           // this team's row of the record (wave-uniform), + c0 / 2 per thread
+    const uint64_t hstep = ((uint64_t)T * Lp) >> 1;
+    uint32_t mslot = 0;                                                           // mailbox entry of the current row: (row / T) % MT_MD
+    // wave-uniform switches as bits of ONE scalar (tested with s_bitcmp; as booleans captured by the row lambda they came back as
+    // v_cndmask / v_cmp pairs at every use)
+    const uint32_t FL = (uint32_t)__builtin_amdgcn_readfirstlane((int)((has_left ? 1u : 0u) | (has_right ? 2u : 0u) | (plain ? 4u : 0u)));
+    const uint32_t va_done = (uint32_t)(uintptr_t)(lds_p)&Y.done[w][0], va_rdone = (uint32_t)(uintptr_t)(lds_p)&Y.done[has_right ? w + 1 : w][t];
+    const uint32_t va_lcnt = (uint32_t)(uintptr_t)(lds_p)&Y.mcnt[has_left ? w - 1 : 0][t], va_lmail = (uint32_t)(uintptr_t)(lds_p)&Y.mail[has_left ? w - 1 : 0][t][0][0];
+
+    // one row.  pd: its plan record; nx: where the record of this team's next row is fetched to
+    auto step = [&](const uint32_t row, const u32x16 pd, u32x16 &nx) __attribute__((always_inline)) {
+        const uint32_t klo = pd[0], khi = pd[1], self_off = pd[2], ctl = pd[12];
+        const int32_t need = (int32_t)pd[3];
+        // ---- one burst: counters, the left mailbox, the four ring entries (missing predecessors are the zero slot) ----
+        u32x4 dn;
+        uint32_t rdv, lcv;
+        u32x2 lmv;
+        slot_regs e0, e1, e2, e3;
+        {
+            const uint32_t va_lm = va_lmail + 8u * mslot;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b64 %3, %7"
+                         : "=&v"(dn), "=&v"(rdv), "=&v"(lcv), "=&v"(lmv) : "v"(va_done), "v"(va_rdone), "v"(va_lcnt), "v"(va_lm) : "memory");
+        }
+        issue_slot(pd[4], e0); issue_slot(pd[5], e1); issue_slot(pd[6], e2); issue_slot(pd[7], e3);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn), "+v"(rdv), "+v"(lcv), "+v"(lmv) : : "memory");
+        land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
+        if constexpr (T > 1) {
+            // the rows this one reads are final in this column block: min over the teams of their last finished row + T > need
+            int32_t m = __builtin_amdgcn_readfirstlane(min(min((int32_t)dn.x, (int32_t)dn.y), min((int32_t)dn.z, (int32_t)dn.w)));
+            if (m + T <= need) {
+                // not yet: poll the counters alone (the ring entries are 4 to 20 LDS cycles each: a dozen waiting wavefronts re-reading
+                // them would take the LDS from the ones that work), then read the entries again
+                uint32_t spins = 0;
+                do {
+                    if (++spins > MT_SPIN_LIMIT || sk_ld(p_abort)) { give_up(1, row, (uint32_t)m, (uint32_t)need); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"(va_done) : "memory");
+                    m = __builtin_amdgcn_readfirstlane(min(min((int32_t)dn.x, (int32_t)dn.y), min((int32_t)dn.z, (int32_t)dn.w)));
+                } while (m + T <= need);
+                issue_slot(pd[4], e0); issue_slot(pd[5], e1); issue_slot(pd[6], e2); issue_slot(pd[7], e3);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
+            }
+        }
+        s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            HM[u] = pk_max(pk_max(as_pk(word(e0, u)), as_pk(word(e1, u))), pk_max(as_pk(word(e2, u)), as_pk(word(e3, u))));
+            FM[u] = pk_max(pk_max(as_pk(word(e0, NP + u)), as_pk(word(e1, NP + u))), pk_max(as_pk(word(e2, NP + u)), as_pk(word(e3, NP + u))));
+        }
+        uint32_t r0[RW];
+        if (ctl & MT_MORE4) {
+            issue_slot(pd[8], e0); issue_slot(pd[9], e1); issue_slot(pd[10], e2); issue_slot(pd[11], e3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                HM[u] = pk_max(pk_max(HM[u], as_pk(word(e0, u))), pk_max(pk_max(as_pk(word(e1, u)), as_pk(word(e2, u))), as_pk(word(e3, u))));
+                FM[u] = pk_max(pk_max(FM[u], as_pk(word(e0, NP + u))), pk_max(pk_max(as_pk(word(e1, NP + u)), as_pk(word(e2, NP + u))), as_pk(word(e3, NP + u))));
+            }
+        }
+        {   // the record of this team's next row: requested behind the row's LDS wait (lgkmcnt counts scalar loads too: ahead of it,
+            // that wait would be for the scalar cache), it has the rest of the row to arrive
+            uint64_t pp = (uint64_t)(cpm + (row + T - 1));
+            uint32_t dep = as_u(HM[0]);
+            asm volatile("" : "+s"(pp), "+v"(dep));
+            HM[0] = as_pk(dep);
+            nx = *(cplanm_t)pp;
+        }
+        if (ctl & MT_SLOW) {
+            // in-edges beyond the ring (their record words from HBM, decoded into the ring's terms) and in-edges after the eighth
+            const uint32_t n_all = pd[13], farmask = (ctl >> 8) & 0xFFu;
+            auto far_fetch = [&](uint32_t prow) __attribute__((always_inline)) {
+                uint32_t x[NP];
+                const uint32_t cc = act ? c0 : 0u;
+                const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + cc);
+                const bool need_left = lane == 0 && w > 0 && act;
+                const uint32_t hl16 = ((const uint16_t *)hq)[need_left ? -1 : 0];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { const uint32_t v = hq[u]; x[u] = act ? v : 0x80008000u; }      // H = 0, H - F = 2: what a column beyond the row decodes to
+                const uint32_t wl = need_left ? (hl16 & 0x3FFFu) << 16 : 0u;
+                drain_vector_loads();
+                uint32_t hp[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    hp[u] = x[u] & 0x3FFF3FFFu;
+                    u16x2 wu;
+                    __builtin_memcpy(&wu, &x[u], 4);
+                    const u16x2 d = __builtin_elementwise_min(wu >> (u16x2){14, 14}, (u16x2){2, 2});
+                    s16x2 ds;
+                    __builtin_memcpy(&ds, &d, 4);
+                    FM[u] = pk_max(FM[u], as_pk(hp[u]) - ds);                                        // B = H - min(H - F, 2)
+                }
+                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) HM[u] = pk_max(HM[u], pk_left(hp[u], u == 0 ? left : hp[u - 1]));      // A = H shifted by a column
+            };
+            for (uint32_t k = 0; k < 8 && k < n_all; ++k) {
+                if (!((farmask >> k) & 1u)) continue;
+                uint32_t prow = k >= 4 ? cpc[row - 1][k - 4] : cpb[row - 1][k];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(prow));
+                far_fetch(prow);
+            }
+            if (n_all > 8) {
+                uint32_t e = pd[14];
+                for (uint32_t k = 8; k < n_all; ++k) {
+                    const uint2 ed = S.edges[e]; e = ed.y;
+                    const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
+                    drain_vector_loads();
+                    if (row - prow <= reach) {
+                        ld_slot((prow % slots) * SLOTB, r0);
+#pragma unroll
+                        for (int u = 0; u < NP; ++u) { HM[u] = pk_max(HM[u], as_pk(r0[u])); FM[u] = pk_max(FM[u], as_pk(r0[NP + u])); }
+                    } else far_fetch(prow);
+                }
+            }
+        }
+        // ---- Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair) ----
+        s16x2 HNp[NP], EX[NP], SC[NP], FN[NP];
+        s16x2 RUN = pk_splat(-32768);
+        if (FL & 4u) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) SC[u] = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
+        } else {
+            const uint32_t letter = ctl >> 24;
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
+                SC[u] = as_pk(pack16(s0, s1));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            FN[u] = FM[u] + pk_splat(POA_E);
+            HNp[u] = pk_max(pk_max(HM[u] + SC[u], FN[u]), pk_splat(0));
+            const s16x2 v = pk_max(RUN, HNp[u] + UC[u]);                                   // (max(run, u_a), max(run, u_b))
+            EX[u] = as_pk(__builtin_amdgcn_alignbit(as_u(v), as_u(RUN), 16));              // (run, max(run, u_a)): both halves of RUN are equal
+            RUN = pk_max(v, __builtin_shufflevector(v, v, 1, 0));                          // max(run, u_a, u_b) in both halves
+        }
+        const uint32_t wincl = wave_scan_max_dup(as_u(RUN));
+        const uint32_t texcl = (uint32_t)wave_shr1((int32_t)wincl, (int32_t)0x80008000u);
+        // ---- the prefix over the column blocks to the left (same team), ours to the right ----
+        uint32_t sbase = as_u(pk_splat(POA_G - POA_E));        // u_0
+        uint32_t hl = 0;
+        if (FL & 1u) {
+            // what the burst at the top of the row found in the left mailbox is this row's if the left wavefront had already published
+            // it (a wavefront that trails its left neighbour by half a row or more: no wait at all); otherwise poll
+            uint32_t cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)lcv), leT = lmv.x, leH = lmv.y;
+            uint32_t spins = 0;
+            while ((int32_t)(cl - row) < 0) {
+                if (++spins > MT_SPIN_LIMIT || sk_ld(p_abort)) { give_up(2, row, cl, row); break; }
+                __builtin_amdgcn_s_sleep(1);
+                cl = sk_ld(p_lcnt); leT = sk_ld(p_lmail + 2 * mslot); leH = sk_ld(p_lmail + 2 * mslot + 1);
+                cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl);
+            }
+            hl = (uint32_t)__builtin_amdgcn_readfirstlane((int)leH);
+            sbase = (uint32_t)max((int32_t)sbase, __builtin_amdgcn_readfirstlane((int)leT));
+        }
+        const s16x2 BASE = pk_max(as_pk(texcl), as_pk(sbase));
+        uint32_t W[NP];
+        s16x2 HN[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const s16x2 EV = pk_max(BASE, EX[u]) + JE[u];
+            HN[u] = pk_max(HNp[u], EV);
+        }
+        // What other wavefronts wait for goes out FIRST, in the order of who waits longest: the mailbox entry (the column block to the
+        // right, same row), the ring entry + counter (rows that read this one); the record word, the running maximum and the record
+        // store are nobody's critical path (a lone wavefront issues in order: every instruction ahead of a publication delays it).
+        if (FL & 2u) {
+            // the entry this row's mail goes to still holds row - MT_MD * T: its reader has finished that row (the counter read at the
+            // top of the row says so almost always: it only grows)
+            int32_t cr = __builtin_amdgcn_readfirstlane((int32_t)rdv);
+            uint32_t spins = 0;
+            while (cr + (int32_t)(MT_MD * T) < (int32_t)row) {
+                if (++spins > MT_SPIN_LIMIT || sk_ld(p_abort)) { give_up(3, row, (uint32_t)cr, row); break; }
+                __builtin_amdgcn_s_sleep(1);
+                cr = __builtin_amdgcn_readfirstlane((int32_t)sk_ld(p_rdone));
+            }
+            const uint32_t tc = (uint32_t)max((int32_t)sbase, __builtin_amdgcn_readlane((int32_t)wincl, 63));
+            // lane 63 writes {prefix, H of its last column (high half)} and then the counter; the other lanes write junk words
+            const lds_p mp = (lds_p)(uintptr_t)(a_mail + 8u * mslot);
+            { u32x2 mv; mv.x = tc; mv.y = as_u(HN[NP - 1]); *(volatile __attribute__((address_space(3))) u32x2 *)mp = mv; }
+            *(volatile lds_p)(uintptr_t)a_mcnt = row;
+        }
+        {
+            uint32_t R[RW];
+            const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HN[NP - 1]), (int32_t)hl);       // lane 0: the H the left column block published
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                R[u] = as_u(pk_left(as_u(HN[u]), u == 0 ? left : as_u(HN[u - 1])));
+                R[NP + u] = as_u(pk_max(HN[u] - pk_splat(2), FN[u]));
+            }
+            st_slot(self_off, R);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NP; ++u)         // H (14 bits) | min(H - F, 3) << 14: the record word (traceback, rows beyond the ring)
+                asm("v_lshl_or_b32 %0, %1, 14, %2" : "=v"(W[u]) : "v"(as_u(pk_min(HN[u] - FN[u], pk_splat(3)))), "v"(as_u(HN[u])));
+            if (act) {                           // the record BEFORE the counter: a row that reads it back from HBM (beyond the ring) issues its load after it has seen the counter
+                uint32_t *hq = hrow + (c0 >> 1);
+                if (NP % 2 == 0) {
+#pragma unroll
+                    for (int u = 0; u < NP / 2; ++u) ((uint2 *)hq)[u] = make_uint2(W[2 * u], W[2 * u + 1]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) hq[u] = W[u];
+                }
+            }
+            if constexpr (T > 1 || NW > 1) *(volatile lds_p)(uintptr_t)a_done = row;       // after the ring entry (LDS operations of a wavefront complete in order)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) MXA = pk_max(MXA, HN[u]);
+        }
+        hrow += hstep;
+        mslot = (mslot + 1u) & (uint32_t)(MT_MD - 1);
+    };
+
+    if (wave_act) {
+        // two rows per trip, two register sets for the plan record (no copies)
+        u32x16 pa = cpm[t], pb = pa;
+        uint32_t row = (uint32_t)t + 1u;
+        while (row <= n && !__builtin_amdgcn_readfirstlane((int)dead)) {
+            step(row, pa, pb);
+            row += T;
+            if (row > n || __builtin_amdgcn_readfirstlane((int)dead)) break;
+            step(row, pb, pa);
+            row += T;
+        }
+        *(volatile lds_p)(uintptr_t)a_done = (uint32_t)MT_BIG;          // every row of this wavefront is final
+    }
+    // block-wide best score and the row threads (places in a row) whose columns reach it (the first row that reaches it comes from
+    // a rescan of those columns in the record, kernel body).  A place is held by T threads, one per team: flags in LDS, one entry each.
+    const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
+    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) X.best[wv] = wb;
+    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
+    __syncthreads();                             // (also: every row loop has ended, the ring is free)
+    best = 0;
+#pragma unroll
+    for (int q = 0; q < NW * T; ++q) best = max(best, X.best[q]);
+    uint8_t *flag = (uint8_t *)S.ring;
+    if (tid < NTC) flag[tid] = 0;
+    __syncthreads();
+    if (best > 0 && lbest == best) flag[ct] = 1;
+    __syncthreads();
+    if (tid < NTC && flag[tid]) {
+        const uint32_t slot = atomicAdd(&X.ntl, 1u);
+        if (slot < 16) X.tl[slot] = (uint32_t)tid;
+    }
+    __syncthreads();
+    best_row = 0;
+    multi = best > 0;
+    if (sk_ld(p_abort)) { S.err = POA_ERR_SYNC; best = 0; multi = false; }      // (uniform: the barriers above have passed)
+}
+
 // ---- rows of 2561 .. 8192 columns (PK == 3): 32-bit cells, up to SIXTEEN wavefronts per pack ------------------
 // A pack of long reads used to be one workgroup of four wavefronts with 16-32 columns per lane in 250-410 registers: one
 // wavefront per SIMD, one pack per CU, tens of seconds per pack while most of the device idled (config 5).  Here the row is
@@ -1970,8 +2411,11 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 // PK: 0 = 32-bit registers + int16 record + nibbles (dp_rows), 1 = packed int16 pairs, record word H | min(H-F,3) << 14 (dp_rows_v3),
 // 2 = int32 segments (dp_rows_long / _longr), 3 = 32-bit cells on up to 16 wavefronts (dp_rows_wide),
 // 5 / 6 = the packed record of PK 1 written by the skewed wavefront pipeline (dp_rows_sk), ring format 0 (record words) / 1 (ready-made terms)
-__host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 5 || PK == 6; }
-__host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 6; }
+// 7 = the same record written by teams of wavefronts (dp_rows_mt): the RING template argument is the number of TEAMS, the ring is sized at launch
+__host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 5 || PK == 6 || PK == 7; }
+__host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 6 || PK == 7; }
+__host__ __device__ constexpr int pk_teams(int RING, int PK) { return PK == 7 ? RING : 1; }
+__host__ __device__ constexpr uint32_t mt_slot_bytes(int CPL, int NW) { return 64u * NW * CPL * 4u; }      // one ring slot of dp_rows_mt: 4 bytes per cell
 // dwords of LDS ring per thread and row; bytes of the ring (+ the left-column values of the barrier forms); bytes of the LDS behind
 // the sequence: the graph walks' two node bitmaps, their DFS stack, the ring
 __host__ __device__ constexpr uint32_t poa_ring_words(int CPL, int NW, int PK) { return pk_readymade(PK) ? CPL : !pk_packed(PK) && 64 * NW * CPL > 2048 ? CPL : CPL / 2; }
@@ -1984,13 +2428,14 @@ __host__ __device__ constexpr uint32_t poa_region_bytes(uint32_t node_cap, int C
 
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
-constexpr int poa_min_waves(int CPL, int NW, int PK) {
-    return PK == 5 || PK == 6 ? (((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4 > 8 ? 8 : ((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4)
+constexpr int poa_min_waves(int CPL, int NW, int PK, int RING_OR_T = 1) {
+    return PK == 7 ? (RING_OR_T == 2 ? 6 : 4) : PK == 5 || PK == 6 ? (((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4 > 8 ? 8 : ((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4)
          : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : 1;
 }
 template <int CPL, int RING, int NW, int PK>
-__global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kernel(poa_args A) {
-    constexpr uint32_t NT = 64 * NW;
+__global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW, PK, RING)) void poa_kernel(poa_args A) {
+    constexpr uint32_t NT = 64 * NW * pk_teams(RING, PK);      // threads of the workgroup
+    constexpr uint32_t NTC = 64 * NW;                          // threads a row is spread over
     using cell_t = typename std::conditional<PK == 2, int32_t, uint16_t>::type;     // DP matrix cell (16-bit records hold H >= 0 unsigned)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t s_pack;
@@ -2005,7 +2450,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         uint8_t *base = A.arena + (uint64_t)blockIdx.x * A.slot_stride;
         S.nrec = (uint4 *)(base + A.o_nrec); S.nal = (uint4 *)(base + A.o_nal); S.edges = (uint2 *)(base + A.o_edges);
         S.rank = (int32_t *)(base + A.o_rank); S.order = (uint32_t *)(base + A.o_order); S.order2 = (uint32_t *)(base + A.o_order2);
-        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb); S.planc = (uint4 *)(base + A.o_planc); S.pland = (uint4 *)(base + A.o_pland);
+        S.srank = (int32_t *)(base + A.o_srank); S.rowmax = (int32_t *)(base + A.o_rowmax); S.lh = (int32_t *)(base + A.o_lh); S.nn = (uint32_t *)(base + A.o_nn); S.plan = (uint4 *)(base + A.o_plan); S.planb = (uint4 *)(base + A.o_planb); S.planc = (uint4 *)(base + A.o_planc); S.pland = (uint4 *)(base + A.o_pland); S.planm = (uint32_t *)(base + A.o_planm);
         S.H = (int16_t *)(base + A.o_H); S.F = (int16_t *)(base + A.o_F); S.E = (int16_t *)(base + A.o_E);
         S.aln = (int32_t *)(base + A.o_aln); S.ainfo = (uint4 *)(base + A.o_ainfo); S.spill = (uint32_t *)(base + A.o_spill);
         const uint32_t bit_words = poa_bit_words(A.node_cap);
@@ -2016,8 +2461,10 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)RING * NT * poa_ring_words(CPL, NW, PK));
+        S.lh_ring = (int32_t *)(S.ring + (size_t)(PK == 7 ? 0 : RING) * NT * poa_ring_words(CPL, NW, PK));
     }
+    // bytes of the LDS ring (between two DPs: room for the tie labels and the traceback's chain)
+    const uint32_t ring_bytes = PK == 7 ? (A.ring_slots + 1u) * mt_slot_bytes(CPL, NW) : poa_ring_bytes(CPL, RING, NW, PK);
 
     while (true) {
         __syncthreads();
@@ -2057,7 +2504,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
             if (S.n_nodes > 0) {
                 const uint32_t n = S.n_nodes;
                 const uint32_t Lp = (L + CPL - 1) / CPL * CPL;
-                if ((uint64_t)(n + 1) * Lp > A.cell_cap || (PK != 2 && Lp > NT * CPL)) { S.err = POA_ERR_CELLS; break; }
+                if ((uint64_t)(n + 1) * Lp > A.cell_cap || (PK != 2 && Lp > NTC * CPL)) { S.err = POA_ERR_CELLS; break; }
                 // ---- 1. rows are taken in the incrementally maintained block order (merge_order) ----
                 unsigned long long t0 = PT_NOW();
                 // ---- 2. plan + sequence to LDS (all threads) ----
@@ -2099,6 +2546,37 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         // everything beyond the ring from planb / planc), w = edge index of the 9th in-edge
                         S.pland[r] = make_uint4(rd_letter(rec.x) | (min(n_in, 255u) << 8), dy, dz, e);
                     }
+                    if constexpr (PK == 7) {
+                        // dp_rows_mt's record, everything ready-made (see there): score table halves, LDS offsets of the row's own ring
+                        // slot and of the slots of its first eight predecessors (the all-zero slot for the missing ones and for the ones
+                        // beyond the ring), the row that must be final before this one starts
+                        constexpr uint32_t SLOTB = mt_slot_bytes(CPL, NW);
+                        const uint32_t slots = A.ring_slots, reach = A.ring_reach, zoff = slots * SLOTB;
+                        uint32_t po[8], farmask = 0, need_row = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) {
+                            po[k] = zoff;
+                            if (k < n_in) {
+                                const uint32_t prow_k = k < 4 ? u4_get(pr, k) : u4_get(pr2, k - 4);
+                                need_row = max(need_row, prow_k);            // in the ring or not: the row must be final (and its record stored) before this one reads it
+                                if (r + 1 - prow_k <= reach) po[k] = (prow_k % slots) * SLOTB;
+                                else farmask |= 1u << k;
+                            }
+                        }
+                        if (n_in > 8) {                                  // (rare) the rows of the further in-edges count for the wait as well
+                            uint32_t e2 = e;
+                            for (uint32_t k = 8; k < n_in; ++k) { const uint2 ed = S.edges[e2]; e2 = ed.y; need_row = max(need_row, (uint32_t)S.rank[ed.x] + 1); }
+                        }
+                        const int32_t need = max((int32_t)need_row, (int32_t)(r + 1) - (int32_t)A.ring_slack);
+                        const uint32_t letter = rd_letter(rec.x), li = (letter >> 1) & 3u;
+                        const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));      // low / high bytes of {-4, -4, -4, -4} with 5 at li
+                        const uint32_t ctl = (n_in > 4 ? MT_MORE4 : 0u) | ((farmask || n_in > 8) ? MT_SLOW : 0u) | (farmask << 8) | (letter << 24);
+                        uint4 *pm = (uint4 *)(S.planm + 16 * (size_t)r);
+                        pm[0] = make_uint4(klo, khi, ((r + 1) % slots) * SLOTB, (uint32_t)need);
+                        pm[1] = make_uint4(po[0], po[1], po[2], po[3]);
+                        pm[2] = make_uint4(po[4], po[5], po[6], po[7]);
+                        pm[3] = make_uint4(ctl, n_in, e, 0);
+                    }
                 }
 #ifdef POA_PREDSTAT
                 atomicAdd(&A.counters[4], ps_in); atomicAdd(&A.counters[5], ps_far); atomicAdd(&A.counters[6], ps_prev);
@@ -2113,6 +2591,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                 if constexpr (PK == 2 && RING > 0) dp_rows_longr<CPL, RING, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 3) dp_rows_wide<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
+                else if constexpr (PK == 7) dp_rows_mt<CPL, NW, RING>(S, X, A, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 5 || PK == 6) dp_rows_sk<CPL, RING, NW, PK == 6 ? 1 : 0>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
@@ -2180,7 +2659,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                         if (tid == 0) { atomicAdd(&A.counters[4], 1ull << 32); if (need_sort) atomicAdd(&A.counters[4], 1ull); }
 #endif
                     }
-                    if (need_sort && RING > 0 && 2u * n <= poa_ring_bytes(CPL, RING, NW, PK) && S.n_nodes <= 0xFFFFu && !(A.debug & 1u)) {
+                    if (need_sort && RING > 0 && 2u * n <= ring_bytes && S.n_nodes <= 0xFFFFu && !(A.debug & 1u)) {
                         // labels instead of the full sort (tie_labels): 16 bits per row in the ring's LDS, which holds nothing between two DPs
                         uint16_t *lab = (uint16_t *)S.ring;
                         for (uint32_t r = tid; r < n; r += NT) lab[r] = (uint16_t)S.order[r];
@@ -2271,7 +2750,7 @@ __global__ __launch_bounds__(64 * NW, poa_min_waves(CPL, NW, PK)) void poa_kerne
                     // by the general code (all lanes uniformly, lane 0 writes).  aln[] receives (row | -1, pos | -1);
                     // rows become node ids in add_alignment.
                     uint16_t *tq0 = (uint16_t *)S.done;                   // [n+1] row of the first in-edge (0: none / virtual)
-                    const uint32_t tb_bytes = poa_region_bytes(A.node_cap, CPL, RING, NW, PK);
+                    const uint32_t tb_bytes = (2u * poa_bit_words(A.node_cap) + POA_STACK) * 4u + ring_bytes;
                     const bool fast_tb = 3u * (n + 2u) <= tb_bytes && n < 0xFFFFu && !(A.debug & 2u);
                     uint8_t *tlet = (uint8_t *)(tq0 + (n + 2u));          // [n+1] letter of the row's node
                     if (fast_tb) {
@@ -2668,14 +3147,14 @@ template <int CPL, int RING, int NW, int PK>
 static hipError_t launch_poa(const poa_args &A, uint32_t n_slots, size_t shm, hipStream_t st) {
     if (shm > 60 * 1024)
         (void)hipFuncSetAttribute((const void *)poa_kernel<CPL, RING, NW, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((poa_kernel<CPL, RING, NW, PK>), dim3(n_slots), dim3(64 * NW), shm, st, A);
+    hipLaunchKernelGGL((poa_kernel<CPL, RING, NW, PK>), dim3(n_slots), dim3(64 * NW * pk_teams(RING, PK)), shm, st, A);
     return hipGetLastError();
 }
 
 template <int CPL, int RING, int NW, int PK>
 static int max_blocks_per_cu(size_t shm) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, RING, NW, PK>, 64 * NW, shm) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, poa_kernel<CPL, RING, NW, PK>, 64 * NW * pk_teams(RING, PK), shm) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
@@ -2710,15 +3189,23 @@ static const poa_variant k_dense[4] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_V
 // wavefronts 607 / 990 ms, on eight wavefronts 651 / 1046 ms, on ONE wavefront of 16 / 24 columns per lane (no mailbox at all)
 // 759 / 1333 ms -- a wavefront's own row is what a lone pack waits for: more wavefronts do not shorten it, fewer lengthen it)
 static const poa_variant k_sparse[4] = {POA_VARIANT(4, 8, 4, 6), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(10, 8, 4, 6)};
+// teams of wavefronts (dp_rows_mt; the second argument is the number of TEAMS, the ring is sized at launch): four teams for a pack
+// that has a CU to itself, two when two or three packs share one, one = the lean skewed pipeline
+static const poa_variant k_mt4[4] = {POA_VARIANT(4, 4, 4, 7), POA_VARIANT(6, 4, 4, 7), POA_VARIANT(8, 4, 4, 7), POA_VARIANT(10, 4, 4, 7)};
+static const poa_variant k_mt2[4] = {POA_VARIANT(4, 2, 4, 7), POA_VARIANT(6, 2, 4, 7), POA_VARIANT(8, 2, 4, 7), POA_VARIANT(10, 2, 4, 7)};
+static const poa_variant k_mt4w = POA_VARIANT(8, 4, 2, 7);      // (measurement) 1024 columns as two column blocks of 8 columns per lane: fewer instructions per cell, eight wavefronts
+static const poa_variant k_mt1[4] = {POA_VARIANT(4, 1, 4, 7), POA_VARIANT(6, 1, 4, 7), POA_VARIANT(8, 1, 4, 7), POA_VARIANT(10, 1, 4, 7)};
 // experiments (RATTLE_POA_EXP=<a>,<b>,<c>,<d>: index into the candidate table of the 1024- / 1536- / 2048- / 2560-column class; -1 or
 // absent: the default): the skewed wavefront pipeline (dp_rows_sk) with the record words (PK 5) or the ready-made terms (PK 6) in
 // its ring, on 2 / 4 / 8 wavefronts
 #define POA_EXP_MAX 6
+#ifdef POA_EXPERIMENTS
 static const poa_variant k_exp[4][POA_EXP_MAX] = {
     {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(2, 8, 8, 5), POA_VARIANT(8, 8, 2, 6)},
     {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 6, 4, 6)},
     {POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5)},
     {POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 6), POA_VARIANT(10, 4, 4, 6), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5)}};
+#endif
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -2819,17 +3306,24 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // predecessor terms (4 bytes per cell of ring: four packs per CU at most, which is all a sparse pass has).
     int exp_pick[4] = {-1, -1, -1, -1};
     if (getenv("RATTLE_POA_EXP")) sscanf(getenv("RATTLE_POA_EXP"), "%d,%d,%d,%d", &exp_pick[0], &exp_pick[1], &exp_pick[2], &exp_pick[3]);
-    const int force_mode = getenv("RATTLE_POA_MODE") ? (getenv("RATTLE_POA_MODE")[0] == 's' ? 2 : getenv("RATTLE_POA_MODE")[0] == 'd' ? 1 : 0) : 0;      // tests: "sparse" / "dense"
+    // tests / measurements: RATTLE_POA_MODE = dense | sparse | mt4 | mt2 | mt1 forces one form for the packed classes
+    const char *mode_s = getenv("RATTLE_POA_MODE");
+    const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : mode_s[0] == 's' ? 2 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : !strcmp(mode_s, "mt4w") ? 6 : 0;
+    uint32_t live_per_cu = 1;                      // packs per CU the pass about to start will keep resident (all classes)
     auto choose_variants = [&]() {
         uint64_t live = 0;
         for (int c = 0; c < POA_GROUPS; ++c) live += C[c].todo.size();
-        static const int per_cu = getenv("RATTLE_POA_SPARSE_PER_CU") ? atoi(getenv("RATTLE_POA_SPARSE_PER_CU")) : POA_SPARSE_PACKS_PER_CU;      // (measurement aid)
-        const bool sparse = force_mode ? force_mode == 2 : live < (uint64_t)per_cu * n_cu;
+        live_per_cu = (uint32_t)std::max<uint64_t>(1, (live + n_cu - 1) / n_cu);
+        // by packs per CU: one -> four teams per pack (16 wavefronts: the CU is the pack's); two or three -> two teams; four -> the skewed
+        // pipeline with ready-made terms (LDS holds four such rings); more -> the barrier form with record words (seven or eight per CU)
+        int mode = force_mode ? force_mode : live_per_cu <= 1 ? 3 : live_per_cu <= 3 ? 4 : live_per_cu <= POA_SPARSE_PACKS_PER_CU ? 2 : 1;
         for (int c = 0; c < POA_GROUPS; ++c) {
             C[c].V = &k_latency[poa_group_class(c)];
             if (c < 4) {
-                C[c].V = sparse ? &k_sparse[c] : &k_dense[c];
+                C[c].V = mode == 1 ? &k_dense[c] : mode == 2 ? &k_sparse[c] : mode == 3 ? &k_mt4[c] : mode == 4 ? &k_mt2[c] : mode == 6 ? (c == 0 ? &k_mt4w : &k_mt4[c]) : &k_mt1[c];
+#ifdef POA_EXPERIMENTS
                 if (exp_pick[c] >= 0 && exp_pick[c] < POA_EXP_MAX) C[c].V = &k_exp[c][exp_pick[c]];
+#endif
             }
         }
     };
@@ -2857,6 +3351,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
         A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
         A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16); A.o_pland = take((uint64_t)ncap * 16);
+        A.o_planm = take(P.V->pk == 7 ? ((uint64_t)ncap + 8) * 64 : 0);
         const uint64_t cell_bytes = long_rows ? 4 : 2;
         if (pk_packed(P.V->pk)) {          // H words carry F's two bits, E's two bits per column sit in a per-thread array
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(0);      // E is rebuilt on demand by the traceback
@@ -2869,9 +3364,31 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         P.per_slot = o;
         A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
         const uint32_t lds_seq = long_rows ? 16u : qcap;
+        A.ring_slots = A.ring_reach = A.ring_slack = 0;
+        if (P.V->pk == 7) {
+            // dp_rows_mt: the ring takes the LDS a workgroup can have when `live_per_cu` packs share a CU (up to 24 slots + the zero
+            // slot); `slack` rows may be in flight behind the reader (two rounds of the teams when there is room, one otherwise),
+            // `reach` = slots - slack rows back are served from the ring, the rest from the record in HBM
+            const uint32_t teams = P.V->ring, slotb = mt_slot_bytes((int)P.V->cpl, (int)P.V->nw);
+            const uint32_t fixed = lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + 64u + 3072u;      // + the kernel's static LDS
+            uint32_t ppc = std::max<uint32_t>(1, std::min<uint32_t>(live_per_cu, teams == 4 ? 1u : teams == 2 ? 3u : 4u));
+            uint32_t slots = 0, slack = 0;
+            for (; ppc >= 1; --ppc) {
+                const uint32_t room = 160u * 1024 / ppc;
+                slots = room > fixed + 2 * slotb ? std::min<uint32_t>(24, (room - fixed) / slotb - 1) : 0;
+                slack = teams > 1 ? std::max<uint32_t>(teams, std::min<uint32_t>(2 * teams, slots > 10 ? slots - 10 : 0)) : 0;
+                if (slots >= slack + 6 || ppc == 1) break;
+            }
+            if (slots < slack + 2) { slots = slack + 2; }      // (the launch fails loudly if even that does not fit)
+            if (getenv("RATTLE_POA_MT_SLOTS")) slots = std::max<uint32_t>(slack + 2, (uint32_t)atoi(getenv("RATTLE_POA_MT_SLOTS")));      // tests: a short ring, to exercise the record path
+            A.ring_slots = slots; A.ring_slack = slack; A.ring_reach = slots - slack;
+        }
         auto lds_bytes = [&](const poa_variant *V) {
+            if (V->pk == 7) return (size_t)lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + (size_t)(A.ring_slots + 1) * mt_slot_bytes((int)V->cpl, (int)V->nw) + 64;
             return (size_t)lds_seq + poa_region_bytes(ncap, (int)V->cpl, (int)V->ring, (int)V->nw, (int)V->pk) + 64;
         };
+        // a retry pass with a huge graph: the node bitmaps leave no room for a ready-made ring -- fall back to the dense form (2 bytes per cell)
+        if (gc < 4 && P.V->pk != 1 && lds_bytes(P.V) > 158u * 1024) { P.V = &k_dense[gc]; A.ring_slots = A.ring_reach = A.ring_slack = 0; A.o_planm = take(0); }
         if ((gc == 4 || gc == 5 || gc == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[gc - 4];
         if (gc == POA_CLASSES - 1 && lds_bytes(P.V) > 158u * 1024) P.V = &k_long_noring;
         P.shm = lds_bytes(P.V);
@@ -2999,8 +3516,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             aoff += P.per_slot * P.n_slots;
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
-                fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, ring %u) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl, P.V->ring, pass, P.todo.size(), P.n_slots,
+                fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, %s %u%s) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
+                        poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl,
+                        P.V->pk == 7 ? "teams" : "ring", P.V->ring, P.V->pk == 7 ? (", ring " + std::to_string(A.ring_slots) + " reach " + std::to_string(A.ring_reach)).c_str() : "", pass, P.todo.size(), P.n_slots,
                         P.per_slot / 1e6, P.bpc);
         }
         if (e != hipSuccess) { set_error(std::string("poa setup: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; break; }
@@ -3060,7 +3578,16 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 const uint32_t s = h_status[p];
                 if (s == POA_OK) continue;
                 if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) again.push_back(p);
-                else { set_error("poa_kernel: pack " + std::to_string(p) + " failed with status " + std::to_string(s)); rc = RATTLE_ERR_HIP; break; }
+                else {
+                    std::string msg = "poa_kernel: pack " + std::to_string(p) + " failed with status " + std::to_string(s);
+                    if (s == POA_ERR_SYNC) {       // a wavefront of dp_rows_mt gave up waiting: say who, for what, at which row
+                        unsigned long long dbg[3] = {0, 0, 0};
+                        (void)hipMemcpy(dbg, d_cnt.p + 8, sizeof(dbg), hipMemcpyDeviceToHost);
+                        msg += " (wait " + std::to_string(dbg[0] & 0xFF) + " of team " + std::to_string((dbg[0] >> 8) & 0xFF) + " block " + std::to_string((dbg[0] >> 16) & 0xFF) + " at row " + std::to_string(dbg[0] >> 32) +
+                               ": saw " + std::to_string((int32_t)(dbg[1] & 0xFFFFFFFFu)) + ", wants " + std::to_string((int32_t)(dbg[1] >> 32)) + "; rows " + std::to_string(dbg[2] & 0xFFFFFFFFu) + ", columns " + std::to_string(dbg[2] >> 32) + ")";
+                    }
+                    set_error(msg); rc = RATTLE_ERR_HIP; break;
+                }
             }
             P.todo.swap(again);
             if (!P.todo.empty()) {

@@ -97,15 +97,44 @@ def test_length_classes_match_oracle(gpu_ctx, oracle, length, depth):
         assert got == want
 
 
+@pytest.mark.parametrize("mode", ["dense", "sparse", "mt4", "mt2", "mt1"])
+@pytest.mark.parametrize("length,depth", [(700, 40), (1300, 30), (1800, 25), (2300, 20)])
+def test_packed_classes_in_every_form_of_the_row_loop(gpu_ctx, oracle, monkeypatch, length, depth, mode):
+    """The four packed column classes under every form of the row loop (RATTLE_POA_MODE): barrier + record-word ring, skewed
+    wavefront pipeline + ready-made ring, and the teams of wavefronts (4 / 2 / 1 teams: rows that do not depend on each other run
+    at the same time, poa.hip dp_rows_mt) -- all byte-identical to the oracle."""
+    monkeypatch.setenv("RATTLE_POA_MODE", mode)
+    rng = np.random.default_rng(length + 1)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    tx = acgt[rng.integers(0, 4, length)]
+    pack = []
+    for _ in range(depth):
+        r = rng.random(len(tx))
+        s = tx.copy()
+        sub = (r >= 0.03) & (r < 0.07)
+        s[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        s = s[r >= 0.03]
+        pos = np.sort(rng.integers(0, len(s) + 1, int(0.03 * len(s))))
+        s = np.insert(s, pos, acgt[rng.integers(0, 4, len(pos))])
+        pack.append(s[int(rng.integers(0, 30)):].tobytes())
+    pack.sort(key=lambda x: -len(x))
+    rows, width, counters = gpu_ctx.poa_msa([pack, pack[::-1], pack[: depth // 2]])
+    for got, p in zip(rows, (pack, pack[::-1], pack[: depth // 2])):
+        want, _ = oracle.poa_msa(p)
+        assert got == want
+
+
 @pytest.mark.parametrize("env", [{"RATTLE_POA_DEBUG": "1"}, {"RATTLE_POA_DEBUG": "2"}, {"RATTLE_POA_DEBUG": "3"},
-                                 {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_EXP": "0,0,0,0"}, {"RATTLE_POA_EXP": "1,1,1,1"},
-                                 {"RATTLE_POA_EXP": "3,3,2,2"}, {"RATTLE_POA_EXP": "5,5,1,2"}, {"RATTLE_POA_EXP": "1,1,1,1", "RATTLE_POA_DEBUG": "3"},
-                                 {"RATTLE_POA_EXP": "4,4,0,0", "RATTLE_POA_NODE_CAP": "700"}])
+                                 {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_MODE": "sparse"}, {"RATTLE_POA_MODE": "dense"},
+                                 {"RATTLE_POA_MODE": "mt4"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
+                                 {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_DEBUG": "3"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_NODE_CAP": "700"},
+                                 {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "10"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_MT_SLOTS": "6"},
+                                 {"RATTLE_POA_MODE": "mt1", "RATTLE_POA_MT_SLOTS": "3"}])
 def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
     """The slow paths behind the fast ones stay exact: full topological sort for ties (bit 0), traceback without
-    the LDS chain (bit 1), packs re-run with a larger arena after a node-capacity overflow; and the candidate row kernels of
-    round 4 (RATTLE_POA_EXP: the skewed wavefront pipeline with record words or ready-made terms in its ring, on 2 / 4 / 8
-    wavefronts, rings of 4 / 6 / 8 rows)."""
+    the LDS chain (bit 1), packs re-run with a larger arena after a node-capacity overflow; and every form of the row loop
+    (RATTLE_POA_MODE: the barrier form, the skewed wavefront pipeline, teams of wavefronts on 4 / 2 / 1 teams -- the last with
+    rings so short that many predecessors come from the record in HBM)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     packs = _packs_from_synth(400, 10, seed=11)
@@ -115,7 +144,8 @@ def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
         assert rows[p] == want, p
 
 
-@pytest.mark.parametrize("env", [{}, {"RATTLE_POA_MODE": "dense"}, {"RATTLE_POA_EXP": "0,0,0,0"}, {"RATTLE_POA_EXP": "1,5,1,1"}])
+@pytest.mark.parametrize("env", [{}, {"RATTLE_POA_MODE": "dense"}, {"RATTLE_POA_MODE": "sparse"}, {"RATTLE_POA_MODE": "mt4"},
+                                 {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"}, {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "9"}])
 def test_predecessors_hundreds_of_rows_back_and_many_in_edges(gpu_ctx, oracle, monkeypatch, env):
     """The row loop reads a COMPACT plan record: the distances to a row's first eight predecessor rows in a byte each, saturated
     at 255, the in-degree capped at 255 (poa.hip, round 4).  Reads that skip 300-600 bases of the others (an exon left out) give
