@@ -42,26 +42,7 @@ __attribute__((constructor)) static void settle_hw_queues() {
 }
 int hw_queues() { return g_hw_queues; }
 
-static std::mutex g_park_mu;
-static int g_park_depth = 0;
-static std::vector<void *> g_parked;
-void dev_free(void *p) {
-    if (!p) return;
-    {
-        std::lock_guard<std::mutex> lk(g_park_mu);
-        if (g_park_depth > 0) { g_parked.push_back(p); return; }
-    }
-    (void)hipFree(p);
-}
-void park_frees(bool on) {
-    std::vector<void *> now;
-    {
-        std::lock_guard<std::mutex> lk(g_park_mu);
-        if (on) { ++g_park_depth; return; }
-        if (g_park_depth > 0 && --g_park_depth == 0) now.swap(g_parked);
-    }
-    for (void *p : now) (void)hipFree(p);
-}
+void dev_free(void *p) { if (p) (void)hipFree(p); }
 
 }  // namespace rattle
 

@@ -68,11 +68,7 @@ void parallel_for(size_t n, int n_threads, F f) {
 
 // Growable device buffer (never shrinks; contents are not preserved across grow()).  Owns its
 // allocation and frees it on destruction, so early error returns do not leak HBM; borrow() makes a
-// hipFree waits for the whole device.  While two flows share the device (correct_driver.hip: the big clusters' chain beside
-// stage 1) a buffer release must not make one flow wait for the other's kernels: between park_frees(true) and
-// park_frees(false) releases are only noted, and carried out by the latter (abi.hip).
 void dev_free(void *p);
-void park_frees(bool on);
 
 // non-owning view of another buffer (the child contexts of cluster_subsets share the parent's index).
 template <typename T>
@@ -177,7 +173,6 @@ struct exchange {
     void *user = nullptr;
     void *comm = nullptr;               // ncclComm_t
     void *rccl = nullptr;               // dlopen handle of librccl.so
-    hipStream_t side_stream = nullptr;  // set while the side flow of `correct` owns the exchange: its collectives must not queue behind the main stream's kernels
     uint64_t calls = 0, bytes = 0;      // statistics
     // staging of the RCCL all-gather-v, kept between calls: the sharded cluster driver exchanges a few KB per greedy round
     // (119 rounds at 1e6 reads) and three hipMalloc / hipFree pairs per exchange were three device-wide synchronisations each
@@ -291,12 +286,6 @@ struct rattle_ctx {
     hipStream_t poa_st[16] = {};     // one per column class: classes run concurrently
     hipEvent_t poa_ev[16] = {};
     hipEvent_t poa_go = nullptr;
-    // two correction flows on one device (correct_driver.hip): the helper context of the side flow (own streams and arena),
-    // a flag kernel C's host side raises once the kernels of its first pass are launched, and a request to leave a few
-    // workgroup places of the device free (the side flow's POA #3 groups arrive while this flow's persistent workgroups run)
-    rattle_ctx *helper = nullptr;
-    std::atomic<int> *poa_launched = nullptr;
-    int poa_reserve = 0;
     rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns
     // reads staged in HBM by rattle_hip_stage_reads (keys: the host buffers they were copied from)
     const uint8_t *staged_seq_key = nullptr, *staged_qual_key = nullptr;
@@ -318,7 +307,6 @@ struct rattle_ctx {
         if (device < 0) return;                 // host-only context: nothing on a device
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        if (helper) { delete helper; helper = nullptr; }
         if (poa_arena) (void)hipFree(poa_arena);
         for (int i = 0; i < 16; ++i) { if (poa_st[i]) (void)hipStreamDestroy(poa_st[i]); if (poa_ev[i]) (void)hipEventDestroy(poa_ev[i]); }
         if (poa_go) (void)hipEventDestroy(poa_go);

@@ -338,31 +338,21 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         for (uint32_t c = 0; c < n_clusters; ++c) if (PL.cl_np[c] >= BIG) big_packs += PL.cl_np[c];
         if (big_packs >= big_min) for (uint32_t c = 0; c < n_clusters; ++c) { big[c] = PL.cl_np[c] >= BIG; any_big |= big[c] != 0; }
     }
-    // Round 4, measured and NOT the default: the chain of the big clusters -- POA #1 of their packs, POA #2 of their packs (2a),
-    // POA #3 (3a: hundreds of pack consensi aligned one after the other by ONE workgroup) -- is 1.3 s of mostly idle device at 1e6
-    // reads when the stages follow each other.  With RATTLE_CORRECT_OVERLAP=1 stage 1 runs in two groups: group 0 = the packs of the
-    // big clusters, first and alone; then their 2a -> 3a chain runs on a helper context (own streams, own arena, a second host
-    // thread) BESIDE the POA #1 of group 1 (everything else).  2a is launched before group 1's POA #1 so that its many short
-    // workgroups take the device first; group 1's persistent workgroups leave a few places free (poa_reserve) for the handful of
-    // workgroups 3a needs later.  Several ranks: the collectives keep their order (after 2a, after 3a + 2b, after 3b); the first
-    // is issued by the side flow on its own stream (exchange::side_stream).  Results are byte-identical (tests compare) -- but
-    // the step got SLOWER, 5.64 -> 5.99 s (profiles/README.md, round 4): two stage-1 passes have two tails (a pass lasts as long
-    // as a pack that starts in its last wave of places: 1.83 + 2.89 s against 3.83 s for one pass), which costs more than the
-    // hidden chain saves.  What would pay is the pack's POA #2 on the workgroup that just finished its POA #1 (kernel D inside
-    // kernel C): no second pass, no hand-over of places.
-    const bool overlap = any_big && getenv("RATTLE_CORRECT_OVERLAP") && atoi(getenv("RATTLE_CORRECT_OVERLAP")) != 0;
+    // (Round 4 also ran the big clusters' chain as a second flow on a helper context beside the POA #1 of everything else: byte-
+    // identical, but slower -- two stage-1 passes have two tails -- and removed in round 5.  What shortens the chain instead is the
+    // row loop of a lone workgroup: poa.hip, dp_rows_mt.)
     struct s1group {
         stage S;
         std::vector<sref> r;                         // the group's pack members, pack after pack
         std::vector<uint32_t> ks;                    // index in `mine` of each of its packs
         std::vector<uint32_t> olen, tfront, tback;   // per member
-    } G[2];
-    std::vector<uint8_t> g_of(nm, 1);
+    } G[1];
+    std::vector<uint8_t> g_of(nm, 0);
     std::vector<uint32_t> k_in(nm, 0);
-    for (int g = 0; g < 2; ++g) G[g].S.first.assign(1, 0);
+    G[0].S.first.assign(1, 0);
     for (uint32_t k = 0; k < nm; ++k) {
         const uint32_t p = mine[k];
-        const int g = overlap && big[PL.pk_cid[p]] ? 0 : 1;
+        const int g = 0;
         g_of[k] = (uint8_t)g; k_in[k] = (uint32_t)G[g].ks.size();
         G[g].ks.push_back(k);
         for (uint32_t q = PL.first[p]; q < PL.first[p + 1]; ++q) G[g].r.push_back(PL.members[q]);
@@ -388,7 +378,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         ok['A'] = ok['C'] = ok['G'] = ok['T'] = ok['U'] = true;
         std::atomic<int> bad(0);
         const size_t chunk = 4096;
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < 1; ++g) {
             const std::vector<sref> &R1 = G[g].r;
             const size_t n1g = R1.size();
             parallel_for((n1g + chunk - 1) / chunk, P->n_threads, [&](size_t c) {
@@ -464,7 +454,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             desc[q] = gather_desc{off[X.r[q].rid], X.S.off[q], len, X.r[q].rev};
             X.S.off[q + 1] = X.S.off[q] + len;
         }
-        phase_timer T(g == 0 ? "correct: stage 1 (big clusters)" : "correct: stage 1");
+        phase_timer T("correct: stage 1");
         RT_TRY(run_stage(ctx, X.S, desc, {gather_part{0, n1, dev_seq, dev_qual}}, 1, P, order, cnt));
         RT_HIP(hipMemcpyAsync(X.olen.data(), X.S.olen.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
         RT_HIP(hipMemcpyAsync(X.tfront.data(), X.S.tfront.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
@@ -490,7 +480,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         }
         {
             phase_timer T("correct: corrected reads D2H");
-            std::vector<gather_desc> od[2];
+            std::vector<gather_desc> od[1];
             std::vector<int32_t> o_rid, o_cid;
             uint64_t tot = 0;
             for (uint32_t k = 0; k < nm; ++k) {
@@ -513,18 +503,12 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             C.seq = (char *)malloc(tot + 1); C.qual = (char *)malloc(tot + 1);
             C.seq[tot] = 0; C.qual[tot] = 0;
             {
-                // offsets in output order: the two groups' descriptors interleave by pack, so walk them by destination
-                size_t ia = 0, ib = 0;
-                for (size_t i = 0; i < nc; ++i) {
-                    const bool from_a = ia < od[0].size() && (ib >= od[1].size() || od[0][ia].dst < od[1][ib].dst);
-                    C.off[i] = from_a ? od[0][ia++].dst : od[1][ib++].dst;
-                    C.read_id[i] = o_rid[i]; C.cluster_id[i] = o_cid[i]; C.n_reads[i] = 0;
-                }
+                for (size_t i = 0; i < nc; ++i) { C.off[i] = od[0][i].dst; C.read_id[i] = o_rid[i]; C.cluster_id[i] = o_cid[i]; C.n_reads[i] = 0; }
             }
             C.off[nc] = tot;
             if (nc) {
                 RT_TRY(d_os.reserve(tot + 64)); RT_TRY(d_oq.reserve(tot + 64));
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < 1; ++g) {
                     if (od[g].empty()) continue;
                     dbuf<gather_desc> d_od;
                     RT_TRY(d_od.reserve(od[g].size()));
@@ -675,115 +659,26 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         for (size_t i = 0; i < g3a_all.size(); ++i) if ((int)own[i] == rank) g3a.push_back(g3a_all[i]);
     };
 
-    uint64_t cnt_main[8] = {0}, cnt_side[8] = {0};
+    uint64_t cnt_main[8] = {0};
     std::vector<skip_t> sk_2a, sk_3a, sk_2b, sk_3b;
-    std::vector<uint8_t> bytes_2a, bytes_3a, bytes_2b, bytes_3b;
+    std::vector<uint8_t> bytes_3b;
     if (nm) LOCAL_TRY(upload_reads());
-    if (overlap) {
-        // ---- group 0 alone, then its chain on the helper context beside group 1
-        if (nm) LOCAL_TRY(stage1_group(0, cnt_main));
-        std::vector<uint32_t> s2a;
-        for (uint32_t k : G[0].ks) if (!pk_dead[mine[k]]) s2a.push_back(k);
-        // packs of group 0 given up in stage 1 are announced with the first exchange
-        for (uint32_t k : G[0].ks) if (pk_dead[mine[k]] == 1) put_rec(bytes_2a, mine[k], 1u << 1, nullptr, 0);
-        // The side flow runs on every rank that takes this path (the choice depends on the arguments alone), whatever it has to
-        // do here: with several ranks its first step that matters is the all-gather after 2a, which every rank must join -- with
-        // its consensi, with nothing, or with a failure record (a failure so far, or no helper context).
-        int side_rc = local_rc;
-        std::string side_msg = local_msg;
-        if (side_rc == 0 && !ctx->helper) {          // (also without packs for 2a: the POA #3 groups are dealt over the ranks afresh)
-            const int r = rattle_hip_ctx_create(ctx->device, &ctx->helper);
-            if (r != 0) { if (nranks == 1) return r; local_step(r); side_rc = local_rc; side_msg = local_msg; }
-        }
-        rattle_ctx *hx = ctx->helper;
-        std::thread side;
-        std::atomic<int> side_launched(0);
-        const bool side_poa = side_rc == 0 && !s2a.empty() && hx;
-        if (side_poa) { hx->timing = ctx->timing; hx->poa_launched = &side_launched; }
-        park_frees(true);                            // hipFree waits for the whole device: no release of either flow may wait for the other's kernels
-        ctx->xchg.side_stream = hx ? hx->stream : nullptr;
-        side = std::thread([&, hx, side_poa]() {
-            auto fail = [&](int r) { if (!side_rc) { side_rc = r; side_msg = rattle_hip_last_error(); } side_launched = 1; };
-            int r = 0;
-            if (hx && hipSetDevice(hx->device) != hipSuccess) { set_error("helper flow: hipSetDevice failed"); r = RATTLE_ERR_HIP; }
-            if (r == 0 && side_poa) r = ensure_post_constants(hx);
-            if (r == 0 && side_poa) r = cons_pass(hx, "correct: stage 2a (beside stage 1)", s2a, {}, bytes_2a, sk_2a, cnt_side);
-            side_launched = 1;                       // (also when 2a had nothing to launch)
-            if (r) fail(r);
-            r = exchange_stage(bytes_2a, side_rc, side_msg);
-            if (r) { fail(r); return; }
-            std::vector<uint32_t> g3a;
-            big_groups(g3a);
-            if (!g3a.empty() && !hx) { set_error("helper flow: no helper context"); fail(RATTLE_ERR_STATE); return; }
-            if (!g3a.empty()) {
-                r = ensure_post_constants(hx);
-                if (r == 0) r = cons_pass(hx, "correct: stage 3a (beside stage 1)", {}, g3a, bytes_3a, sk_3a, cnt_side);
-            }
-            if (r) fail(r);
-        });
-        // joins the side flow and un-parks the frees on EVERY way out of this block
-        struct side_joiner { std::thread &t; exchange &x; ~side_joiner() { if (t.joinable()) t.join(); x.side_stream = nullptr; park_frees(false); } };
-        {
-            side_joiner sj{side, ctx->xchg};
-            // group 1's persistent workgroups would take every place of the device: 2a's launches go first
-            while (!side_launched) std::this_thread::yield();
-            if (hx) hx->poa_launched = nullptr;
-            ctx->poa_reserve = 1;                    // leave a few places for 3a's workgroups
-            int r1 = 0;
-            if (nm && local_rc == 0) r1 = stage1_group(1, cnt_main);
-            ctx->poa_reserve = 0;
-            if (ctx->timing) (void)hipEventRecord(ctx->ev0, st);      // group 1 is done (its stream is idle): the side flow's time beyond this point is not hidden
-            side.join();
-            if (r1 != 0) { if (nranks == 1) return r1; local_step(r1); }
-        }
-        if (hx) {
-            // kernel statistics of the call.  The side flow's kernels ran BESIDE group 1's POA #1: adding their durations to this
-            // context's would count that stretch of device time twice (and the cells-per-second figure derived from it would sink
-            // although the call got shorter).  Kernel C's time is therefore the main flow's plus what the side flow needed AFTER
-            // group 1 had finished (events on the two streams); launches, bytes and kernel D's (short) times add up.
-            float beyond = 0;
-            if (ctx->timing && hx->stats[K_POA].launches && hipEventRecord(hx->ev1, hx->stream) == hipSuccess && hipEventSynchronize(hx->ev1) == hipSuccess &&
-                hipEventElapsedTime(&beyond, ctx->ev0, hx->ev1) == hipSuccess && beyond > 0)
-                ctx->stats[K_POA].ms += beyond;
-            for (int i = 0; i < K_COUNT; ++i) {
-                if (i != K_POA) ctx->stats[i].ms += hx->stats[i].ms;
-                ctx->stats[i].launches += hx->stats[i].launches; ctx->stats[i].bytes += hx->stats[i].bytes;
-                hx->stats[i] = kstat();
-            }
-        }
-        if (side_rc && !local_rc) {                  // the side flow failed (here, or on another rank: the exchange said so)
-            set_error(side_msg);
-            if (nranks == 1) return side_rc;
-            local_rc = side_rc; local_msg = side_msg;
-        }
-        if (nm && local_rc == 0) LOCAL_TRY(stage1_finish());
-        d_rseq.release(); d_rqual.release();
-        std::vector<uint32_t> s2b;
-        for (uint32_t k : G[1].ks) if (!pk_dead[mine[k]]) s2b.push_back(k);
-        LOCAL_TRY(cons_pass(ctx, "correct: stage 2b", s2b, {}, bytes_2b, sk_2b, cnt_main));
-        std::vector<uint8_t> bytes;
-        for (uint32_t k : G[1].ks) if (pk_dead[mine[k]] == 1) put_rec(bytes, mine[k], 1u << 1, nullptr, 0);      // group 1's packs given up in stage 1
-        bytes.insert(bytes.end(), bytes_3a.begin(), bytes_3a.end());
-        bytes.insert(bytes.end(), bytes_2b.begin(), bytes_2b.end());
-        RT_TRY(exchange_stage(bytes, local_rc, local_msg));
-    } else {
-        if (nm) LOCAL_TRY(stage1_group(1, cnt_main));
-        if (nm && local_rc == 0) LOCAL_TRY(stage1_finish());
-        d_rseq.release(); d_rqual.release();
-        std::vector<uint8_t> bytes;
-        // packs given up in stage 1 are announced with the first exchange
-        for (uint32_t k = 0; k < nm; ++k) if (pk_dead[mine[k]] == 1) put_rec(bytes, mine[k], 1u << 1, nullptr, 0);
-        // stage 2a: my packs of the big clusters
-        std::vector<uint32_t> s2a, s2b;
-        for (uint32_t k = 0; k < nm; ++k) if (!pk_dead[mine[k]]) (big[PL.pk_cid[mine[k]]] ? s2a : s2b).push_back(k);
-        LOCAL_TRY(cons_pass(ctx, "correct: stage 2a", s2a, {}, bytes, sk_2a, cnt_main));
-        if (any_big) { RT_TRY(exchange_stage(bytes, local_rc, local_msg)); bytes.clear(); }
-        // stage 2b+3a: POA #3 groups of the big clusters (LPT over ranks), then my packs of all other clusters
-        std::vector<uint32_t> g3a;
-        big_groups(g3a);
-        LOCAL_TRY(cons_pass(ctx, "correct: stage 2b+3a", s2b, g3a, bytes, sk_3a, cnt_main));
-        RT_TRY(exchange_stage(bytes, local_rc, local_msg));
-    }
+    if (nm) LOCAL_TRY(stage1_group(0, cnt_main));
+    if (nm && local_rc == 0) LOCAL_TRY(stage1_finish());
+    d_rseq.release(); d_rqual.release();
+    std::vector<uint8_t> bytes;
+    // packs given up in stage 1 are announced with the first exchange
+    for (uint32_t k = 0; k < nm; ++k) if (pk_dead[mine[k]] == 1) put_rec(bytes, mine[k], 1u << 1, nullptr, 0);
+    // stage 2a: my packs of the big clusters
+    std::vector<uint32_t> s2a, s2b;
+    for (uint32_t k = 0; k < nm; ++k) if (!pk_dead[mine[k]]) (big[PL.pk_cid[mine[k]]] ? s2a : s2b).push_back(k);
+    LOCAL_TRY(cons_pass(ctx, "correct: stage 2a", s2a, {}, bytes, sk_2a, cnt_main));
+    if (any_big) { RT_TRY(exchange_stage(bytes, local_rc, local_msg)); bytes.clear(); }
+    // stage 2b+3a: POA #3 groups of the big clusters (LPT over ranks), then my packs of all other clusters
+    std::vector<uint32_t> g3a;
+    big_groups(g3a);
+    LOCAL_TRY(cons_pass(ctx, "correct: stage 2b+3a", s2b, g3a, bytes, sk_3a, cnt_main));
+    RT_TRY(exchange_stage(bytes, local_rc, local_msg));
     if (!nm || local_rc) {
         if (d2h.joinable()) d2h.join();
         if (R->corrected.off) { rattle_read_set &C = R->corrected; free(C.read_id); free(C.cluster_id); free(C.n_reads); free(C.off); free(C.seq); free(C.qual); C = rattle_read_set(); }
@@ -797,7 +692,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             if (nranks == 1) return RATTLE_ERR_HIP;
             local_step(RATTLE_ERR_HIP);
         }
-        G[0].S.release(); G[1].S.release();
+        G[0].S.release();
         // stage 3b: POA #3 of the other clusters with more than one live pack
         std::vector<uint32_t> g3b_all, g3b, own, g;
         std::vector<uint64_t> cost;
@@ -816,8 +711,8 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     }
     // skipped packs of the consensus stages in the order the sequential flow meets them: 2a, then 3a before 2b (one pass), then 3b
     for (std::vector<skip_t> *v : {&sk_2a, &sk_3a, &sk_2b, &sk_3b}) for (skip_t &x : *v) skips.push_back(std::move(x));
-    counters[0] += cnt_main[0] + cnt_side[0];
-    counters[1] += cnt_main[1] + cnt_side[1];
+    counters[0] += cnt_main[0];
+    counters[1] += cnt_main[1];
     if (d2h.joinable()) d2h.join();
     d_os.release(); d_oq.release();
 #undef LOCAL_TRY

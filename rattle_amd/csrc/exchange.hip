@@ -83,7 +83,7 @@ int rccl_allgatherv(rattle_ctx *ctx, const uint8_t *d_send, uint8_t *d_recv, con
     uint64_t at = 0;
     int bad = 0;                                  // an error inside the group must not leave it open
     for (int r = 0; r < X.nranks && !bad; ++r) {
-        if (bytes[r]) bad = A.Broadcast(r == X.rank ? d_send : d_recv + at, d_recv + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, X.side_stream ? X.side_stream : ctx->stream);
+        if (bytes[r]) bad = A.Broadcast(r == X.rank ? d_send : d_recv + at, d_recv + at, bytes[r], NCCL_UINT8, r, (nccl_comm)X.comm, ctx->stream);
         at += bytes[r];
     }
     const int end = A.GroupEnd();
@@ -102,7 +102,7 @@ int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vect
     std::vector<uint64_t> bytes((size_t)X.nranks, 0);
     const uint64_t my_bytes = mine.size();
     if (X.comm) {
-        hipStream_t st = X.side_stream ? X.side_stream : ctx->stream;
+        hipStream_t st = ctx->stream;
         RT_TRY(X.d_sz.reserve((size_t)X.nranks + 1)); RT_TRY(X.h_sz.reserve((size_t)X.nranks + 1));
         X.h_sz.p[X.nranks] = my_bytes;
         RT_HIP(hipMemcpyAsync(X.d_sz.p + X.nranks, X.h_sz.p + X.nranks, 8, hipMemcpyHostToDevice, st));

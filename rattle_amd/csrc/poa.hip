@@ -89,9 +89,9 @@ struct poa_args {
     uint32_t node_cap, edge_cap;
     uint64_t cell_cap;             // elements per matrix
     uint32_t aln_cap, spill_cap, seq_cap;
-    uint64_t o_planm;              // multi-team rows (dp_rows_mt): the row loop's own 64-byte record per row
-    uint32_t ring_slots, ring_reach, ring_slack;      // ... and its ring, sized at launch: slots in LDS (+ one all-zero slot), rows a reader looks back, rows that may be in flight
-    uint32_t debug;                // tests: bit 0 = resolve ties with the full sort, bit 1 = traceback without the LDS fast path
+    uint64_t o_planm;              // multi-team rows (dp_rows_mt): the row loop's own 32-byte record per row
+    uint32_t ring_slots, ring_reach, ring_slack;      // ... and its ring, sized at launch: slots in LDS, rows a reader looks back, rows that may be in flight
+    uint32_t debug;                // tests: bit 0 = resolve ties with the full sort, bit 1 = traceback without the LDS fast path, bit 2 = ... without its jump tables
     uint32_t *out_col;             // per base: node id during the run, MSA column at the end
     uint32_t *out_width;           // per pack
     uint32_t *status;              // per pack: 0 ok, else error code
@@ -110,7 +110,7 @@ enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_
 
 struct poa_ws {                    // per-block workspace: global pointers + LDS + wave-uniform state
     uint4 *nrec, *nal, *plan, *planb, *planc, *pland;
-    uint32_t *planm;                       // dp_rows_mt: 16 dwords per row
+    uint32_t *planm;                       // dp_rows_mt: 8 dwords per row
     uint2 *edges;
     int32_t *rank;                         // node -> DP row - 1 (block order), MSA column in the final pass
     uint32_t *order, *order2;              // DP row - 1 -> node (double buffer for the incremental merge)
@@ -1398,11 +1398,11 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 //         entries per wavefront, back-pressure on the right neighbour's done counter, as in dp_rows_sk).
 //     All waits are for smaller rows, or the same row in a smaller block: no cycles (simulated on host threads,
 //     tests/stubs/mt_protocol_sim.cpp).
-// (2) The row is on a scalar diet.  The plan record of a row is 64 bytes (one scalar-cache line, one s_load_dwordx16, fetched a row
+// (2) The row is on a scalar diet.  The plan record of a row is 32 bytes (one s_load_dwordx8, fetched a row
 //     ahead behind the row's first LDS wait) and holds everything READY-MADE: the two halves of the score table, the LDS byte
 //     offset of the row's own ring slot and of the ring slots of its first eight predecessors, the row number to wait for.
-//     Missing predecessors (and the ones beyond the ring) point at an all-zero slot (A = 0, B = g - e: the neutral element of
-//     both maxima, and what the virtual start row holds), so the common path -- up to four in-edges, all in the ring: 88 % of the
+//     Missing predecessors (and the ones beyond the ring) point once more at the entry of a predecessor that IS in the ring (a
+//     maximum does not mind seeing a term twice), so the common path -- up to four in-edges, all in the ring: 88 % of the
 //     rows -- has no branch at all and no per-predecessor scalar work; a second group of four takes one uniform branch; in-edges
 //     beyond the ring or beyond the eighth take the slow path.  One-lane LDS writes (counters, mailbox) are 64-lane writes whose
 //     other lanes hit a junk word: no exec-mask games.  The ring (ready-made terms, 4 bytes per cell) is sized at launch from
@@ -1411,11 +1411,13 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 #define MT_MD 4                                   // mailbox entries per wavefront (rows of its team it may run ahead of its right neighbour)
 #endif
 #define MT_BIG 0x7FFFFF00
+#define MT_UNIT 11                                // ring offsets travel in units of 2 KB (a byte each in the plan record)
 #define MT_MORE4 1u                               // plan flags: in-edges 5 .. 8 are in use
-#define MT_SLOW 2u                                // ... some in-edge lies beyond the ring, or there are more than eight
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define MT_SLOW 2u                                // ... some in-edge lies beyond the ring, or there are more than eight, or none is in the ring
+#define MT_NOBASE 4u                              // no in-edge in the ring (virtual start row, or all beyond it): the maxima start from the neutral element
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(4))) u32x16 *cplanm_t;
+typedef const __attribute__((address_space(4))) u32x8 *cplanm_t;
 typedef __attribute__((address_space(3))) uint32_t *lds_p;
 template <int NW, int T> struct alignas(16) mt_sync {
     int32_t done[NW][4];                          // [w][t]: last row team t has finished in column block w (teams that do not exist: MT_BIG)
@@ -1424,6 +1426,15 @@ template <int NW, int T> struct alignas(16) mt_sync {
     uint32_t junk[64 * 2 + 8];                    // where the other 63 lanes of a one-lane write go
     uint32_t abort;                               // a wavefront gave up waiting (MT_SPIN_LIMIT polls): everybody leaves, the pack fails with POA_ERR_SYNC
 };
+#ifndef MT_POLL_FULL
+#define MT_POLL_FULL 0                            // up to this many teams a waiting row re-reads its ring entries with every poll of the counters (beyond: the counters alone, the entries once after them)
+#endif
+#ifndef MT_POLL_SLEEP
+#define MT_POLL_SLEEP 1
+#endif
+#ifndef MT2_MINWAVES
+#define MT2_MINWAVES 6                            // two teams, 1024-column class: 80 registers, three packs per CU (measured: 680 against 492 GCUPS at 768 packs); the wider classes need their 128
+#endif
 #ifndef MT_SPIN_LIMIT
 #define MT_SPIN_LIMIT (1u << 20)                  // polls of one wait (>= 0.1 s): every spin is bounded -- a protocol error must cost a failed call, not a hung device
 #endif
@@ -1433,6 +1444,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
     constexpr int NTC = 64 * NW, NP = CPL / 2, RW = 2 * NP;
     constexpr uint32_t SLOTB = (uint32_t)NTC * RW * 4u;                 // bytes of one ring slot
     static_assert(NTC * CPL <= 2560 && CPL % 2 == 0 && T <= 4, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
+    static_assert(SLOTB % (1u << MT_UNIT) == 0 && 24u * (SLOTB >> MT_UNIT) <= 255u, "a ring slot offset fits a byte of 2 KB units");
     __shared__ mt_sync<NW, T> Y;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wv % NW, t = wv / NW;                                  // column block, team
@@ -1476,7 +1488,6 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
     const sk_ptr p_rdone = (sk_ptr)&Y.done[has_right ? w + 1 : w][t];
     const sk_ptr p_lcnt = (sk_ptr)&Y.mcnt[has_left ? w - 1 : 0][t], p_lmail = (sk_ptr)&Y.mail[has_left ? w - 1 : 0][t][0][0];
     uint32_t *const Hrec = (uint32_t *)S.H;                            // the record, a dword per column pair
-    const uint32_t zoff = A.ring_slots * SLOTB;                        // the all-zero slot
     const uint32_t reach = A.ring_reach, slots = A.ring_slots;
 
     if (tid < NW * 4) { ((int32_t *)Y.done)[tid] = (tid & 3) < T ? (tid & 3) + 1 - T : MT_BIG; ((uint32_t *)Y.mcnt)[tid] = 0; }
@@ -1492,18 +1503,13 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
         }
         dead = 1u;
     };
-    if (t == 0) {                                // the zero slot: A = H[p][j-1] = 0, B = max(H + g - e, F) = g - e
-        lds_p z = (lds_p)(uintptr_t)(rb + zoff);
-#pragma unroll
-        for (int u = 0; u < NP; ++u) { z[u] = 0u; z[NP + u] = as_u(pk_splat(POA_G - POA_E)); }
-    }
     // the plan through the scalar cache (see dp_rows_v3)
     uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc, ppm = (uint64_t)S.planm;
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc), "+s"(ppm) : : "memory");
     const cplan_t cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
     (void)ppa;
     const cplanm_t cpm = (cplanm_t)ppm;
-    __syncthreads();                             // counters and the zero slot are in place before anybody looks at them
+    __syncthreads();                             // the counters are in place before anybody looks at them
 
     // ---- LDS reads of a row, issued back to back by hand and waited for ONCE ----
     // A row used to pay four or five LDS round trips one after the other (counters, ring entries, mailbox, back-pressure: ~150
@@ -1573,10 +1579,16 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
     const uint32_t va_lcnt = (uint32_t)(uintptr_t)(lds_p)&Y.mcnt[has_left ? w - 1 : 0][t], va_lmail = (uint32_t)(uintptr_t)(lds_p)&Y.mail[has_left ? w - 1 : 0][t][0][0];
 
     // one row.  pd: its plan record; nx: where the record of this team's next row is fetched to
-    auto step = [&](const uint32_t row, const u32x16 pd, u32x16 &nx) __attribute__((always_inline)) {
-        const uint32_t klo = pd[0], khi = pd[1], self_off = pd[2], ctl = pd[12];
-        const int32_t need = (int32_t)pd[3];
-        // ---- one burst: counters, the left mailbox, the four ring entries (missing predecessors are the zero slot) ----
+    // The record of a row: 32 bytes, one s_load_dwordx8 (two sets of them live across the loop: with 64-byte records the kernel ran out
+    // of scalar registers and, in some builds, reloaded spilled ones -- v_readlane -- 300 times per trip of the loop; a two-team pack then
+    // ran no faster than a one-team pack).  x klo, y khi (score table halves), z the row that must be final, w = own slot | flags << 8 |
+    // far in-edges << 16 | letter << 24, [4] / [5] the slots of in-edges 1-4 / 5-8 in a byte each, [6] in-degree, [7] edge index of
+    // the ninth in-edge.  A slot is given in units of 2 KB (MT_UNIT): slot bytes are 4, 6, 8 or 10 KB.
+    auto step = [&](const uint32_t row, const u32x8 pd, u32x8 &nx) __attribute__((always_inline)) {
+        const uint32_t klo = pd[0], khi = pd[1], self_off = (pd[3] & 0xFFu) << MT_UNIT, ctl = pd[3] >> 8;
+        const int32_t need = (int32_t)pd[2];
+        const uint32_t o0 = (pd[4] & 0xFFu) << MT_UNIT, o1 = ((pd[4] >> 8) & 0xFFu) << MT_UNIT, o2 = ((pd[4] >> 16) & 0xFFu) << MT_UNIT, o3 = (pd[4] >> 24) << MT_UNIT;
+        // ---- one burst: counters, the left mailbox, the four ring entries (missing predecessors repeat one that is there) ----
         u32x4 dn;
         uint32_t rdv, lcv;
         u32x2 lmv;
@@ -1586,7 +1598,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b64 %3, %7"
                          : "=&v"(dn), "=&v"(rdv), "=&v"(lcv), "=&v"(lmv) : "v"(va_done), "v"(va_rdone), "v"(va_lcnt), "v"(va_lm) : "memory");
         }
-        issue_slot(pd[4], e0); issue_slot(pd[5], e1); issue_slot(pd[6], e2); issue_slot(pd[7], e3);
+        issue_slot(o0, e0); issue_slot(o1, e1); issue_slot(o2, e2); issue_slot(o3, e3);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn), "+v"(rdv), "+v"(lcv), "+v"(lmv) : : "memory");
         land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
         if constexpr (T > 1) {
@@ -1598,13 +1610,20 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
                 uint32_t spins = 0;
                 do {
                     if (++spins > MT_SPIN_LIMIT || sk_ld(p_abort)) { give_up(1, row, (uint32_t)m, (uint32_t)need); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"(va_done) : "memory");
+                    if (MT_POLL_SLEEP) __builtin_amdgcn_s_sleep(1);
+                    if (MT_POLL_FULL && T <= MT_POLL_FULL) {
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(dn) : "v"(va_done) : "memory");
+                        issue_slot(o0, e0); issue_slot(o1, e1); issue_slot(o2, e2); issue_slot(o3, e3);
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dn) : : "memory");
+                        land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
+                    } else asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dn) : "v"(va_done) : "memory");
                     m = __builtin_amdgcn_readfirstlane(min(min((int32_t)dn.x, (int32_t)dn.y), min((int32_t)dn.z, (int32_t)dn.w)));
                 } while (m + T <= need);
-                issue_slot(pd[4], e0); issue_slot(pd[5], e1); issue_slot(pd[6], e2); issue_slot(pd[7], e3);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
+                if (!(MT_POLL_FULL && T <= MT_POLL_FULL)) {
+                    issue_slot(o0, e0); issue_slot(o1, e1); issue_slot(o2, e2); issue_slot(o3, e3);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
+                }
             }
         }
         s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
@@ -1615,7 +1634,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
         }
         uint32_t r0[RW];
         if (ctl & MT_MORE4) {
-            issue_slot(pd[8], e0); issue_slot(pd[9], e1); issue_slot(pd[10], e2); issue_slot(pd[11], e3);
+            issue_slot((pd[5] & 0xFFu) << MT_UNIT, e0); issue_slot(((pd[5] >> 8) & 0xFFu) << MT_UNIT, e1); issue_slot(((pd[5] >> 16) & 0xFFu) << MT_UNIT, e2); issue_slot((pd[5] >> 24) << MT_UNIT, e3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             land_slot(e0); land_slot(e1); land_slot(e2); land_slot(e3);
 #pragma unroll
@@ -1634,7 +1653,11 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
         }
         if (ctl & MT_SLOW) {
             // in-edges beyond the ring (their record words from HBM, decoded into the ring's terms) and in-edges after the eighth
-            const uint32_t n_all = pd[13], farmask = (ctl >> 8) & 0xFFu;
+            const uint32_t n_all = pd[6], farmask = (ctl >> 8) & 0xFFu;
+            if (ctl & MT_NOBASE) {               // what the four entries held is nobody's predecessor: H[p][j-1] = 0, max(H + g - e, F) = g - e
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
+            }
             auto far_fetch = [&](uint32_t prow) __attribute__((always_inline)) {
                 uint32_t x[NP];
                 const uint32_t cc = act ? c0 : 0u;
@@ -1667,7 +1690,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
                 far_fetch(prow);
             }
             if (n_all > 8) {
-                uint32_t e = pd[14];
+                uint32_t e = pd[7];
                 for (uint32_t k = 8; k < n_all; ++k) {
                     const uint2 ed = S.edges[e]; e = ed.y;
                     const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
@@ -1687,7 +1710,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
 #pragma unroll
             for (int u = 0; u < NP; ++u) SC[u] = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
         } else {
-            const uint32_t letter = ctl >> 24;
+            const uint32_t letter = ctl >> 16;
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
                 const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
@@ -1783,7 +1806,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
 
     if (wave_act) {
         // two rows per trip, two register sets for the plan record (no copies)
-        u32x16 pa = cpm[t], pb = pa;
+        u32x8 pa = cpm[t], pb = pa;
         uint32_t row = (uint32_t)t + 1u;
         while (row <= n && !__builtin_amdgcn_readfirstlane((int)dead)) {
             step(row, pa, pb);
@@ -2429,7 +2452,7 @@ __host__ __device__ constexpr uint32_t poa_region_bytes(uint32_t node_cap, int C
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
 constexpr int poa_min_waves(int CPL, int NW, int PK, int RING_OR_T = 1) {
-    return PK == 7 ? (RING_OR_T == 2 ? 6 : 4) : PK == 5 || PK == 6 ? (((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4 > 8 ? 8 : ((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4)
+    return PK == 7 ? (RING_OR_T == 2 && CPL == 4 ? MT2_MINWAVES : 4) : PK == 5 || PK == 6 ? (((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4 > 8 ? 8 : ((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4)
          : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : 1;
 }
 template <int CPL, int RING, int NW, int PK>
@@ -2464,7 +2487,7 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
         S.lh_ring = (int32_t *)(S.ring + (size_t)(PK == 7 ? 0 : RING) * NT * poa_ring_words(CPL, NW, PK));
     }
     // bytes of the LDS ring (between two DPs: room for the tie labels and the traceback's chain)
-    const uint32_t ring_bytes = PK == 7 ? (A.ring_slots + 1u) * mt_slot_bytes(CPL, NW) : poa_ring_bytes(CPL, RING, NW, PK);
+    const uint32_t ring_bytes = PK == 7 ? A.ring_slots * mt_slot_bytes(CPL, NW) : poa_ring_bytes(CPL, RING, NW, PK);
 
     while (true) {
         __syncthreads();
@@ -2548,21 +2571,28 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                     }
                     if constexpr (PK == 7) {
                         // dp_rows_mt's record, everything ready-made (see there): score table halves, LDS offsets of the row's own ring
-                        // slot and of the slots of its first eight predecessors (the all-zero slot for the missing ones and for the ones
+                        // slot and of the slots of its first eight predecessors (a repeated entry for the missing ones and for the ones
                         // beyond the ring), the row that must be final before this one starts
                         constexpr uint32_t SLOTB = mt_slot_bytes(CPL, NW);
-                        const uint32_t slots = A.ring_slots, reach = A.ring_reach, zoff = slots * SLOTB;
-                        uint32_t po[8], farmask = 0, need_row = 0;
+                        const uint32_t slots = A.ring_slots, reach = A.ring_reach;
+                        uint32_t po[8], farmask = 0, need_row = 0, base = 0xFFFFFFFFu;
 #pragma unroll
                         for (uint32_t k = 0; k < 8; ++k) {
-                            po[k] = zoff;
+                            po[k] = 0xFFFFFFFFu;
                             if (k < n_in) {
                                 const uint32_t prow_k = k < 4 ? u4_get(pr, k) : u4_get(pr2, k - 4);
                                 need_row = max(need_row, prow_k);            // in the ring or not: the row must be final (and its record stored) before this one reads it
-                                if (r + 1 - prow_k <= reach) po[k] = (prow_k % slots) * SLOTB;
+                                if (r + 1 - prow_k <= reach) { po[k] = (prow_k % slots) * SLOTB; if (base == 0xFFFFFFFFu) base = po[k]; }
                                 else farmask |= 1u << k;
                             }
                         }
+                        // missing in-edges (and the ones beyond the ring) read the entry of an in-edge that IS in the ring once more: the
+                        // maximum does not care, and no slot has to be set aside for a neutral entry.  No in-edge in the ring at all: the
+                        // row's own slot (any valid address), and MT_NOBASE tells the loop to start from the neutral element instead
+                        const bool nobase = base == 0xFFFFFFFFu;
+                        if (nobase) base = ((r + 1) % slots) * SLOTB;
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) if (po[k] == 0xFFFFFFFFu) po[k] = base;
                         if (n_in > 8) {                                  // (rare) the rows of the further in-edges count for the wait as well
                             uint32_t e2 = e;
                             for (uint32_t k = 8; k < n_in; ++k) { const uint2 ed = S.edges[e2]; e2 = ed.y; need_row = max(need_row, (uint32_t)S.rank[ed.x] + 1); }
@@ -2570,12 +2600,12 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                         const int32_t need = max((int32_t)need_row, (int32_t)(r + 1) - (int32_t)A.ring_slack);
                         const uint32_t letter = rd_letter(rec.x), li = (letter >> 1) & 3u;
                         const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));      // low / high bytes of {-4, -4, -4, -4} with 5 at li
-                        const uint32_t ctl = (n_in > 4 ? MT_MORE4 : 0u) | ((farmask || n_in > 8) ? MT_SLOW : 0u) | (farmask << 8) | (letter << 24);
-                        uint4 *pm = (uint4 *)(S.planm + 16 * (size_t)r);
-                        pm[0] = make_uint4(klo, khi, ((r + 1) % slots) * SLOTB, (uint32_t)need);
-                        pm[1] = make_uint4(po[0], po[1], po[2], po[3]);
-                        pm[2] = make_uint4(po[4], po[5], po[6], po[7]);
-                        pm[3] = make_uint4(ctl, n_in, e, 0);
+                        const uint32_t ctl = (n_in > 4 ? MT_MORE4 : 0u) | ((farmask || n_in > 8 || nobase) ? MT_SLOW : 0u) | (nobase ? MT_NOBASE : 0u) | (farmask << 8) | (letter << 16);
+                        uint4 *pm = (uint4 *)(S.planm + 8 * (size_t)r);
+                        const uint32_t self_u = (((r + 1) % slots) * SLOTB) >> MT_UNIT;
+                        pm[0] = make_uint4(klo, khi, (uint32_t)need, self_u | (ctl << 8));
+                        pm[1] = make_uint4((po[0] >> MT_UNIT) | (po[1] >> MT_UNIT) << 8 | (po[2] >> MT_UNIT) << 16 | (po[3] >> MT_UNIT) << 24,
+                                           (po[4] >> MT_UNIT) | (po[5] >> MT_UNIT) << 8 | (po[6] >> MT_UNIT) << 16 | (po[7] >> MT_UNIT) << 24, n_in, e);
                     }
                 }
 #ifdef POA_PREDSTAT
@@ -2752,7 +2782,13 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                     uint16_t *tq0 = (uint16_t *)S.done;                   // [n+1] row of the first in-edge (0: none / virtual)
                     const uint32_t tb_bytes = (2u * poa_bit_words(A.node_cap) + POA_STACK) * 4u + ring_bytes;
                     const bool fast_tb = 3u * (n + 2u) <= tb_bytes && n < 0xFFFFu && !(A.debug & 2u);
-                    uint8_t *tlet = (uint8_t *)(tq0 + (n + 2u));          // [n+1] letter of the row's node
+                    // Round 5: jump tables over the chain of first predecessors (4 and 16 steps at once) where the LDS has room for them:
+                    // lane h reaches the row of ITS step in at most 3 + 3 (+ 3) dependent LDS reads instead of h, and with all three
+                    // tables the whole wavefront verifies 64 steps per round trip instead of 16 (the chain walk was sixteen dependent
+                    // LDS reads per batch, by every lane).  levels: 1 = the chain alone (as before), 2 = + 4 steps, 3 = + 16 steps.
+                    const uint32_t tq_levels = !fast_tb || (A.debug & 4u) ? 1u : 7u * (n + 2u) <= tb_bytes ? 3u : 5u * (n + 2u) <= tb_bytes ? 2u : 1u;
+                    uint16_t *tq4 = tq0 + (n + 2u), *tq16 = tq4 + (n + 2u);
+                    uint8_t *tlet = (uint8_t *)(tq0 + tq_levels * (n + 2u));          // [n+1] letter of the row's node
                     if (fast_tb) {
                         for (uint32_t r = 1 + tid; r <= n; r += NT) {
                             const uint32_t info = S.plan[r - 1].x;
@@ -2761,6 +2797,14 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                         }
                         if (tid == 0) { tq0[0] = 0; tlet[0] = 0; }
                         __syncthreads();
+                        if (tq_levels >= 2) {
+                            for (uint32_t r = tid; r <= n; r += NT) tq4[r] = tq0[tq0[tq0[tq0[r]]]];
+                            __syncthreads();
+                        }
+                        if (tq_levels >= 3) {
+                            for (uint32_t r = tid; r <= n; r += NT) tq16[r] = tq4[tq4[tq4[tq4[r]]]];
+                            __syncthreads();
+                        }
                     }
                     if (w0) {
                         const uint32_t lane = (uint32_t)tid;
@@ -2811,13 +2855,27 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                             uint4 fpl = make_uint4(0, 0, 0, 0), fplb = make_uint4(0, 0, 0, 0);
                             int pf_lane = -1;                              // lane holding the plan of row i, or -1
                             if (fast_tb) {
-                                constexpr uint32_t K = 16;
+                                const uint32_t K = tq_levels == 3 ? 64u : 16u;
                                 uint32_t my_i = 0, my_next = 0, cur = i;
+                                if (tq_levels == 1) {
 #pragma unroll
-                                for (uint32_t h = 0; h < K; ++h) {
-                                    const uint32_t nx = tq0[cur];
-                                    if (lane == h) { my_i = cur; my_next = nx; }
-                                    cur = nx;
+                                    for (uint32_t h = 0; h < 16; ++h) {
+                                        const uint32_t nx = tq0[cur];
+                                        if (lane == h) { my_i = cur; my_next = nx; }
+                                        cur = nx;
+                                    }
+                                } else {
+                                    // lane h = 16 a + 4 b + c: a jumps of sixteen, b of four, c single steps
+                                    const uint32_t ja = lane >> 4, jb = (lane >> 2) & 3u, jc = lane & 3u;
+                                    if (tq_levels == 3) {
+#pragma unroll
+                                        for (uint32_t q = 0; q < 3; ++q) if (q < ja) cur = tq16[cur];
+                                    }
+#pragma unroll
+                                    for (uint32_t q = 0; q < 3; ++q) if (q < jb) cur = tq4[cur];
+#pragma unroll
+                                    for (uint32_t q = 0; q < 3; ++q) if (q < jc) cur = tq0[cur];
+                                    my_i = cur; my_next = tq0[cur];
                                 }
                                 const bool in = lane < K && j > lane;       // column of my step: j - lane >= 1
                                 const uint32_t my_j = in ? j - lane : 1u;
@@ -2830,7 +2888,7 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                 const int32_t mc = tlet[my_i] == (PK == 2 ? s[my_j - 1] : S.sq[my_j - 1]) ? POA_M : POA_N;
                                 const bool ok = in && my_i != 0 && hcur != 0 && hcur == c + mc;
                                 const unsigned long long okm = __ballot(ok);
-                                const uint32_t m = (uint32_t)__builtin_ctzll(~okm);         // consecutive verified steps
+                                const uint32_t m = ~okm ? (uint32_t)__builtin_ctzll(~okm) : 64u;         // consecutive verified steps
                                 if (m) {
                                     if (cnt + m > A.aln_cap) { err = POA_ERR_ALN; break; }
                                     if (lane < m) { S.aln[2 * (cnt + lane)] = (int32_t)my_i; S.aln[2 * (cnt + lane) + 1] = (int32_t)(my_j - 1); }
@@ -3169,11 +3227,14 @@ struct poa_variant {
 };
 #define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, PK, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
 #define POA_CLASSES 8
-#define POA_GROUPS 12                          // + the shallow packs of classes 4 .. 7 as groups of their own (poa_device_run)
+#define POA_GROUPS 16                          // + the shallow packs of classes 4 .. 7 and the LONG-CHAIN packs of classes 0 .. 3 as groups of their own (poa_device_run)
+#ifndef POA_CHAIN_SEQS
+#define POA_CHAIN_SEQS 256                      // a pack of more sequences than any read pack has (split: 200) is a POA #3 group: hundreds of alignments one after the other
+#endif
 #ifndef POA_SHALLOW_READS
 #define POA_SHALLOW_READS 40
 #endif
-static inline int poa_group_class(int g) { return g < POA_CLASSES ? g : g - 4; }
+static inline int poa_group_class(int g) { return g < POA_CLASSES ? g : g < 12 ? g - 4 : g - 12; }
 static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144, 8192};
 static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1),
                                                    POA_VARIANT(8, POA_WIDE_RING, 8, 3), POA_VARIANT(8, POA_WIDE_RING, 12, 3), POA_VARIANT(8, POA_WIDE_RING, 16, 3),
@@ -3240,6 +3301,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         // on its depth (~1.15 + 0.02 x reads nodes per base, measured at 10 % error).  The shallow packs of a long class get a
         // group of their own, so that the deep ones do not dictate everybody's slot (config 5: 47 slots of 1.15 GB for 747 packs)
         if (cls >= 4 && pack_first[p + 1] - pack_first[p] <= POA_SHALLOW_READS) cls += 4;
+        // a POA #3 group of a many-pack cluster (hundreds of pack consensi, correct.cpp:520-532) is ONE workgroup's serial work for the
+        // whole pass (0.8 s at 1e6 reads in round 4, beside thousands of POA #2 packs in the dense form): such packs form groups of their
+        // own, whose form is chosen by THEIR number -- teams of wavefronts, the shortest row there is -- not by the crowd's
+        if (cls < 4 && pack_first[p + 1] - pack_first[p] > POA_CHAIN_SEQS) cls += 12;
         by_class[cls].push_back(p);
     }
 
@@ -3309,14 +3374,23 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // tests / measurements: RATTLE_POA_MODE = dense | sparse | mt4 | mt2 | mt1 forces one form for the packed classes
     const char *mode_s = getenv("RATTLE_POA_MODE");
     const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : mode_s[0] == 's' ? 2 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : !strcmp(mode_s, "mt4w") ? 6 : 0;
-    uint32_t live_per_cu = 1;                      // packs per CU the pass about to start will keep resident (all classes)
+    uint32_t live_per_cu = 1, chain_per_cu = 1;    // packs per CU the pass about to start will keep resident (all classes; the long-chain groups)
     auto choose_variants = [&]() {
-        uint64_t live = 0;
-        for (int c = 0; c < POA_GROUPS; ++c) live += C[c].todo.size();
+        uint64_t live = 0, chains = 0;
+        for (int c = 0; c < 12; ++c) live += C[c].todo.size();
+        for (int c = 12; c < POA_GROUPS; ++c) chains += C[c].todo.size();
         live_per_cu = (uint32_t)std::max<uint64_t>(1, (live + n_cu - 1) / n_cu);
+        chain_per_cu = (uint32_t)std::max<uint64_t>(1, (chains + n_cu - 1) / n_cu);
         // by packs per CU: one -> four teams per pack (16 wavefronts: the CU is the pack's); two or three -> two teams; four -> the skewed
         // pipeline with ready-made terms (LDS holds four such rings); more -> the barrier form with record words (seven or eight per CU)
-        int mode = force_mode ? force_mode : live_per_cu <= 1 ? 3 : live_per_cu <= 3 ? 4 : live_per_cu <= POA_SPARSE_PACKS_PER_CU ? 2 : 1;
+        // (in eighths of a pack per CU: 829 packs on 256 CUs are 3.2 per CU -- two teams at three per CU with a short queue, not the next form up)
+        const uint64_t l8 = live * 8 / n_cu;
+        // measured (profiles/round5_forms_by_load.txt; 1024- / 1536-column class, GCUPS): one pack per CU -- four teams 303 / 494, two
+        // teams 313 / 463; two per CU -- two teams 557 / 750; three -- two teams 680 / 624 (a short queue), one team 544 / 697, pipeline
+        // 498 / 454, barrier form 441 / 529; four -- one team 631, pipeline 635 / 569, barrier 569 / 649; five and more: the barrier form
+        int mode = force_mode ? force_mode : l8 <= 10 ? 3 : l8 <= 36 ? 4 : 1;
+        const uint64_t c8 = chains * 8 / n_cu;
+        const int chain_mode = force_mode >= 3 ? force_mode : c8 <= 10 ? 3 : 4;
         for (int c = 0; c < POA_GROUPS; ++c) {
             C[c].V = &k_latency[poa_group_class(c)];
             if (c < 4) {
@@ -3325,6 +3399,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 if (exp_pick[c] >= 0 && exp_pick[c] < POA_EXP_MAX) C[c].V = &k_exp[c][exp_pick[c]];
 #endif
             }
+            if (c >= 12) { const int gc = c - 12; C[c].V = force_mode == 1 ? &k_dense[gc] : force_mode == 2 ? &k_sparse[gc] : chain_mode == 3 ? &k_mt4[gc] : chain_mode == 4 ? &k_mt2[gc] : &k_mt1[gc]; }
         }
     };
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
@@ -3351,7 +3426,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
         A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
         A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16); A.o_pland = take((uint64_t)ncap * 16);
-        A.o_planm = take(P.V->pk == 7 ? ((uint64_t)ncap + 8) * 64 : 0);
+        A.o_planm = take(P.V->pk == 7 ? ((uint64_t)ncap + 8) * 32 : 0);
         const uint64_t cell_bytes = long_rows ? 4 : 2;
         if (pk_packed(P.V->pk)) {          // H words carry F's two bits, E's two bits per column sit in a per-thread array
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(0);      // E is rebuilt on demand by the traceback
@@ -3366,16 +3441,15 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         A.ring_slots = A.ring_reach = A.ring_slack = 0;
         if (P.V->pk == 7) {
-            // dp_rows_mt: the ring takes the LDS a workgroup can have when `live_per_cu` packs share a CU (up to 24 slots + the zero
-            // slot); `slack` rows may be in flight behind the reader (two rounds of the teams when there is room, one otherwise),
+            // dp_rows_mt: the ring takes the LDS a workgroup can have when `live_per_cu` packs share a CU (up to 24 slots); `slack` rows may be in flight behind the reader (two rounds of the teams when there is room, one otherwise),
             // `reach` = slots - slack rows back are served from the ring, the rest from the record in HBM
             const uint32_t teams = P.V->ring, slotb = mt_slot_bytes((int)P.V->cpl, (int)P.V->nw);
             const uint32_t fixed = lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + 64u + 3072u;      // + the kernel's static LDS
-            uint32_t ppc = std::max<uint32_t>(1, std::min<uint32_t>(live_per_cu, teams == 4 ? 1u : teams == 2 ? 3u : 4u));
+            uint32_t ppc = std::max<uint32_t>(1, std::min<uint32_t>(c >= 12 ? chain_per_cu : live_per_cu, teams == 4 ? 1u : teams == 2 ? (MT2_MINWAVES >= 6 && P.V->cpl == 4 ? 3u : 2u) : 4u));      // (registers: 16 wavefronts of 128 per CU)
             uint32_t slots = 0, slack = 0;
             for (; ppc >= 1; --ppc) {
                 const uint32_t room = 160u * 1024 / ppc;
-                slots = room > fixed + 2 * slotb ? std::min<uint32_t>(24, (room - fixed) / slotb - 1) : 0;
+                slots = room > fixed + 2 * slotb ? std::min<uint32_t>(24, (room - fixed) / slotb) : 0;
                 slack = teams > 1 ? std::max<uint32_t>(teams, std::min<uint32_t>(2 * teams, slots > 10 ? slots - 10 : 0)) : 0;
                 if (slots >= slack + 6 || ppc == 1) break;
             }
@@ -3384,7 +3458,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.ring_slots = slots; A.ring_slack = slack; A.ring_reach = slots - slack;
         }
         auto lds_bytes = [&](const poa_variant *V) {
-            if (V->pk == 7) return (size_t)lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + (size_t)(A.ring_slots + 1) * mt_slot_bytes((int)V->cpl, (int)V->nw) + 64;
+            if (V->pk == 7) return (size_t)lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + (size_t)A.ring_slots * mt_slot_bytes((int)V->cpl, (int)V->nw) + 64;
             return (size_t)lds_seq + poa_region_bytes(ncap, (int)V->cpl, (int)V->ring, (int)V->nw, (int)V->pk) + 64;
         };
         // a retry pass with a huge graph: the node bitmaps leave no room for a ready-made ring -- fall back to the dense form (2 bytes per cell)
@@ -3448,7 +3522,6 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             any = true;
             P.bpc = P.V->max_blocks(P.shm);
             uint32_t places = n_cu * (uint32_t)P.bpc;
-            if (ctx->poa_reserve) places -= std::max<uint32_t>(places / 24, 8);      // ~4 % of the device's places stay free for another flow's late, few workgroups
             P.n_slots = std::min<uint32_t>((uint32_t)P.todo.size(), places);
             want_bytes += P.per_slot * P.n_slots;
         }
@@ -3517,7 +3590,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             qoff += (uint32_t)P.todo.size();
             if (getenv("RATTLE_TIMING"))
                 fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, %s %u%s) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl,
+                        poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : c >= 12 ? "(long chains) " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl,
                         P.V->pk == 7 ? "teams" : "ring", P.V->ring, P.V->pk == 7 ? (", ring " + std::to_string(A.ring_slots) + " reach " + std::to_string(A.ring_reach)).c_str() : "", pass, P.todo.size(), P.n_slots,
                         P.per_slot / 1e6, P.bpc);
         }
@@ -3564,7 +3637,6 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 e = hipEventRecord(ctx->poa_ev[t], ctx->poa_st[t]);
                 if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->poa_ev[t], 0);
             }
-            if (ctx->poa_launched) *ctx->poa_launched = 1;       // another flow was waiting for these launches to go first
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_status.data(), d_status.p, n_packs * 4, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -41,12 +41,9 @@ def test_correct_big_cluster_stage_split_matches_oracle(gpu_ctx, oracle, monkeyp
     assert sizes[-1] > 75 and sizes[0] < 50                     # clusters with >= 3 packs and with < 3 packs exist
     monkeypatch.setenv("RATTLE_BIG_CLUSTER_PACKS", "3")
     monkeypatch.setenv("RATTLE_BIG_MIN_PACKS", "0")
-    # round 4: with RATTLE_CORRECT_OVERLAP=1 the chain of the big clusters (2a -> 3a) runs on a helper context beside the POA #1 of all
-    # other packs (stage 1 in two groups); the default keeps the stages one after the other -- both must give the oracle's bytes
-    for ov in ("1", "0", "1"):
-        monkeypatch.setenv("RATTLE_CORRECT_OVERLAP", ov)
+    for _ in range(2):
         got = correct_command(gpu_ctx, headers, seqs, quals, clusters, split=25)
-        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2], ov
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
         assert int(got[3][0]) == int(want[3][0])
 
 
@@ -283,7 +280,6 @@ def test_correct_outputs_do_not_depend_on_scheduling(gpu_ctx, monkeypatch):
 
     base = run()
     variants = [{"RATTLE_POA_STREAMS": "1"}, {"RATTLE_POA_STREAMS": "12"}, {"RATTLE_BIG_CLUSTER_PACKS": "3", "RATTLE_BIG_MIN_PACKS": "0"},
-                {"RATTLE_BIG_CLUSTER_PACKS": "3", "RATTLE_BIG_MIN_PACKS": "0", "RATTLE_CORRECT_OVERLAP": "1"},
                 {"RATTLE_POA_MODE": "sparse"}, {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_STREAMS": "2"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
                 {"RATTLE_POA_MODE": "dense"}]
     for env in variants:

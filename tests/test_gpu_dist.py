@@ -83,9 +83,9 @@ def test_sharded_job_equals_single_gpu(tmp_path, world, transport, big):
     if transport == "device":
         env.update(fake_rccl(tmp_path))
     if big:
-        # the big-cluster flow of `correct` on every rank: stage 1 in two groups, the chain 2a -> all-gather -> 3a on the helper
-        # context and its own stream beside group 1's POA #1 (correct_driver.hip); the unsharded reference takes the same path
-        env.update(RATTLE_BIG_CLUSTER_PACKS="3", RATTLE_BIG_MIN_PACKS="0", RATTLE_CORRECT_OVERLAP="1")
+        # the big-cluster flow of `correct` on every rank: POA #2 of the many-pack clusters first (2a), all-gather, their POA #3 beside
+        # everybody else's POA #2 (correct_driver.hip); the unsharded reference takes the same path
+        env.update(RATTLE_BIG_CLUSTER_PACKS="3", RATTLE_BIG_MIN_PACKS="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(29700 + world + (10 if transport == "device" else 0)), str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

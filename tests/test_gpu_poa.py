@@ -124,7 +124,8 @@ def test_packed_classes_in_every_form_of_the_row_loop(gpu_ctx, oracle, monkeypat
         assert got == want
 
 
-@pytest.mark.parametrize("env", [{"RATTLE_POA_DEBUG": "1"}, {"RATTLE_POA_DEBUG": "2"}, {"RATTLE_POA_DEBUG": "3"},
+@pytest.mark.parametrize("env", [{"RATTLE_POA_DEBUG": "1"}, {"RATTLE_POA_DEBUG": "2"}, {"RATTLE_POA_DEBUG": "3"}, {"RATTLE_POA_DEBUG": "4"},
+                                 {"RATTLE_POA_DEBUG": "4", "RATTLE_POA_MODE": "dense"},
                                  {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_MODE": "sparse"}, {"RATTLE_POA_MODE": "dense"},
                                  {"RATTLE_POA_MODE": "mt4"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
                                  {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_DEBUG": "3"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_NODE_CAP": "700"},
