@@ -29,6 +29,8 @@ from rattle_amd.api import K_FILTER, K_KMER, K_POA, K_POST, K_SCORE, Context  # 
 
 METRIC = "reads/sec for `cluster`+`correct` on 1e6×1kb synthetic ONT reads, 1→8 GPU"
 VALU_PEAK_TINSTR = 256 * 4 * 2.4e9 / 2 / 1e12      # wave64 VALU instructions per second: 256 CUs x 4 SIMDs, 2 cycles each at 2.4 GHz
+VALU_PRACTICAL_TINSTR = 256 * 4 * 2.4e9 / 4.3 / 1e12      # ... at the issue rate MEASURED for this kernel's mix (v_pk_*_i16, v_max_i32, DPP, v_perm: 4.3 cycles, tools/ubench_valu.hip)
+SALU_PEAK_TINSTR = 256 * 2.4e9 / 1e12               # one scalar unit per CU, one instruction per cycle
 
 
 def make_workload(n_reads, genes, seed, isoforms=1):
@@ -164,8 +166,9 @@ def _latest(*names):
     return os.path.join("profiles", names[-1])
 
 
-PMC_FILE = _latest("round4_pmc_poa.json", "round3_pmc_poa.json")      # kernel C (tools/gpu_pmc_only.sh); `pmc_stale` says whether it matches the tree
-PMC_ISO_FILE = _latest("round4_pmc_iso.json", "round3_pmc_iso.json")      # kernel B in the --iso flow (tools/gpu_pmc_iso.sh)
+PMC_FILE = _latest("round5_pmc_poa.json", "round4_pmc_poa.json", "round3_pmc_poa.json")      # kernel C (tools/gpu_pmc_only.sh); `pmc_stale` says whether it matches the tree
+PMC_100K_FILE = _latest("round5_pmc_poa_100k.json", "round4_pmc_poa.json")      # ... at 1e5 reads: the under-filled device runs other forms of the row loop (teams of wavefronts)
+PMC_ISO_FILE = _latest("round5_pmc_iso.json", "round4_pmc_iso.json", "round3_pmc_iso.json")      # kernel B in the --iso flow (tools/gpu_pmc_iso.sh)
 
 
 def toyset_line(ctx_cls, device):
@@ -240,18 +243,23 @@ def iso_roofline(kst):
                     "kernel B from the committed PMC passes of the same flow (tools/gpu_pmc_iso.sh), per launch"}
 
 
-def poa_roofline(kst, cells, steps, per_gpu=1, copy_gbs=None):
+def poa_roofline(kst, cells, steps, per_gpu=1, copy_gbs=None, pmc_file=None):
     """kernel C: exact DP cells over its HIP-event time, priced in wave64 VALU instructions per second (it is bound by VALU issue /
     per-row latency, not by HBM: SURVEY 8d, profiles/) against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; `cells` = per step"""
     ms, launches, alg = kst["poa_align"]
     gcups = cells / per_gpu / (ms / steps * 1e-3) / 1e9 if ms > 0 else 0.0
     hbm6 = 6.0 * gcups
-    pmc = pmc_reference()
+    pmc = pmc_reference(pmc_file)
     ipc = pmc.get("valu_wave_instr_per_cell") if pmc else None
+    spc = pmc.get("salu_wave_instr_per_cell") if pmc else None
     ach = gcups * 1e9 * ipc / 1e12 if ipc else None
     return {
         "bound": "valu_issue", "kernel": "poa_align", "achieved": ach, "peak": VALU_PEAK_TINSTR, "unit": "Tinstr/s",
         "frac": ach / VALU_PEAK_TINSTR if ach else None,
+        # `frac` falls when instructions are cut at equal GCUPS; the two gauges that do not mislead: the fraction of the issue rate this
+        # instruction mix can reach at all, and how busy the CU's one scalar unit is (round 4: it was the busier of the two)
+        "frac_practical": ach / VALU_PRACTICAL_TINSTR if ach else None, "peak_practical": VALU_PRACTICAL_TINSTR,
+        "salu_wave_instr_per_cell": spc, "salu_frac": gcups * 1e9 * spc / 1e12 / SALU_PEAK_TINSTR if spc else None,
         "valu_wave_instr_per_cell": ipc, "gcups": gcups, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
         "cells_per_launch": cells * steps / max(launches, 1),
         # HBM view: SURVEY 8(d)'s 6 B per DP cell (three int16 matrices) and what the kernel really stores
@@ -259,7 +267,7 @@ def poa_roofline(kst, cells, steps, per_gpu=1, copy_gbs=None):
                 "stored_bytes_per_cell": pmc.get("hbm_bytes_per_cell") if pmc else None,
                 "achieved_stored_gbs": gcups * pmc["hbm_bytes_per_cell"] if pmc and pmc.get("hbm_bytes_per_cell") else None},
         "traffic": (pmc["hbm_bytes_per_cell"] * cells * steps / max(launches, 1)) if pmc and pmc.get("hbm_bytes_per_cell") else None,
-        "pmc_source": PMC_FILE if pmc else None,
+        "pmc_source": (pmc_file or PMC_FILE) if pmc else None,
         # true: poa.hip / common.h changed after the counter passes were collected -- the per-cell constants (and `frac`,
         # `traffic`) then describe an older kernel; GCUPS and the timings are always live
         "pmc_stale": bool(pmc.get("stale")) if pmc else None,
@@ -322,7 +330,7 @@ def side_config(device, n_reads, iso, steps=2):
         assert (cluster_digest(cl), res.digest()) == dg_w, "result differs between passes"
         rec["workload"] = f"{n} synthetic cDNA reads, {genes} transcripts, `rattle cluster` k=10 gene level + `rattle correct` (BASELINE configs[1] size)"
         rec["clusters"], rec["packs"], rec["cluster_reads_per_s"] = int(len(cl.main_id)), int(counters[2]), n / (t_cluster / steps)
-        rec["roofline"] = poa_roofline(kst, int(counters[0]), steps)
+        rec["roofline"] = poa_roofline(kst, int(counters[0]), steps, pmc_file=PMC_100K_FILE)
     rec["digest_equal_across_steps"] = True
     for o in outs:
         if o[2] is not None:

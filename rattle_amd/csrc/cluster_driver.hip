@@ -224,16 +224,35 @@ struct evaluator {
             std::vector<std::vector<uint8_t>> all;
             RT_TRY(xchg_allgatherv(ctx, pay, all));
             q.hits.clear();
-            for (const std::vector<uint8_t> &b : all) {
+            const bool replay = xchg_replaying(ctx);      // (measurement aid, common.h: the piece beside this rank's own is the WHOLE job's hit list)
+            for (int p = 0; p < R; ++p) {
+                const std::vector<uint8_t> &b = all[(size_t)p];
+                if (replay && b.empty()) continue;
                 if (b.size() < 24 || (b.size() - 24) % 12) { set_error("cluster exchange: malformed hit list"); return RATTLE_ERR_HIP; }
-                for (int i = 0; i < 3; ++i) { uint64_t d; memcpy(&d, b.data() + 8 * i, 8); q.counters[i] += d; }
+                if (!(replay && p == r)) for (int i = 0; i < 3; ++i) { uint64_t d; memcpy(&d, b.data() + 8 * i, 8); q.counters[i] += d; }
                 for (size_t at = 24; at < b.size(); at += 12) {
                     uint32_t t[3];
                     memcpy(t, b.data() + at, 12);
+                    if (replay && p != r && t[1] % (uint32_t)R == (uint32_t)r) continue;      // this rank's own hits arrived in its own piece
                     q.hits.push_back(hit_t{t[0], t[1], (uint8_t)t[2]});
                 }
             }
             return 0;
+        }
+        if (shard && xchg_recording(ctx)) {
+            // single rank, recording: the same payload a sharded job exchanges here, for the whole request
+            if (reqs.size() != 1 || reqs[0]->triangular) { set_error("sharded evaluation takes one rectangular request"); return RATTLE_ERR_STATE; }
+            request &q = *reqs[0];
+            uint64_t before[3] = {q.counters[0], q.counters[1], q.counters[2]};
+            RT_TRY(run_chunks(reqs));
+            std::vector<uint8_t> pay(24 + q.hits.size() * 12);
+            for (int i = 0; i < 3; ++i) { const uint64_t d = q.counters[i] - before[i]; memcpy(pay.data() + 8 * i, &d, 8); }
+            for (size_t i = 0; i < q.hits.size(); ++i) {
+                const uint32_t t[3] = {q.hits[i].seed, q.hits[i].cand, q.hits[i].rev};
+                memcpy(pay.data() + 24 + 12 * i, t, 12);
+            }
+            std::vector<std::vector<uint8_t>> all;
+            return xchg_allgatherv(ctx, pay, all);
         }
         return run_chunks(reqs);
     }

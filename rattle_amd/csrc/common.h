@@ -25,10 +25,12 @@ struct phase_timer {
         static const bool enabled = getenv("RATTLE_TIMING") != nullptr;
         on = enabled;
     }
-    ~phase_timer() {
+    void stop() {
         if (on) fprintf(stderr, "[rattle] %-28s %8.1f ms\n", name,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        on = false;
     }
+    ~phase_timer() { stop(); }
 };
 
 void set_error(const std::string &msg);
@@ -174,6 +176,11 @@ struct exchange {
     void *comm = nullptr;               // ncclComm_t
     void *rccl = nullptr;               // dlopen handle of librccl.so
     uint64_t calls = 0, bytes = 0;      // statistics
+    // Measurement aid (round 5: the multi-GPU curve measured on ONE GPU, tools/rank_replay.py): what the ranks of a job exchange is
+    // recorded by a single-rank run (RATTLE_XCHG_RECORD=<file>: every exchange point appends the job's WHOLE payload), and a context
+    // configured as rank r of R with rattle_hip_set_exchange(.., fn = NULL) under RATTLE_XCHG_REPLAY=<file> then runs its own share
+    // alone: at every exchange it gets its own piece back plus the recorded whole (its peers' part of it).
+    FILE *replay = nullptr;
     // staging of the RCCL all-gather-v, kept between calls: the sharded cluster driver exchanges a few KB per greedy round
     // (119 rounds at 1e6 reads) and three hipMalloc / hipFree pairs per exchange were three device-wide synchronisations each
     dbuf<uint64_t> d_sz;
@@ -182,6 +189,7 @@ struct exchange {
     hbuf<uint8_t> h_send, h_recv;       // pinned: the copies are asynchronous and run at link speed
     void reset() {
         rank = 0; nranks = 1; fn = nullptr; user = nullptr; comm = nullptr; calls = 0; bytes = 0;      // the loader's handle (rccl) stays
+        if (replay) { fclose(replay); replay = nullptr; }
         d_sz.release(); d_send.release(); d_recv.release(); h_sz.release(); h_send.release(); h_recv.release();
     }
 };
@@ -207,6 +215,8 @@ int plan_packs(const uint64_t *off, uint32_t n_reads, uint32_t n_clusters, const
 // longest-processing-time-first assignment of weighted items to nranks bins (ties: lower index / lower rank)
 void lpt_assign(const std::vector<uint64_t> &cost, int nranks, std::vector<uint32_t> &owner);
 // all-gather of one byte string per rank (sizes first, then the payload)
+bool xchg_recording(const rattle_ctx *ctx);
+bool xchg_replaying(const rattle_ctx *ctx);
 int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all);
 
 // one rectangle of kernel A's launch: seeds [s_base, s_base+ns) x candidates [c_base, c_base+nc) of the uploaded
@@ -284,6 +294,7 @@ struct rattle_ctx {
     uint8_t *poa_arena = nullptr;
     size_t poa_arena_bytes = 0;
     hipStream_t poa_st[16] = {};     // one per column class: classes run concurrently
+    int poa_shallow_graphs = 0;      // hint of the caller for the next poa_device_run: near-identical sequences (POA #2 / #3), graphs that are almost chains
     hipEvent_t poa_ev[16] = {};
     hipEvent_t poa_go = nullptr;
     rattle::hbuf<uint32_t> h_poa_col;       // pinned staging for the per-base MSA columns

@@ -212,6 +212,10 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     unsigned long long h_cnt[16];
     {
         phase_timer T("  stage: POA");
+        // POA #2 / #3 align corrected reads / pack consensi: their graphs are almost chains -- rows that depend on each other
+        // (teams of wavefronts gain nothing), and per alignment as much serial work as DP (what pays is many packs per CU)
+        ctx->poa_shallow_graphs = mode == 2;
+        struct unhint { rattle_ctx *c; ~unhint() { c->poa_shallow_graphs = 0; } } uh{ctx};
         RT_TRY(poa_device_run(ctx, S.seq.p, S.d_off.p, S.off.data(), n, S.first.data(), np, S.col.p, S.d_width.p, S.width.data(), h_cnt, &S.skipped));
     }
     d_desc.release();
@@ -573,7 +577,8 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
                 if (all[r].size() >= 12) { memcpy(&id, all[r].data(), 4); memcpy(&flag, all[r].data() + 4, 4); }
                 if (id == 0xFFFFFFFFu && flag == 0xFFFFFFFFu) { set_error("correct_reads failed on rank " + std::to_string(r)); return RATTLE_ERR_HIP; }
             }
-        } else { all.resize(1); all[0].swap(mine_bytes); }
+        } else if (xchg_recording(ctx)) RT_TRY(xchg_allgatherv(ctx, mine_bytes, all));      // (measurement aid, common.h)
+        else { all.resize(1); all[0].swap(mine_bytes); }
         for (const std::vector<uint8_t> &b : all) {
             size_t at = 0;
             while (at + 12 <= b.size()) {
@@ -707,7 +712,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
         LOCAL_TRY(cons_pass(ctx, "correct: stage 3b", {}, g3b, bytes_3b, sk_3b, cnt_main));
         // several ranks: this exchange always takes place, so that every rank leaves with the same verdict (the caller's
         // next collective is the gather of the corrected reads)
-        if (!g3b_all.empty() || nranks > 1) RT_TRY(exchange_stage(bytes_3b, local_rc, local_msg));
+        if (!g3b_all.empty() || nranks > 1 || xchg_recording(ctx)) RT_TRY(exchange_stage(bytes_3b, local_rc, local_msg));
     }
     // skipped packs of the consensus stages in the order the sequential flow meets them: 2a, then 3a before 2b (one pass), then 3b
     for (std::vector<skip_t> *v : {&sk_2a, &sk_3a, &sk_2b, &sk_3b}) for (skip_t &x : *v) skips.push_back(std::move(x));

@@ -94,11 +94,38 @@ int rccl_allgatherv(rattle_ctx *ctx, const uint8_t *d_send, uint8_t *d_recv, con
 
 }  // namespace
 
+// RATTLE_XCHG_RECORD (single rank): the file every exchange point appends the job's whole payload to
+static FILE *xchg_record_file() {
+    static FILE *f = getenv("RATTLE_XCHG_RECORD") ? fopen(getenv("RATTLE_XCHG_RECORD"), "wb") : nullptr;
+    return f;
+}
+bool xchg_recording(const rattle_ctx *ctx) { return ctx->xchg.nranks == 1 && xchg_record_file() != nullptr; }
+bool xchg_replaying(const rattle_ctx *ctx) { return ctx->xchg.replay != nullptr; }
+
 int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all) {
     exchange &X = ctx->xchg;
     all.assign((size_t)X.nranks, {});
-    if (X.nranks == 1) { all[0] = mine; return 0; }
+    if (X.nranks == 1) {
+        all[0] = mine;
+        if (FILE *f = xchg_record_file()) {
+            const uint64_t n = mine.size();
+            if (fwrite(&n, 8, 1, f) != 1 || (n && fwrite(mine.data(), 1, n, f) != n)) { set_error("exchange record: write failed"); return RATTLE_ERR_HIP; }
+            fflush(f);
+        }
+        return 0;
+    }
     ++X.calls;
+    if (X.replay) {
+        // this rank's own piece, and the recorded whole of the single-rank job in the next rank's place (the caller drops what is its own in it)
+        uint64_t n = 0;
+        if (fread(&n, 8, 1, X.replay) != 1) { set_error("exchange replay: the record has no entry for this exchange"); return RATTLE_ERR_STATE; }
+        std::vector<uint8_t> &whole = all[(size_t)((X.rank + 1) % X.nranks)];
+        whole.resize(n);
+        if (n && fread(whole.data(), 1, n, X.replay) != n) { set_error("exchange replay: short record"); return RATTLE_ERR_STATE; }
+        all[(size_t)X.rank] = mine;
+        X.bytes += n;
+        return 0;
+    }
     std::vector<uint64_t> bytes((size_t)X.nranks, 0);
     const uint64_t my_bytes = mine.size();
     if (X.comm) {
@@ -151,6 +178,29 @@ struct gathered {
 static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int root, gathered &G) {
     exchange &X = ctx->xchg;
     G.p.assign((size_t)X.nranks, nullptr); G.n.assign((size_t)X.nranks, 0);
+    if (X.replay) {
+        // the ranks' pieces travel through files beside the record: every rank leaves its piece, the root (run last) picks the others up
+        const std::string base = std::string(getenv("RATTLE_XCHG_REPLAY")) + ".gather.";
+        if (X.rank != root) {
+            FILE *f = fopen((base + std::to_string(X.rank)).c_str(), "wb");
+            if (!f || (mine.size() && fwrite(mine.data(), 1, mine.size(), f) != mine.size())) { if (f) fclose(f); set_error("gather replay: cannot write this rank's piece"); return RATTLE_ERR_HIP; }
+            fclose(f);
+            return 0;
+        }
+        G.owned.assign((size_t)X.nranks, {});
+        for (int r = 0; r < X.nranks; ++r) {
+            if (r == root) { G.owned[r] = mine; continue; }
+            FILE *f = fopen((base + std::to_string(r)).c_str(), "rb");
+            if (!f) { set_error("gather replay: the piece of rank " + std::to_string(r) + " is missing (run the root last)"); return RATTLE_ERR_STATE; }
+            fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+            G.owned[r].resize((size_t)n);
+            const bool ok = n == 0 || fread(G.owned[r].data(), 1, (size_t)n, f) == (size_t)n;
+            fclose(f);
+            if (!ok) { set_error("gather replay: short piece"); return RATTLE_ERR_STATE; }
+        }
+        for (int r = 0; r < X.nranks; ++r) { G.p[r] = G.owned[r].data(); G.n[r] = G.owned[r].size(); }
+        return 0;
+    }
     if (X.nranks == 1 || !X.comm) {
         RT_TRY(xchg_allgatherv(ctx, mine, G.owned));
         if (X.rank == root) for (int r = 0; r < X.nranks; ++r) { G.p[r] = G.owned[r].data(); G.n[r] = G.owned[r].size(); }
@@ -283,24 +333,37 @@ void merge_sets(const std::vector<piece_view> &V, rattle_read_set &S, uint32_t *
         }
         tot += V[p].n ? V[p].off[V[p].n] : 0;
     }
-    std::stable_sort(refs.begin(), refs.end(), [](const rec_ref &a, const rec_ref &b) { return a.key < b.key; });
+    // A rank's records arrive in pack order already (round 5: the root's merge of 1e6 reads took 0.5 s, a third of it this sort):
+    // a counting sort over the keys (pack indices) is stable and linear
+    {
+        uint64_t kmax = 0;
+        for (const rec_ref &r : refs) kmax = std::max(kmax, r.key);
+        if (kmax < (1ull << 26) && refs.size() > 4096) {
+            std::vector<uint32_t> start(kmax + 2, 0);
+            for (const rec_ref &r : refs) ++start[r.key + 1];
+            for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+            std::vector<rec_ref> sorted(refs.size());
+            for (const rec_ref &r : refs) sorted[start[r.key]++] = r;          // pieces in rank order, records in their order: stable
+            refs.swap(sorted);
+        } else std::stable_sort(refs.begin(), refs.end(), [](const rec_ref &a, const rec_ref &b) { return a.key < b.key; });
+    }
     alloc_set(S, (uint32_t)refs.size(), tot);
     uint32_t *pk = (uint32_t *)malloc(std::max<size_t>(1, refs.size()) * 4);
     uint64_t at = 0;
     for (size_t i = 0; i < refs.size(); ++i) {
         const piece_view &P = V[refs[i].piece];
         const uint32_t j = refs[i].idx;
-        S.read_id[i] = P.read_id[j]; S.cluster_id[i] = P.cluster_id[j]; S.n_reads[i] = P.n_reads[j];
         S.off[i] = at;
-        pk[i] = P.pack[j];
         at += P.off[j + 1] - P.off[j];
     }
     const size_t chunk = 4096;
-    parallel_for((refs.size() + chunk - 1) / chunk, refs.size() > 8 * chunk ? 16 : 1, [&](size_t c) {
+    parallel_for((refs.size() + chunk - 1) / chunk, refs.size() > 8 * chunk ? 32 : 1, [&](size_t c) {      // 32 host threads: 2 x 2 GB of copies into fresh pages
         for (size_t i = c * chunk; i < std::min(refs.size(), (c + 1) * chunk); ++i) {
             const piece_view &P = V[refs[i].piece];
             const uint32_t j = refs[i].idx;
             const uint64_t len = P.off[j + 1] - P.off[j];
+            S.read_id[i] = P.read_id[j]; S.cluster_id[i] = P.cluster_id[j]; S.n_reads[i] = P.n_reads[j];
+            pk[i] = P.pack[j];
             memcpy(S.seq + S.off[i], P.seq + P.off[j], len); memcpy(S.qual + S.off[i], P.qual + P.off[j], len);
         }
     });
@@ -315,6 +378,7 @@ int correction_gather(rattle_ctx *ctx, const rattle_correction *L, int root, rat
     *merged = nullptr;
     if (root < 0 || root >= X.nranks) { set_error("root out of range"); return RATTLE_ERR_ARG; }
     std::vector<uint8_t> mine;
+    phase_timer T_ser("gather: serialise this rank's share");
     put_set(mine, L->corrected, L->corrected_pack);
     put_set(mine, L->uncorrected, L->uncorrected_pack);
     {
@@ -325,9 +389,14 @@ int correction_gather(rattle_ctx *ctx, const rattle_correction *L, int root, rat
         if ((3 * n + tot) & 1) { const uint32_t z = 0; put(mine, &z, 1); }
         put(mine, L->counters, 8);
     }
+    T_ser.stop();
     gathered G;
-    RT_TRY(xchg_gatherv(ctx, mine, root, G));
+    {
+        phase_timer T_tr("gather: transport");
+        RT_TRY(xchg_gatherv(ctx, mine, root, G));
+    }
     if (X.rank != root) return 0;
+    phase_timer T_merge("gather: merge on the root");
     rattle_correction *R = (rattle_correction *)calloc(1, sizeof(rattle_correction));
     std::vector<piece_view> cor, unc;
     struct skip_ref { int32_t cid; uint32_t pack, stage; const int32_t *rid; uint64_t n; };
@@ -389,8 +458,14 @@ using namespace rattle;
 extern "C" {
 
 int rattle_hip_set_exchange(rattle_ctx *c, int rank, int nranks, rattle_allgatherv_fn fn, void *user) {
-    if (!c || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) { set_error("bad exchange arguments"); return RATTLE_ERR_ARG; }
+    const char *replay = getenv("RATTLE_XCHG_REPLAY");      // (measurement aid: this rank alone, its peers' payloads from a record; common.h)
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn && !replay)) { set_error("bad exchange arguments"); return RATTLE_ERR_ARG; }
     if (c->xchg.comm) { set_error("an RCCL communicator is attached: rattle_hip_comm_destroy first"); return RATTLE_ERR_STATE; }
+    if (c->xchg.replay) { fclose(c->xchg.replay); c->xchg.replay = nullptr; }
+    if (nranks > 1 && !fn) {
+        c->xchg.replay = fopen(replay, "rb");
+        if (!c->xchg.replay) { set_error(std::string("exchange replay: cannot open ") + replay); return RATTLE_ERR_ARG; }
+    }
     c->xchg.rank = rank; c->xchg.nranks = nranks; c->xchg.fn = fn; c->xchg.user = user;
     return 0;
 }

@@ -2913,9 +2913,19 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                             } else { pl = S.plan[i - 1]; plb = S.planb[i - 1]; }
                             const uint32_t n_in = rd_nin(pl.x);
                             const uint32_t npred = n_in ? n_in : 1u;
+                            // Round 5: the record words every test of this step may need -- the cells above (vertical moves, first four
+                            // predecessors) and the cell to the left -- are requested TOGETHER with the diagonal candidates: a gap used to
+                            // cost a memory round trip per predecessor tried, one after the other, behind the diagonal's own
+                            int32_t wv[4] = {-1, -1, -1, -1}, wh = -1;          // -1: no such cell (virtual row / column 0)
                             {
                                 const int32_t mc = rd_letter(pl.x) == (PK == 2 ? s[j - 1] : S.sq[j - 1]) ? POA_M : POA_N;
                                 const uint32_t q0 = n_in ? plb.x : 0u, q1 = npred > 1 ? plb.y : q0, q2 = npred > 2 ? plb.z : q0, q3 = npred > 3 ? plb.w : q0;
+                                if constexpr (pk_packed(PK)) {
+                                    const uint32_t qq[4] = {q0, q1, q2, q3};
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) if (qq[k] != 0 && (uint32_t)k < npred) wv[k] = (int32_t)H[(uint64_t)qq[k] * Lp + j - 1];
+                                    if (j > 1) wh = (int32_t)H[(uint64_t)i * Lp + j - 2];
+                                }
                                 const int32_t c0 = Hat(q0, j - 1), c1 = Hat(q1, j - 1), c2 = Hat(q2, j - 1), c3 = Hat(q3, j - 1);
                                 if (Hij == c0 + mc) { pi = q0; Hn = c0; found = true; }
                                 else if (npred > 1 && Hij == c1 + mc) { pi = q1; Hn = c1; found = true; }
@@ -2938,11 +2948,18 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                 for (uint32_t k = 0; k < npred; ++k) {
                                     uint32_t p = 0;
                                     if (n_in) { if (k < 4) p = u4_get(plb, k); else { const uint2 ed = S.edges[e]; e = ed.y; p = (uint32_t)S.rank[ed.x] + 1; } }
-                                    if ((ext_up = (Hij == Fat(p, j) + POA_E)) || Hij == Hat(p, j) + POA_G) { pi = p; pj = j; found = true; break; }
+                                    int32_t Fp, Hp;
+                                    if (pk_packed(PK) && k < 4) {            // from the words requested above
+                                        const int32_t w = wv[k];
+                                        Hp = w == -1 ? 0 : (w & 0x3FFF);
+                                        Fp = w == -1 ? POA_NEG : (w & 0x3FFF) - ((w >> 14) & 3);
+                                    } else { Fp = Fat(p, j); Hp = Hat(p, j); }
+                                    if ((ext_up = (Hij == Fp + POA_E)) || Hij == Hp + POA_G) { pi = p; pj = j; found = true; break; }
                                 }
                             }
                             if (!found) {
-                                if ((ext_left = (Hij == Eat(i, j - 1) + POA_E)) || Hij == Hat(i, j - 1) + POA_G) { pi = i; pj = j - 1; found = true; }
+                                const int32_t Hl = pk_packed(PK) ? (wh == -1 ? 0 : (wh & 0x3FFF)) : Hat(i, j - 1);
+                                if ((ext_left = (Hij == Eat(i, j - 1) + POA_E)) || Hij == Hl + POA_G) { pi = i; pj = j - 1; found = true; }
                             }
                             if (!found) { err = POA_ERR_GRAPH; break; }
                             put(i == pi ? -1 : (int32_t)i, j == pj ? -1 : (int32_t)(j - 1));
@@ -3389,6 +3406,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         // teams 313 / 463; two per CU -- two teams 557 / 750; three -- two teams 680 / 624 (a short queue), one team 544 / 697, pipeline
         // 498 / 454, barrier form 441 / 529; four -- one team 631, pipeline 635 / 569, barrier 569 / 649; five and more: the barrier form
         int mode = force_mode ? force_mode : l8 <= 10 ? 3 : l8 <= 36 ? 4 : 1;
+        // near-chain graphs (POA #2 / #3, the caller says so): no row parallelism to find, and per alignment as much serial work as DP --
+        // beyond two packs per CU the barrier form with everything resident wins (measured in the rank replay at 1e6 reads: 833 such
+        // packs took 0.46-0.53 s on two teams, 1667 of them 0.39 s in the barrier form)
+        if (!force_mode && ctx->poa_shallow_graphs && l8 > 18) mode = 1;
         const uint64_t c8 = chains * 8 / n_cu;
         const int chain_mode = force_mode >= 3 ? force_mode : c8 <= 10 ? 3 : 4;
         for (int c = 0; c < POA_GROUPS; ++c) {

@@ -201,3 +201,16 @@ def test_local_failure_reaches_every_rank_instead_of_hanging(tmp_path, world):
                         "--master-port", str(29730 + world), str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("FAIL_OK") == world and "THEN_OK" in r.stdout and "NO_ERROR" not in r.stdout
+
+
+def test_rank_replay_reproduces_the_single_rank_result(tmp_path):
+    """tools/rank_replay.py (the multi-GPU curve measured on one GPU): the single-rank job records what it holds at every exchange
+    point, then every rank of a world of three runs its own share ALONE with its peers' payloads from that record (replay transport
+    of exchange.hip) -- the root's merged result must be the single-rank result, byte for byte (digest over every output array)."""
+    out = tmp_path / "replay.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rank_replay.py"), "--reads", "4000", "--world", "3", "--record", str(tmp_path / "rec.bin"),
+                        "--out", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    import json
+    res = json.loads(out.read_text())
+    assert res["root_result_equals_single_rank"] and len(res["ranks"]) == 3
