@@ -33,6 +33,37 @@ VALU_PRACTICAL_TINSTR = 256 * 4 * 2.4e9 / 4.3 / 1e12      # ... at the issue rat
 SALU_PEAK_TINSTR = 256 * 2.4e9 / 1e12               # one scalar unit per CU, one instruction per cycle
 
 
+def device_state():
+    """What the box says about the device's clocks and power right now (sysfs; None where it says nothing): boxes and consecutive runs
+    differ by +-8 % for one binary, so the line carries the state it was measured in, before and after the timed region."""
+    import glob
+    st = {}
+    try:
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if not os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                continue
+            for key, f in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+                try:
+                    cur = [l.split(":")[1].strip().rstrip("*").strip() for l in open(os.path.join(d, f)) if "*" in l]
+                    st[key] = cur[0] if cur else None
+                except Exception:
+                    st[key] = None
+            try:
+                st["busy_percent"] = int(open(os.path.join(d, "gpu_busy_percent")).read())
+            except Exception:
+                pass
+            for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                for key, f, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+                    try:
+                        st.setdefault(key, round(int(open(os.path.join(hw, f)).read()) * scale, 1))
+                    except Exception:
+                        pass
+            break
+    except Exception:
+        pass
+    return st or None
+
+
 def make_workload(n_reads, genes, seed, isoforms=1):
     # mean ~1 kb transcripts (8 exons of U[50,210]), 10 % error, both strands (cDNA); packed arrays
     return synth.reads_packed(n_reads, genes, isoforms, True, seed=seed, exon=(50, 210))
@@ -478,20 +509,27 @@ def main():
             hold = psutil.virtual_memory().available > 3 * per * (a.steps + 2)
         except Exception:
             hold = False
+    state0 = device_state() if rank == 0 else None
     barrier()
     t0 = time.time()
     last = None
+    step_ms = []
     for _ in range(a.steps):
         if last is not None and not a.iso:
             if hold:
                 held.append(last[1])
             else:
                 last[1].free()
+        ts = time.time()
         last = step()
+        step_ms.append((time.time() - ts) * 1e3)
     barrier()
     dt = time.time() - t0
+    state1 = device_state() if rank == 0 else None
+    tf = time.time()
     for h in held:
         h.free()
+    free_ms = (time.time() - tf) * 1e3 / max(1, len(held)) if held else None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -546,6 +584,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if a.weak else "strong", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic", "inputs": "host buffers per step (PCIe inclusive)" if a.no_stage else "resident in HBM (rattle_hip_stage_reads)",
             "checks": checks,
+            # every timed step on its own (first-step vs steady state), the state of the device around the timed region, and what the
+            # harness kept OUT of the timed region: a step's ~2 GB result is freed after the timer stops when the host has the memory
+            # (`results_held`), which costs `result_free_ms` per step when it is done between steps instead
+            "step_ms": [round(x, 1) for x in step_ms], "device_state": {"before": state0, "after": state1},
+            "results_held": bool(hold), "result_free_ms": free_ms,
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
             "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items() if v > 0},
             "phase_reads_per_s": {k: n_reads / (v / a.steps) for k, v in PHASES.items() if v > 0},

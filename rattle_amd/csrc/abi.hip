@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <dirent.h>
 #include <unistd.h>
 
 #include <memory>
@@ -28,15 +29,22 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
 // starts -- the first HIP call of the process -- so the value is settled when this library is LOADED, not when kernel C runs:
 // if the variable is set by then it is taken at its word; if it is not and the runtime has not started yet (no /dev/kfd
 // descriptor in the process), the library sets it to 12 itself; otherwise the runtime is already running with its default of 4.
+// RATTLE_NO_ENV_SETUP=1 keeps the library's hands off the environment (a multi-threaded host that cannot have setenv() called under
+// it at dlopen time, or one that wants the runtime's default for its other HIP users): kernel C then deals its classes onto four streams.
 static int g_hw_queues = 4;
 __attribute__((constructor)) static void settle_hw_queues() {
     if (const char *v = getenv("GPU_MAX_HW_QUEUES")) { g_hw_queues = std::max(1, atoi(v)); return; }
+    if (getenv("RATTLE_NO_ENV_SETUP")) return;
     bool runtime_up = false;
-    char link[64], target[256];
-    for (int fd = 0; fd < 1024 && !runtime_up; ++fd) {
-        snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
-        const ssize_t n = readlink(link, target, sizeof target - 1);
-        if (n > 0) { target[n] = 0; runtime_up = strcmp(target, "/dev/kfd") == 0; }
+    if (DIR *d = opendir("/proc/self/fd")) {                 // every descriptor of the process, whatever its number
+        char link[300], target[256];
+        while (struct dirent *e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            snprintf(link, sizeof link, "/proc/self/fd/%s", e->d_name);
+            const ssize_t n = readlink(link, target, sizeof target - 1);
+            if (n > 0) { target[n] = 0; if (strcmp(target, "/dev/kfd") == 0) { runtime_up = true; break; } }
+        }
+        closedir(d);
     }
     if (!runtime_up) { setenv("GPU_MAX_HW_QUEUES", "12", 0); g_hw_queues = 12; }
 }

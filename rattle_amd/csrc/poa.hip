@@ -3285,6 +3285,30 @@ static const poa_variant k_exp[4][POA_EXP_MAX] = {
     {POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 6), POA_VARIANT(10, 4, 4, 6), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5)}};
 #endif
 
+// Every switch kernel C's host side takes from the environment (tests and measurements only; read once per call, so a test may change
+// them between calls): one place, one struct.
+struct poa_env {
+    const char *timeline = nullptr;      // RATTLE_POA_TIMELINE=<file>: when each pack's workgroup started and finished it
+    const char *mode = nullptr;          // RATTLE_POA_MODE = dense | sparse | mt4 | mt2 | mt1 | mt4w: one form of the row loop for the packed classes
+    const char *profile_json = nullptr;  // RATTLE_POA_PROFILE_JSON=<file> (POA_PROFILE builds): phase shares per class
+    const char *exp = nullptr;           // RATTLE_POA_EXP (POA_EXPERIMENTS builds): index into the candidate table per class
+    uint32_t node_cap = 0;               // RATTLE_POA_NODE_CAP: first-pass node capacity (tests lower it to force re-runs)
+    uint64_t budget_mb = 0;              // RATTLE_POA_BUDGET_MB: arena budget (tests shrink it to exercise the skip path)
+    uint32_t debug = 0;                  // RATTLE_POA_DEBUG: bit 0 full sort for ties, bit 1 traceback without the LDS chain, bit 2 ... without jump tables
+    uint32_t mt_slots = 0;               // RATTLE_POA_MT_SLOTS: ring slots of the team kernels (tests: a short ring, many predecessors from HBM)
+    int streams = 0;                     // RATTLE_POA_STREAMS: streams the classes of a pass are dealt onto
+    bool timing = false;                 // RATTLE_TIMING: one line per class and pass
+    poa_env() {
+        timeline = getenv("RATTLE_POA_TIMELINE"); mode = getenv("RATTLE_POA_MODE"); profile_json = getenv("RATTLE_POA_PROFILE_JSON"); exp = getenv("RATTLE_POA_EXP");
+        if (const char *v = getenv("RATTLE_POA_NODE_CAP")) node_cap = (uint32_t)std::max(64, atoi(v));
+        if (const char *v = getenv("RATTLE_POA_BUDGET_MB")) budget_mb = (uint64_t)atoll(v);
+        if (const char *v = getenv("RATTLE_POA_DEBUG")) debug = (uint32_t)atoi(v);
+        if (const char *v = getenv("RATTLE_POA_MT_SLOTS")) mt_slots = (uint32_t)std::max(1, atoi(v));
+        if (const char *v = getenv("RATTLE_POA_STREAMS")) streams = atoi(v);
+        timing = getenv("RATTLE_TIMING") != nullptr;
+    }
+};
+
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
 // skipped != nullptr: packs that do not fit the device are flagged there (1) instead of failing the call;
@@ -3293,6 +3317,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                    const uint32_t *pack_first, uint32_t n_packs, uint32_t *d_col_out, uint32_t *d_width_out, uint32_t *h_width_out,
                    unsigned long long *h_cnt, std::vector<uint8_t> *skipped) {
     hipStream_t st = ctx->stream;
+    const poa_env ENV;
     for (int i = 0; i < 16; ++i) h_cnt[i] = 0;
     if (skipped) skipped->assign(n_packs, 0);
     if (n_packs == 0 || n_seqs == 0) { for (uint32_t p = 0; p < n_packs; ++p) h_width_out[p] = 0; return 0; }
@@ -3363,12 +3388,12 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     dbuf<uint32_t> d_heads;
     RT_TRY(d_heads.reserve(16));
     // RATTLE_POA_TIMELINE=<file>: when each pack's workgroup started and finished it (measurement aid: how full the device is over a pass)
-    const char *tl_path = getenv("RATTLE_POA_TIMELINE");
+    const char *tl_path = ENV.timeline;
     dbuf<unsigned long long> d_tl;
     if (tl_path) { RT_TRY(d_tl.reserve(2 * (size_t)n_packs)); RT_HIP(hipMemsetAsync(d_tl.p, 0, 16 * (size_t)n_packs, st)); }
     struct cls_plan {
         std::vector<uint32_t> todo;
-        uint32_t node_cap = getenv("RATTLE_POA_NODE_CAP") ? (uint32_t)std::max(64, atoi(getenv("RATTLE_POA_NODE_CAP"))) : 10240u;   // first-round capacity (tests lower it to force re-runs)
+        uint32_t node_cap = 10240u;                // first-round capacity (RATTLE_POA_NODE_CAP: tests lower it to force re-runs)
         uint64_t cell_cap = 24ull << 20;           // elements per matrix
         poa_args A;
         uint64_t per_slot = 0;
@@ -3379,7 +3404,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         bool clamped = false;                      // cell_cap was cut to what one slot can get: packs that still fail are skipped
         const poa_variant *V = nullptr;
     } C[POA_GROUPS];
-    for (int c = 0; c < POA_GROUPS; ++c) C[c].todo = by_class[c];
+    for (int c = 0; c < POA_GROUPS; ++c) { C[c].todo = by_class[c]; if (ENV.node_cap) C[c].node_cap = ENV.node_cap; }
     // The kernel of a class is chosen per PASS from how full the device will be (round 3's verdict: one wavefront / column split
     // per class, chosen by read length only, collapsed to 0.08 of the issue roofline whenever fewer packs were resident than the
     // device has places -- 1e5 reads, the toyset, stages 2a / 3a / 3b, every rank of an 8-GPU job, the re-run of a few packs):
@@ -3387,9 +3412,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // `sparse` = the shortest time per row for a pack that has (most of) a CU to itself: the skewed pipeline with ready-made
     // predecessor terms (4 bytes per cell of ring: four packs per CU at most, which is all a sparse pass has).
     int exp_pick[4] = {-1, -1, -1, -1};
-    if (getenv("RATTLE_POA_EXP")) sscanf(getenv("RATTLE_POA_EXP"), "%d,%d,%d,%d", &exp_pick[0], &exp_pick[1], &exp_pick[2], &exp_pick[3]);
+    if (ENV.exp) sscanf(ENV.exp, "%d,%d,%d,%d", &exp_pick[0], &exp_pick[1], &exp_pick[2], &exp_pick[3]);
     // tests / measurements: RATTLE_POA_MODE = dense | sparse | mt4 | mt2 | mt1 forces one form for the packed classes
-    const char *mode_s = getenv("RATTLE_POA_MODE");
+    const char *mode_s = ENV.mode;
     const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : mode_s[0] == 's' ? 2 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : !strcmp(mode_s, "mt4w") ? 6 : 0;
     uint32_t live_per_cu = 1, chain_per_cu = 1;    // packs per CU the pass about to start will keep resident (all classes; the long-chain groups)
     auto choose_variants = [&]() {
@@ -3426,7 +3451,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
     // The column classes of one pass run concurrently on their own streams.
     // (RATTLE_POA_BUDGET_MB: tests shrink the arena to exercise the skip path)
-    const uint64_t budget = getenv("RATTLE_POA_BUDGET_MB") ? (uint64_t)atoll(getenv("RATTLE_POA_BUDGET_MB")) << 20 : (uint64_t)(free_b * 0.85);
+    const uint64_t budget = ENV.budget_mb ? ENV.budget_mb << 20 : (uint64_t)(free_b * 0.85);
     // slot layout of class c for its current capacities; returns bytes per slot
     auto plan_class = [&](int c, uint64_t tb, uint32_t tl) {
         cls_plan &P = C[c];
@@ -3458,7 +3483,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         }
         A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
         P.per_slot = o;
-        A.debug = getenv("RATTLE_POA_DEBUG") ? (uint32_t)atoi(getenv("RATTLE_POA_DEBUG")) : 0u;
+        A.debug = ENV.debug;
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         A.ring_slots = A.ring_reach = A.ring_slack = 0;
         if (P.V->pk == 7) {
@@ -3475,7 +3500,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 if (slots >= slack + 6 || ppc == 1) break;
             }
             if (slots < slack + 2) { slots = slack + 2; }      // (the launch fails loudly if even that does not fit)
-            if (getenv("RATTLE_POA_MT_SLOTS")) slots = std::max<uint32_t>(slack + 2, (uint32_t)atoi(getenv("RATTLE_POA_MT_SLOTS")));      // tests: a short ring, to exercise the record path
+            if (ENV.mt_slots) slots = std::max<uint32_t>(slack + 2, ENV.mt_slots);      // tests: a short ring, to exercise the record path
             A.ring_slots = slots; A.ring_slack = slack; A.ring_reach = slots - slack;
         }
         auto lds_bytes = [&](const poa_variant *V) {
@@ -3508,7 +3533,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             std::sort(P.todo.begin(), P.todo.end(), [&](uint32_t a, uint32_t b) { return pbases[a] != pbases[b] ? pbases[a] > pbases[b] : a < b; });
             uint64_t tb = 0; uint32_t tl = 0;
             for (uint32_t p : P.todo) { tb = std::max(tb, pbases[p]); tl = std::max(tl, pmaxL[p]); }
-            if (P.rounds == 0 && !getenv("RATTLE_POA_NODE_CAP")) {
+            if (P.rounds == 0 && !ENV.node_cap) {
                 // first-pass capacity: a pack of ~200 reads at 10 % error grows to ~5 nodes per base of its
                 // longest read; packs that still outgrow it are re-run with 4x nodes
                 P.node_cap = std::max<uint32_t>(P.node_cap, (uint32_t)std::min<uint64_t>(7ull * tl, 1u << 20));
@@ -3609,7 +3634,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             A.timeline = tl_path ? d_tl.p : nullptr;
             aoff += P.per_slot * P.n_slots;
             qoff += (uint32_t)P.todo.size();
-            if (getenv("RATTLE_TIMING"))
+            if (ENV.timing)
                 fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, %s %u%s) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
                         poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : c >= 12 ? "(long chains) " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl,
                         P.V->pk == 7 ? "teams" : "ring", P.V->ring, P.V->pk == 7 ? (", ring " + std::to_string(A.ring_slots) + " reach " + std::to_string(A.ring_reach)).c_str() : "", pass, P.todo.size(), P.n_slots,
@@ -3640,7 +3665,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             // 12 when it is loaded before the runtime starts, so that every class gets a queue of its own; an application whose
             // runtime was already running with the default is dealt four streams)
             const int hwq = hw_queues();
-            const int n_streams = std::max(1, std::min(POA_GROUPS, getenv("RATTLE_POA_STREAMS") ? atoi(getenv("RATTLE_POA_STREAMS")) : hwq));
+            const int n_streams = std::max(1, std::min(POA_GROUPS, ENV.streams ? ENV.streams : hwq));
             double load[16] = {0};
             bool used[16] = {false};
             for (int i = 0; i < n_run && e == hipSuccess; ++i) {
@@ -3735,7 +3760,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     {
         // phase breakdown per column class (ticks of the 100 MHz wall clock, summed over the class's workgroups)
         static const char *names[8] = {"plan", "dp_rows", "ties", "traceback", "add_alignment", "merge_order", "final_sort_columns", "pack_total"};
-        FILE *jf = getenv("RATTLE_POA_PROFILE_JSON") ? fopen(getenv("RATTLE_POA_PROFILE_JSON"), "a") : nullptr;
+        FILE *jf = ENV.profile_json ? fopen(ENV.profile_json, "a") : nullptr;
         for (int c = 0; c < POA_CLASSES; ++c) {
             const unsigned long long *q = h_prof + 8 * c;
             if (!q[7]) continue;

@@ -589,6 +589,14 @@ uint64_t input_bytes(const std::vector<std::string> &files) {
     return tot;
 }
 
+// Every output is on disk and closed: what is left is giving back ~10 GB of host buffers, the mapped input and a ~100 GB device
+// arena, one by one -- 0.4-0.5 s of a seven-second `rattle correct` at 1e6 reads (round 4: the CLI was 1.28 x the library).  The
+// kernel reclaims a process's memory, host and device, faster than destructors do.
+[[noreturn]] static void done_exit() {
+    std::cout.flush(); std::cerr.flush(); fflush(nullptr);
+    _exit(EXIT_SUCCESS);
+}
+
 int mode_cluster(int argc, char **argv) {
     std::vector<opt_def> defs = {
         {"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"label", {"-l", "--label"}, true},
@@ -683,8 +691,7 @@ int mode_cluster(int argc, char **argv) {
             for (auto &s : c.seqs) s.seq_id = (int)order[s.seq_id];
         }
         write_clusters(gene, out_path);
-        team.close();
-        return EXIT_SUCCESS;
+        done_exit();
     }
     // main.cpp:281-323: second level per gene cluster with the iso parameters
     P.t_s = a.d("iso_t_s", 0.3); P.t_v = a.d("iso_t_v", 25);
@@ -719,8 +726,7 @@ int mode_cluster(int argc, char **argv) {
     std::cerr << "Isoform clustering done" << std::endl;
     std::cerr << iso.size() << " isoform clusters found" << std::endl;
     write_clusters(iso, out_path);
-    team.close();
-    return EXIT_SUCCESS;
+    done_exit();
 }
 
 int mode_correct(int argc, char **argv) {
@@ -850,7 +856,7 @@ int mode_correct(int argc, char **argv) {
     if (early.failed) { unlink(corrected_tmp.c_str()); die("Error: cannot write " + corrected_path); }
     if (early.done && rename(corrected_tmp.c_str(), corrected_path.c_str()) != 0) die("Error: cannot write " + corrected_path);
     t_lib.reset();
-    cli_timer t_out("format + write outputs");
+    std::unique_ptr<cli_timer> t_out(new cli_timer("format + write outputs"));
     read_set_t consensi;
     // consensus headers, correct.cpp:453-469,495-549: labels counted over the reads of the cluster's packs
     std::vector<std::vector<int>> label_counts(clusters.size(), std::vector<int>(labels.size(), 0));
@@ -908,10 +914,9 @@ int mode_correct(int argc, char **argv) {
               << (R->skipped.read_off[i + 1] - R->skipped.read_off[i]) << "\n";
         std::cerr << R->skipped.n << " pack(s) with " << R->counters[4] << " reads were not corrected (DP beyond the device or the budget): skipped_packs.tsv" << std::endl;
     }
-    rattle_hip_correction_free(R);
-    team.close();
+    t_out.reset();
     std::cerr << "Done" << std::endl;
-    return EXIT_SUCCESS;
+    done_exit();
 }
 
 std::string reverse_complement(const std::string &seq) {          // utils.cpp:15-24

@@ -16,51 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def _device_asm(src, tmp_path):
-    out = tmp_path / (os.path.basename(src) + ".s")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
-                           "-o", str(out), os.path.join(ROOT, "rattle_amd", "csrc", src)], stderr=subprocess.DEVNULL)
-    return out.read_text().splitlines()
-
-
-def _sgprs(line):
-    regs = set()
-    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", line):
-        regs.update(range(int(a), int(b) + 1))
-    regs.update(int(x) for x in re.findall(r"\bs(\d+)\b", line))
-    return regs
+import sys
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_asm
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_bv_filter_scalar_banks_are_not_touched_before_their_wait(tmp_path):
-    lines = [l.strip() for l in _device_asm("bv_filter.hip", tmp_path)]
-    loads = [i for i, l in enumerate(lines) if l.startswith("s_load_dwordx16")]
-    assert len(loads) >= 16                       # eight per strand variant of the kernel (+ the cross-seed prefetch): the hand-written loads are there
-    labels = {re.match(r"^(\.LBB\d+_\d+):", l).group(1): i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
-    for i in loads:
-        m = re.match(r"s_load_dwordx16 s\[(\d+):(\d+)\]", lines[i])
-        bank = set(range(int(m.group(1)), int(m.group(2)) + 1))
-        # every path from the load to the next full lgkmcnt(0) wait (the prefetch of the next seed's first eight dwords crosses
-        # the loop's back edge): follow fall-through and branch targets
-        todo, seen, waits = [i + 1], set(), 0
-        while todo:
-            j = todo.pop()
-            while j < len(lines) and j not in seen:
-                seen.add(j)
-                l = lines[j]
-                if not l or l.startswith((";", ".", "//")) or l.split(";")[0].strip().endswith(":"):
-                    j += 1
-                    continue
-                body = l.split(";")[0].strip()
-                if body.startswith("s_waitcnt") and "lgkmcnt(0)" in body:
-                    waits += 1
-                    break
-                assert not (bank & _sgprs(body)), f"line {j + 1}: `{l}` touches s[{min(bank)}:{max(bank)}] before the wait for its load (line {i + 1})"
-                assert not body.startswith(("s_setpc", "s_endpgm", "s_swappc")), f"line {j + 1}: the kernel may end before the load of line {i + 1} has landed"
-                t = re.match(r"(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", body)
-                if t:
-                    todo.append(labels[t.group(2)])
-                    if t.group(1) == "s_branch":
-                        break
-                j += 1
-        assert waits >= 1 and len(seen) < 400, f"the wait for the load of line {i + 1} is {len(seen)} instructions away"
+    """(the same check gates the library's build: rattle_amd/csrc/Makefile, bv_filter.o)"""
+    check_asm.check_bv_filter(check_asm.device_asm("bv_filter.hip", tmp_path))
