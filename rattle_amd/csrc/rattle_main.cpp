@@ -589,14 +589,10 @@ uint64_t input_bytes(const std::vector<std::string> &files) {
     return tot;
 }
 
-// Every output is on disk and closed: what is left is giving back ~10 GB of host buffers, the mapped input and a ~100 GB device
-// arena, one by one -- 0.4-0.5 s of a seven-second `rattle correct` at 1e6 reads (round 4: the CLI was 1.28 x the library).  The
-// kernel reclaims a process's memory, host and device, faster than destructors do.
-[[noreturn]] static void done_exit() {
-    std::cout.flush(); std::cerr.flush(); fflush(nullptr);
-    _exit(EXIT_SUCCESS);
-}
-
+// (Round 5 tried leaving through _exit() once every output is closed, instead of giving ~10 GB of host buffers and a ~100 GB device
+// arena back one by one: no gain -- the time outside the timers is process START, 0.5 s of library loading and HIP start-up -- and a
+// loss for the next process: the kernel reclaims the device memory of a process that just vanished in the background, and the
+// following `rattle correct` waited 1.1 s instead of 0.04 s for its arena, profiles/round5_cli_e2e_1M.txt.)
 int mode_cluster(int argc, char **argv) {
     std::vector<opt_def> defs = {
         {"help", {"-h", "--help"}, false}, {"input", {"-i", "--input"}, true}, {"label", {"-l", "--label"}, true},
@@ -691,7 +687,8 @@ int mode_cluster(int argc, char **argv) {
             for (auto &s : c.seqs) s.seq_id = (int)order[s.seq_id];
         }
         write_clusters(gene, out_path);
-        done_exit();
+            team.close();
+        return EXIT_SUCCESS;
     }
     // main.cpp:281-323: second level per gene cluster with the iso parameters
     P.t_s = a.d("iso_t_s", 0.3); P.t_v = a.d("iso_t_v", 25);
@@ -726,7 +723,8 @@ int mode_cluster(int argc, char **argv) {
     std::cerr << "Isoform clustering done" << std::endl;
     std::cerr << iso.size() << " isoform clusters found" << std::endl;
     write_clusters(iso, out_path);
-    done_exit();
+    team.close();
+    return EXIT_SUCCESS;
 }
 
 int mode_correct(int argc, char **argv) {
@@ -916,7 +914,9 @@ int mode_correct(int argc, char **argv) {
     }
     t_out.reset();
     std::cerr << "Done" << std::endl;
-    done_exit();
+    rattle_hip_correction_free(R);
+    team.close();
+    return EXIT_SUCCESS;
 }
 
 std::string reverse_complement(const std::string &seq) {          // utils.cpp:15-24

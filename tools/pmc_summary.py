@@ -34,6 +34,13 @@ if "SQ_WAVE_CYCLES" in poa and "SQ_ACTIVE_INST_VALU" in poa:
     res["valu_active_fraction_of_wave_cycles"] = poa["SQ_ACTIVE_INST_VALU"] / poa["SQ_WAVE_CYCLES"]
 if "SQ_WAVE_CYCLES" in poa and "SQ_WAIT_ANY" in poa:
     res["wait_any_fraction_of_wave_cycles"] = poa["SQ_WAIT_ANY"] / poa["SQ_WAVE_CYCLES"]
+# what the waves wait for: issue stalls on the LDS queue, the scalar unit's share, scalar memory instructions
+for name, num in (("lds_issue_stall_fraction_of_wave_cycles", "SQ_WAIT_INST_LDS"), ("scalar_active_fraction_of_wave_cycles", "SQ_ACTIVE_INST_SCA"),
+                  ("lds_active_fraction_of_wave_cycles", "SQ_ACTIVE_INST_LDS"), ("issue_stall_fraction_of_wave_cycles", "SQ_WAIT_INST_ANY")):
+    if num in poa and poa.get("SQ_WAVE_CYCLES"):
+        res[name] = poa[num] / poa["SQ_WAVE_CYCLES"]
+if "SQ_INSTS_SMEM" in poa:
+    res["smem_wave_instr_per_cell"] = poa["SQ_INSTS_SMEM"] / cells
 if "FETCH_SIZE" in poa and "WRITE_SIZE" in poa:
     res["hbm_fetch_bytes_per_cell_x2"] = 2 * 1024 * poa["FETCH_SIZE"] / cells
     res["hbm_write_bytes_per_cell"] = 1024 * poa["WRITE_SIZE"] / cells
