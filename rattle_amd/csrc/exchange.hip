@@ -261,9 +261,8 @@ namespace {
 
 template <typename T>
 void put(std::vector<uint8_t> &b, const T *p, size_t n) {
-    const size_t at = b.size();
-    b.resize(at + n * sizeof(T));
-    if (n) memcpy(b.data() + at, p, n * sizeof(T));
+    // (insert, not resize + memcpy: a resize zero-fills what the copy then overwrites -- 0.16 s of a rank's 250 MB piece at eight ranks)
+    if (n) b.insert(b.end(), (const uint8_t *)p, (const uint8_t *)p + n * sizeof(T));
 }
 template <typename T>
 const T *take(const uint8_t *b, size_t &at, size_t n) {
