@@ -214,7 +214,7 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
         phase_timer T("  stage: POA");
         // POA #2 / #3 align corrected reads / pack consensi: their graphs are almost chains -- rows that depend on each other
         // (teams of wavefronts gain nothing), and per alignment as much serial work as DP (what pays is many packs per CU)
-        ctx->poa_shallow_graphs = mode == 2;
+        ctx->poa_shallow_graphs = mode == 2 && !getenv("RATTLE_NO_SHALLOW_HINT");      // (the switch: A/B of the hint itself)
         struct unhint { rattle_ctx *c; ~unhint() { c->poa_shallow_graphs = 0; } } uh{ctx};
         RT_TRY(poa_device_run(ctx, S.seq.p, S.d_off.p, S.off.data(), n, S.first.data(), np, S.col.p, S.d_width.p, S.width.data(), h_cnt, &S.skipped));
     }

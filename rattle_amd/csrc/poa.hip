@@ -61,12 +61,6 @@ namespace rattle {
 #ifndef POA_RING_4x6
 #define POA_RING_4x6 4
 #endif
-#ifndef POA_SK_BLOCKS
-#define POA_SK_BLOCKS 7                    // skewed pipeline, record words in the ring: workgroups per CU the registers are budgeted for
-#endif
-#ifndef POA_SK_BLOCKS_RM
-#define POA_SK_BLOCKS_RM 4                 // ... ready-made terms in the ring (4 bytes per cell: LDS holds four 1024-column packs per CU)
-#endif
 #define POA_MAX_LEN (1u << 20)           // H <= 5 * length must stay far below 2^28 (POA_NEG)
 
 // node record (uint4): x = letter | n_al << 8 | n_in << 16, y = first in-edge's begin node,
@@ -1000,40 +994,11 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     multi = best > 0;
 }
 
-// ---- the packed row recurrence as a SKEWED PIPELINE of wavefronts (round 4; classes up to 2560 columns) -------------------
-// dp_rows_v3 ends every row with a block-wide rendezvous: all wavefronts write their prefix totals, `s_barrier`, all read them
-// back.  A pack that has the CU to itself then spends ~2400 cycles per row against ~700 of issue (round 3's verdict: the toyset,
-// config 2, every rank of an 8-GPU job, stages 2a / 3a / 3b and the POA #3 of the largest cluster all run like that), and even
-// with seven packs per CU the wavefronts wait 60 % of their cycles.
-//
-// Here no row ends in a barrier.  Wavefront w owns the columns [w * 64 * CPL, (w + 1) * 64 * CPL) of EVERY row and runs the rows
-// on its own clock; what couples it to its neighbours is a mailbox in LDS:
-//   * to finish row r it needs from wavefront w-1 the prefix maximum of u over all columns to its left (T) and, for the
-//     diagonal terms, the H of the column to its left (Hl) -- both are final as soon as w-1 is one row ahead;
-//   * wavefront w-1 publishes {T, Hl} of row r in slot r % SK_D of its mailbox and then the counter cnt = r (LDS operations of
-//     one wavefront complete in issue order, so a reader that sees cnt >= r sees the slot); a reader takes cnt first, the slot
-//     second;
-//   * the writer must not overwrite a slot the reader still needs: it waits (rarely) for the reader's own counter.
-// In the steady state wavefront w trails w-1 by a row or two and never waits; the time of a row is one wavefront's own path,
-// not the slowest wavefront's plus a rendezvous, and the waves of a pack are independent instruction streams for the SIMDs.
-//
-// FMT == 0: the ring holds the record words (as dp_rows_v3: 2 bytes per cell, decoded per reader).
-// FMT == 1: the ring holds the predecessor terms READY-MADE, two words per column pair: A = H[p][j-1] (the diagonal source,
-//   already shifted by a column: the producer shifts once, not every reader) and B = max(H[p][j] + g - e, F[p][j]) (so that
-//   F of the reader = max over predecessors of B, + e).  A reader then spends 2 instructions per pair and predecessor instead
-//   of 7-8 (2.18 in-edges per row: the predecessors were 40 % of the row's VALU work); 4 bytes per cell in LDS.
-// Rows older than the ring come from the record in HBM in both formats.
-#ifndef SK_D
-#define SK_D 12                                   // mailbox slots per wavefront (rows a producer may run ahead of its reader, plus the ring rows a reader still needs); 400 B per pack: 528 cost the record-word form its seventh pack per CU
-#endif
-template <int NW> struct sk_mail {
-    uint32_t cnt[NW];                             // cnt[w]: last row whose {T} wavefront w has published; n + 1: all its rows are final
-    int2 ent[NW][SK_D];                           // slot r % SK_D: {x: prefix max of u over columns 1 .. last column of w (both halves), y: H of its last column << 16}
-};
-// The mailbox is read and written through VOLATILE pointers (no access may be dropped, merged or moved across another) that carry
-// the LDS address space in their type: a volatile access through a generic pointer is not narrowed by the compiler and comes out as
+// ---- LDS words that several wavefronts poll (mailboxes, counters) -------------------------------------------------------------
+// They are read and written through VOLATILE pointers (no access may be dropped, merged or moved across another) that carry the LDS
+// address space in their type: a volatile access through a generic pointer is not narrowed by the compiler and comes out as
 // flat_load / flat_store with system-coherence bits and an s_waitcnt vmcnt(0) behind every store -- which waits for the record
-// stores of the row (a memory round trip per row: the first build of this kernel did exactly that).
+// stores of the row (a memory round trip per row: round 4's first pipeline kernel did exactly that).
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef volatile lds_u32 *sk_ptr;
 __device__ __forceinline__ uint32_t sk_ld(sk_ptr p) { return *p; }
@@ -1042,344 +1007,10 @@ __device__ __forceinline__ void sk_st(sk_ptr p, uint32_t v) { *p = v; }
 // its halves, so the 32-bit DPP scan works on it directly and the result is again a duplicated word
 __device__ __forceinline__ uint32_t wave_scan_max_dup(uint32_t v) { return (uint32_t)wave_scan_max_fused((int32_t)v); }
 
-template <int CPL, int RING, int NW, int FMT>
-__device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32_t Lp, int32_t &best, uint32_t &best_row, bool &multi) {
-    constexpr int NT = 64 * NW, NP = CPL / 2;
-    constexpr int RW = FMT ? 2 * NP : NP;         // ring dwords per thread and row
-    constexpr uint32_t D = SK_D, KEEP = FMT ? 0u : (uint32_t)RING;      // FMT 0: a reader takes the Hl of its ring predecessors from the mailbox
-    static_assert(RING > 0 && (uint32_t)RING + 2 <= D, "the mailbox outlives the ring");
-    constexpr bool RPOW2 = (RING & (RING - 1)) == 0;      // ring slot of a row: row & (RING - 1), or a counter carried from row to row (no division)
-    static_assert(NT * CPL <= 2560 && CPL % 2 == 0, "packed rows: u = Hn + g - (j+1)e must fit 16 bits");
-    __shared__ sk_mail<NW> M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t c0 = (uint32_t)tid * CPL;
-    const bool act = c0 < Lp;
-    uint32_t sw[(CPL + 3) / 4];                  // this thread's CPL sequence bytes
-    {
-        const uint16_t *sp = (const uint16_t *)(S.sq + (act ? c0 : 0));
-#pragma unroll
-        for (int u = 0; u < (CPL + 3) / 4; ++u) sw[u] = 0;
-#pragma unroll
-        for (int u = 0; u < CPL / 2; ++u) sw[u >> 1] |= (act ? (uint32_t)sp[u] : 0u) << (16 * (u & 1));
-    }
-    uint32_t SEL[NP];                            // score table selectors (see dp_rows_v3)
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const uint32_t ca = (sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu, cb = (sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu;
-        const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
-        const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
-        SEL[u] = sa | (sb << 16);
-    }
-    const bool plain = S.plain != 0;
-    s16x2 JE[NP], UC[NP];                        // per column: j*e and g - (j+1)*e
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const int j0 = (int)c0 + 2 * u + 1, j1 = j0 + 1;
-        const s16x2 je = {(short)(j0 * POA_E), (short)(j1 * POA_E)};
-        const s16x2 uc = {(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
-        JE[u] = je; UC[u] = act ? uc : pk_splat(-30000);      // threads beyond the row: u = Hn - 30000 < 0 < every valid u, no select before the scan
-    }
-    s16x2 MXA = pk_splat(0);                    // running maximum of this thread's columns over all rows (pairs)
-    const uint32_t n_act = min((uint32_t)NW, (Lp + 64u * CPL - 1u) / (64u * CPL));      // wavefronts that own columns of this sequence
-    const bool wave_act = (uint32_t)wave < n_act, has_left = wave > 0, has_right = (uint32_t)wave + 1u < n_act;
-    uint32_t *const ring_thr = S.ring + (size_t)tid * RW;              // slot s of this thread: ring_thr + s * NT * RW
-    uint32_t *const Hrec = (uint32_t *)S.H;                            // the record, a dword per column pair
-    const sk_ptr my_cnt = (sk_ptr)&M.cnt[wave], left_cnt = (sk_ptr)&M.cnt[has_left ? wave - 1 : 0], right_cnt = (sk_ptr)&M.cnt[has_right ? wave + 1 : 0];
-    const sk_ptr my_ent = (sk_ptr)&M.ent[wave][0], left_ent = (sk_ptr)&M.ent[has_left ? wave - 1 : 0][0];
-
-    if (tid < NW) M.cnt[tid] = 0;
-    // the plan through the scalar cache (see dp_rows_v3)
-    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc, ppd = (uint64_t)S.pland;
-    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc), "+s"(ppd) : : "memory");
-    const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc, cpd = (cplan_t)ppd;
-    __syncthreads();                             // the counters are zero before anybody looks at them
-
-    auto step = [&](const uint32_t row, const uint32_t rslot, const u32x4 pd) __attribute__((always_inline)) {
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));                      // lane tests are redone per row (see dp_rows_v3)
-        // the compact plan record (see dp_rows_v3): letter, in-degree (capped at 255), the distances to the first eight predecessor rows
-        const uint32_t letter = pd.x & 0xFFu, n_in = (pd.x >> 8) & 0xFFu;
-        uint32_t dist[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { dist[k] = (pd.y >> (8 * k)) & 0xFFu; dist[4 + k] = (pd.z >> (8 * k)) & 0xFFu; }
-        const uint32_t mslot = row % D;
-        // ---- what the neighbours say (requested first, looked at when needed) ----
-        uint32_t cl = 0, cr = 0, leT = 0, leH = 0;
-        if (has_left) { cl = sk_ld(left_cnt); leT = sk_ld(left_ent + 2 * mslot); leH = sk_ld(left_ent + 2 * mslot + 1); }
-        if (has_right) cr = sk_ld(right_cnt);
-        auto wait_left = [&](const uint32_t need) __attribute__((always_inline)) {
-            cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)cl);
-            while ((int32_t)(cl - need) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sk_ld(left_cnt));
-                leT = sk_ld(left_ent + 2 * mslot); leH = sk_ld(left_ent + 2 * mslot + 1);
-            }
-        };
-        // FMT 0 reads the Hl of its ring predecessors (row - 1 among them) from the left mailbox: the left wavefront must have
-        // published row `row` (its row - 1 is then final).  FMT 1 needs the left wavefront only when the prefix is combined.
-        if (FMT == 0 && has_left) wait_left(row);
-        s16x2 HM[NP], FM[NP];                    // maxima over the predecessors: H[p][j-1] and max(H[p][j] + g - e, F[p][j])
-        uint32_t raw[4][RW], rawl[4];
-        // k: which of the four fetch slots; kp: which in-edge (0..7: the plan holds its row; 8: `far_row` is given)
-        auto fetch = [&](const int k, const int kp, const uint32_t d, const uint32_t far_row) __attribute__((always_inline)) {
-            if (d <= (uint32_t)RING) {
-                const uint32_t prow = row - d;
-                uint32_t slot;
-                if constexpr (RPOW2) slot = prow & (uint32_t)(RING - 1);
-                else { const int32_t t = (int32_t)rslot - (int32_t)d; slot = (uint32_t)(t + ((t >> 31) & RING)); }
-                const uint32_t *rp = ring_thr + slot * (uint32_t)(NT * RW);
-                if constexpr (RW == 2) { const uint2 a2 = *(const uint2 *)rp; raw[k][0] = a2.x; raw[k][1] = a2.y; }
-                else if constexpr (RW == 4) { const uint4 a4 = *(const uint4 *)rp; raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; }
-                else if constexpr (RW == 8) {
-                    const uint4 a4 = *(const uint4 *)rp, b4 = *(const uint4 *)(rp + 4);
-                    raw[k][0] = a4.x; raw[k][1] = a4.y; raw[k][2] = a4.z; raw[k][3] = a4.w; raw[k][4] = b4.x; raw[k][5] = b4.y; raw[k][6] = b4.z; raw[k][7] = b4.w;
-                } else if constexpr (RW % 2 == 0) {
-#pragma unroll
-                    for (int u = 0; u < RW / 2; ++u) { const uint2 a2 = ((const uint2 *)rp)[u]; raw[k][2 * u] = a2.x; raw[k][2 * u + 1] = a2.y; }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < RW; ++u) raw[k][u] = rp[u];
-                }
-                rawl[k] = 0;
-                if (FMT == 0 && has_left) rawl[k] = sk_ld(left_ent + 2 * (prow % D) + 1);
-            } else {
-                // beyond the ring (a few per cent of the fetches): the record words from HBM, decoded into the ring's format; the row
-                // itself from the full plan (the distance byte may be saturated)
-                uint32_t prow = kp >= 8 ? far_row : kp >= 4 ? cpc[row - 1][kp - 4] : cpb[row - 1][kp];
-                // the scalar load lands HERE: left pending to the end of this (rare) branch, the compiler waits lgkmcnt(0) before the
-                // next predecessor's ring address on the common path too (same scalar register) -- which serialised the LDS reads of
-                // a row's predecessors
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(prow));
-                // (no divergent control flow in here: see dp_rows_v3)
-                uint32_t w[NP];
-                const uint32_t cc = act ? c0 : 0u;
-                const uint32_t *hq = (const uint32_t *)(S.H + (uint64_t)prow * Lp + cc);
-                const bool need_left = lane == 0 && wave > 0 && act;
-                const uint32_t hl16 = ((const uint16_t *)hq)[need_left ? -1 : 0];
-#pragma unroll
-                for (int u = 0; u < NP; ++u) { const uint32_t x = hq[u]; w[u] = act ? x : 0x80008000u; }      // H = 0, H - F = 2: what a column beyond the row decodes to
-                const uint32_t wl = need_left ? (hl16 & 0x3FFFu) << 16 : 0u;
-                drain_vector_loads();            // rare path: nothing stays pending past it
-                if constexpr (FMT == 0) {
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) raw[k][u] = w[u];
-                    rawl[k] = wl;
-                } else {
-                    uint32_t hp[NP];
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) {
-                        hp[u] = w[u] & 0x3FFF3FFFu;
-                        u16x2 wu;
-                        __builtin_memcpy(&wu, &w[u], 4);
-                        const u16x2 d = __builtin_elementwise_min(wu >> (u16x2){14, 14}, (u16x2){2, 2});
-                        s16x2 ds;
-                        __builtin_memcpy(&ds, &d, 4);
-                        raw[k][NP + u] = as_u(as_pk(hp[u]) - ds);                                  // B = H - min(H - F, 2)
-                    }
-                    const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) raw[k][u] = as_u(pk_left(hp[u], u == 0 ? left : hp[u - 1]));      // A = H shifted by a column
-                    rawl[k] = 0;
-                }
-            }
-        };
-        auto combine = [&](auto first_tag, const uint32_t (&w)[RW], const uint32_t wl) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            if constexpr (FMT == 1) {
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    HM[u] = FIRST ? as_pk(w[u]) : pk_max(HM[u], as_pk(w[u]));
-                    FM[u] = FIRST ? as_pk(w[NP + u]) : pk_max(FM[u], as_pk(w[NP + u]));
-                }
-            } else {
-                uint32_t hp[NP];
-                s16x2 FD[NP];
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    hp[u] = w[u] & 0x3FFF3FFFu;
-                    u16x2 wu;
-                    __builtin_memcpy(&wu, &w[u], 4);
-                    const u16x2 d = __builtin_elementwise_min(wu >> (u16x2){14, 14}, (u16x2){2, 2});      // min(H - F, 2)
-                    s16x2 ds;
-                    __builtin_memcpy(&ds, &d, 4);
-                    FD[u] = as_pk(hp[u]) - ds;                                                            // max(H + g - e, F)
-                }
-                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    const s16x2 HD = pk_left(hp[u], u == 0 ? left : hp[u - 1]);
-                    HM[u] = FIRST ? HD : pk_max(HM[u], HD);
-                    FM[u] = FIRST ? FD[u] : pk_max(FM[u], FD[u]);
-                }
-            }
-        };
-        if (n_in == 0) {                         // virtual start row: H = 0, F = -inf
-#pragma unroll
-            for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
-        } else {
-            fetch(0, 0, dist[0], 0);
-            if (n_in > 1) fetch(1, 1, dist[1], 0);
-            if (n_in > 2) fetch(2, 2, dist[2], 0);
-            if (n_in > 3) fetch(3, 3, dist[3], 0);
-            combine(std::true_type{}, raw[0], rawl[0]);
-            if (n_in > 1) combine(std::false_type{}, raw[1], rawl[1]);
-            if (n_in > 2) combine(std::false_type{}, raw[2], rawl[2]);
-            if (n_in > 3) {
-                combine(std::false_type{}, raw[3], rawl[3]);
-                if (n_in > 4) {
-                    fetch(0, 4, dist[4], 0);
-                    if (n_in > 5) fetch(1, 5, dist[5], 0);
-                    if (n_in > 6) fetch(2, 6, dist[6], 0);
-                    if (n_in > 7) fetch(3, 7, dist[7], 0);
-                    combine(std::false_type{}, raw[0], rawl[0]);
-                    if (n_in > 5) combine(std::false_type{}, raw[1], rawl[1]);
-                    if (n_in > 6) combine(std::false_type{}, raw[2], rawl[2]);
-                    if (n_in > 7) combine(std::false_type{}, raw[3], rawl[3]);
-                    if (n_in > 8) {
-                        uint32_t e = pd.w;
-                        const uint32_t n_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)rd_nin(cpa[row - 1].x));         // the record's count stops at 255
-                        for (uint32_t k = 8; k < n_all; ++k) {
-                            const uint2 ed = S.edges[e]; e = ed.y;
-                            const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
-                            drain_vector_loads();
-                            fetch(0, 8, row - prow, prow);
-                            combine(std::false_type{}, raw[0], rawl[0]);
-                        }
-                    }
-                }
-            }
-        }
-        // Hn = max(diagonal, F, 0); u = Hn + g - (j+1)e; in-thread exclusive prefix max of u (pair by pair)
-        s16x2 HNp[NP], EX[NP], SC[NP], FN[NP];
-        s16x2 RUN = pk_splat(-32768);
-        if (plain) {
-            const uint32_t li = (letter >> 1) & 3u;
-            const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));      // low / high bytes of {-4, -4, -4, -4} with 5 at li
-#pragma unroll
-            for (int u = 0; u < NP; ++u) SC[u] = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
-        } else {
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const int32_t s0 = ((sw[(2 * u) >> 2] >> (8 * ((2 * u) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-                const int32_t s1 = ((sw[(2 * u + 1) >> 2] >> (8 * ((2 * u + 1) & 3))) & 0xFFu) == letter ? POA_M : POA_N;
-                SC[u] = as_pk(pack16(s0, s1));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            FN[u] = FM[u] + pk_splat(POA_E);
-            HNp[u] = pk_max(pk_max(HM[u] + SC[u], FN[u]), pk_splat(0));
-            const s16x2 v = pk_max(RUN, HNp[u] + UC[u]);                                   // (max(run, u_a), max(run, u_b))
-            EX[u] = as_pk(__builtin_amdgcn_alignbit(as_u(v), as_u(RUN), 16));              // (run, max(run, u_a)): both halves of RUN are equal
-            RUN = pk_max(v, __builtin_shufflevector(v, v, 1, 0));                          // max(run, u_a, u_b) in both halves
-        }
-        // the scan runs on the duplicated word itself: no extraction before, no packing after
-        const uint32_t wincl = wave_scan_max_dup(as_u(RUN));
-        const uint32_t texcl = (uint32_t)wave_shr1((int32_t)wincl, (int32_t)0x80008000u);
-        // ---- the prefix over the wavefronts to the left, and ours to the right ----
-        uint32_t sbase = as_u(pk_splat(POA_G - POA_E));        // u_0
-        uint32_t hl = 0;
-        if (has_left) {
-            if (FMT == 1) wait_left(row + 1);
-            const uint32_t Tl = (uint32_t)__builtin_amdgcn_readfirstlane((int)leT);
-            hl = (uint32_t)__builtin_amdgcn_readfirstlane((int)leH);
-            sbase = (uint32_t)max((int32_t)sbase, (int32_t)Tl);
-        }
-        uint32_t sbase_pub = 0;
-        if (has_right) {
-            const uint32_t tc = (uint32_t)max((int32_t)sbase, __builtin_amdgcn_readlane((int32_t)wincl, 63));
-            cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)cr);
-            while ((int32_t)(cr + (D - KEEP) - row) < 0) {         // the slot still holds row - D, which the reader may need until it has published row - D + KEEP
-                __builtin_amdgcn_s_sleep(1);
-                cr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sk_ld(right_cnt));
-            }
-            sbase_pub = tc;
-        }
-        // the counter says two things: to the right, "my prefix of this row is in its slot (and every earlier row of mine is
-        // final)"; to the left, "I have taken your slot of this row" -- so the LAST wavefront keeps it too (its left
-        // neighbour's back-pressure reads it).  One lane, one predicate for both writes.
-        if (n_act > 1 && lane_o == 0) {
-            if (has_right) sk_st(my_ent + 2 * mslot, sbase_pub);
-            sk_st(my_cnt, row);
-        }
-        const s16x2 BASE = pk_max(as_pk(texcl), as_pk(sbase));
-        uint32_t W[NP];
-        s16x2 HN[NP];
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const s16x2 EV = pk_max(BASE, EX[u]) + JE[u];
-            HN[u] = pk_max(HNp[u], EV);
-            MXA = pk_max(MXA, HN[u]);
-            // H (14 bits) | min(H - F, 3) << 14: the record word (traceback, rows beyond the ring), shift and or in one instruction
-            asm("v_lshl_or_b32 %0, %1, 14, %2" : "=v"(W[u]) : "v"(as_u(pk_min(HN[u] - FN[u], pk_splat(3)))), "v"(as_u(HN[u])));
-        }
-        {
-            uint32_t *rp = ring_thr + rslot * (uint32_t)(NT * RW);
-            uint32_t R[RW];
-            if constexpr (FMT == 1) {
-                const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HN[NP - 1]), (int32_t)hl);       // lane 0: the H the left wavefront published
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    R[u] = as_u(pk_left(as_u(HN[u]), u == 0 ? left : as_u(HN[u - 1])));
-                    R[NP + u] = as_u(pk_max(HN[u] - pk_splat(2), FN[u]));
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < NP; ++u) R[u] = W[u];
-            }
-            if constexpr (RW == 2) *(uint2 *)rp = make_uint2(R[0], R[1]);
-            else if constexpr (RW == 4) *(uint4 *)rp = make_uint4(R[0], R[1], R[2], R[3]);
-            else if constexpr (RW == 8) { *(uint4 *)rp = make_uint4(R[0], R[1], R[2], R[3]); *(uint4 *)(rp + 4) = make_uint4(R[4], R[5], R[6], R[7]); }
-            else if constexpr (RW % 2 == 0) {
-#pragma unroll
-                for (int u = 0; u < RW / 2; ++u) ((uint2 *)rp)[u] = make_uint2(R[2 * u], R[2 * u + 1]);
-            } else {
-#pragma unroll
-                for (int u = 0; u < RW; ++u) rp[u] = R[u];
-            }
-            if (has_right && lane_o == 63) sk_st(my_ent + 2 * mslot + 1, as_u(HN[NP - 1]));      // the high half is the H of this wavefront's last column
-            if (act) {
-                uint32_t *hq = Hrec + ((uint64_t)row * Lp >> 1) + (c0 >> 1);
-                if (NP % 2 == 0) {
-#pragma unroll
-                    for (int u = 0; u < NP / 2; ++u) ((uint2 *)hq)[u] = make_uint2(W[2 * u], W[2 * u + 1]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < NP; ++u) hq[u] = W[u];
-                }
-            }
-        }
-    };
-
-    if (wave_act) {
-        u32x4 nd = cpd[0];                               // plan record of the next row, one row ahead
-        uint32_t rslot = 1u % (uint32_t)RING;            // ring slot of the current row
-        for (uint32_t row = 1; row <= n; ++row) {
-            const u32x4 pd = nd;
-            if (row < n) nd = cpd[row];
-            step(row, RPOW2 ? (row & (uint32_t)(RING - 1)) : rslot, pd);
-            rslot = rslot + 1u == (uint32_t)RING ? 0u : rslot + 1u;
-        }
-        if (n_act > 1 && lane == 0) sk_st(my_cnt, n + 1);          // every row of this wavefront is final (its last Hl is in the mailbox)
-    }
-    // block-wide best score and the threads whose columns reach it (the first row that reaches it comes from a rescan of
-    // those threads' columns in the record, kernel body)
-    const int32_t lbest = act ? max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16) : 0;
-    const int32_t wb = wave_last(wave_scan_max(lbest, 0));
-    if (lane == 0) X.best[wave] = wb;
-    if (tid == 0) { X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
-    __syncthreads();
-    best = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) best = max(best, X.best[w]);
-    if (best > 0 && lbest == best) {
-        const uint32_t slot = atomicAdd(&X.ntl, 1u);
-        if (slot < 16) X.tl[slot] = (uint32_t)tid;
-    }
-    __syncthreads();
-    best_row = 0;
-    multi = best > 0;
-}
+// (Round 4's skewed wavefront pipeline, dp_rows_sk -- no barrier per row, wavefronts coupled by an LDS mailbox, record words or
+// ready-made terms in the ring -- was the under-filled device's form for one round.  The one-team instance of dp_rows_mt below is
+// the same pipeline with the lean row and matches or beats it at every load measured (profiles/round5_forms_by_load.txt); it was
+// removed in round 5 with its experiment table.)
 
 // ---- the packed row recurrence on TEAMS of wavefronts (round 5; classes up to 2560 columns, under-filled device) ------------
 // Round 4's finding: a pack that has (most of) a CU to itself is bound by ONE wavefront's instruction stream -- ~240 instructions
@@ -1395,7 +1026,7 @@ __device__ void dp_rows_sk(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
 //         <= x is final" is min over t' of done[w][t'] + T > x -- ONE 16-byte LDS read and one comparison with a number the plan
 //         carries (the largest predecessor row, or row - slack: that also makes the ring slot a row overwrites dead);
 //       * the wavefront to its left of the SAME team for the prefix maximum and the H of its last column (a mailbox of MT_MD
-//         entries per wavefront, back-pressure on the right neighbour's done counter, as in dp_rows_sk).
+//         entries per wavefront, back-pressure on the right neighbour's done counter).
 //     All waits are for smaller rows, or the same row in a smaller block: no cycles (simulated on host threads,
 //     tests/stubs/mt_protocol_sim.cpp).
 // (2) The row is on a scalar diet.  The plan record of a row is 32 bytes (one s_load_dwordx8, fetched a row
@@ -2433,10 +2064,9 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 
 // PK: 0 = 32-bit registers + int16 record + nibbles (dp_rows), 1 = packed int16 pairs, record word H | min(H-F,3) << 14 (dp_rows_v3),
 // 2 = int32 segments (dp_rows_long / _longr), 3 = 32-bit cells on up to 16 wavefronts (dp_rows_wide),
-// 5 / 6 = the packed record of PK 1 written by the skewed wavefront pipeline (dp_rows_sk), ring format 0 (record words) / 1 (ready-made terms)
 // 7 = the same record written by teams of wavefronts (dp_rows_mt): the RING template argument is the number of TEAMS, the ring is sized at launch
-__host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 5 || PK == 6 || PK == 7; }
-__host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 6 || PK == 7; }
+__host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 7; }
+__host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 7; }
 __host__ __device__ constexpr int pk_teams(int RING, int PK) { return PK == 7 ? RING : 1; }
 __host__ __device__ constexpr uint32_t mt_slot_bytes(int CPL, int NW) { return 64u * NW * CPL * 4u; }      // one ring slot of dp_rows_mt: 4 bytes per cell
 // dwords of LDS ring per thread and row; bytes of the ring (+ the left-column values of the barrier forms); bytes of the LDS behind
@@ -2452,7 +2082,7 @@ __host__ __device__ constexpr uint32_t poa_region_bytes(uint32_t node_cap, int C
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
 constexpr int poa_min_waves(int CPL, int NW, int PK, int RING_OR_T = 1) {
-    return PK == 7 ? (RING_OR_T == 2 && CPL == 4 ? MT2_MINWAVES : 4) : PK == 5 || PK == 6 ? (((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4 > 8 ? 8 : ((PK == 6 ? POA_SK_BLOCKS_RM : POA_SK_BLOCKS) * NW + 3) / 4)
+    return PK == 7 ? (RING_OR_T == 2 && CPL == 4 ? MT2_MINWAVES : 4)
          : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : 1;
 }
 template <int CPL, int RING, int NW, int PK>
@@ -2622,7 +2252,6 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                 else if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 3) dp_rows_wide<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 7) dp_rows_mt<CPL, NW, RING>(S, X, A, n, L, Lp, best, best_row, multi);
-                else if constexpr (PK == 5 || PK == 6) dp_rows_sk<CPL, RING, NW, PK == 6 ? 1 : 0>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 cells += (unsigned long long)n * L;
@@ -3259,39 +2888,19 @@ static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 
 static const poa_variant k_long_noring = POA_VARIANT(8, 0, 16, 2);      // ... row-major segments without a ring when the graph's bitmaps leave no LDS for it
 static const poa_variant k_noring[3] = {POA_VARIANT(16, 0, 4, 0), POA_VARIANT(24, 0, 4, 0), POA_VARIANT(32, 0, 4, 0)};      // when the ring no longer fits LDS (huge graphs)
 // the packed classes (up to 2560 columns), by load: see choose_variants in poa_device_run
-#ifndef POA_SPARSE_PACKS_PER_CU
-#define POA_SPARSE_PACKS_PER_CU 4
-#endif
 static const poa_variant k_dense[4] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1)};
-// (measured, one pack per CU, 200 reads of 1 kb / 1.45 kb: barrier form 661 / 1293 ms; skewed pipeline with ready-made terms on four
-// wavefronts 607 / 990 ms, on eight wavefronts 651 / 1046 ms, on ONE wavefront of 16 / 24 columns per lane (no mailbox at all)
-// 759 / 1333 ms -- a wavefront's own row is what a lone pack waits for: more wavefronts do not shorten it, fewer lengthen it)
-static const poa_variant k_sparse[4] = {POA_VARIANT(4, 8, 4, 6), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(10, 8, 4, 6)};
 // teams of wavefronts (dp_rows_mt; the second argument is the number of TEAMS, the ring is sized at launch): four teams for a pack
-// that has a CU to itself, two when two or three packs share one, one = the lean skewed pipeline
+// that has a CU to itself, two when up to four or five packs share one; one team = the lean skewed pipeline (tests, measurements)
 static const poa_variant k_mt4[4] = {POA_VARIANT(4, 4, 4, 7), POA_VARIANT(6, 4, 4, 7), POA_VARIANT(8, 4, 4, 7), POA_VARIANT(10, 4, 4, 7)};
 static const poa_variant k_mt2[4] = {POA_VARIANT(4, 2, 4, 7), POA_VARIANT(6, 2, 4, 7), POA_VARIANT(8, 2, 4, 7), POA_VARIANT(10, 2, 4, 7)};
-static const poa_variant k_mt4w = POA_VARIANT(8, 4, 2, 7);      // (measurement) 1024 columns as two column blocks of 8 columns per lane: fewer instructions per cell, eight wavefronts
 static const poa_variant k_mt1[4] = {POA_VARIANT(4, 1, 4, 7), POA_VARIANT(6, 1, 4, 7), POA_VARIANT(8, 1, 4, 7), POA_VARIANT(10, 1, 4, 7)};
-// experiments (RATTLE_POA_EXP=<a>,<b>,<c>,<d>: index into the candidate table of the 1024- / 1536- / 2048- / 2560-column class; -1 or
-// absent: the default): the skewed wavefront pipeline (dp_rows_sk) with the record words (PK 5) or the ready-made terms (PK 6) in
-// its ring, on 2 / 4 / 8 wavefronts
-#define POA_EXP_MAX 6
-#ifdef POA_EXPERIMENTS
-static const poa_variant k_exp[4][POA_EXP_MAX] = {
-    {POA_VARIANT(4, 8, 4, 5), POA_VARIANT(4, 8, 4, 6), POA_VARIANT(4, 4, 4, 6), POA_VARIANT(2, 8, 8, 6), POA_VARIANT(2, 8, 8, 5), POA_VARIANT(8, 8, 2, 6)},
-    {POA_VARIANT(6, 4, 4, 5), POA_VARIANT(6, 8, 4, 6), POA_VARIANT(6, 4, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(6, 8, 4, 5), POA_VARIANT(6, 6, 4, 6)},
-    {POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 6), POA_VARIANT(4, 8, 8, 6), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5), POA_VARIANT(8, 8, 4, 5)},
-    {POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 6), POA_VARIANT(10, 4, 4, 6), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5), POA_VARIANT(10, 8, 4, 5)}};
-#endif
 
 // Every switch kernel C's host side takes from the environment (tests and measurements only; read once per call, so a test may change
 // them between calls): one place, one struct.
 struct poa_env {
     const char *timeline = nullptr;      // RATTLE_POA_TIMELINE=<file>: when each pack's workgroup started and finished it
-    const char *mode = nullptr;          // RATTLE_POA_MODE = dense | sparse | mt4 | mt2 | mt1 | mt4w: one form of the row loop for the packed classes
+    const char *mode = nullptr;          // RATTLE_POA_MODE = dense | mt4 | mt2 | mt1: one form of the row loop for the packed classes
     const char *profile_json = nullptr;  // RATTLE_POA_PROFILE_JSON=<file> (POA_PROFILE builds): phase shares per class
-    const char *exp = nullptr;           // RATTLE_POA_EXP (POA_EXPERIMENTS builds): index into the candidate table per class
     uint32_t node_cap = 0;               // RATTLE_POA_NODE_CAP: first-pass node capacity (tests lower it to force re-runs)
     uint64_t budget_mb = 0;              // RATTLE_POA_BUDGET_MB: arena budget (tests shrink it to exercise the skip path)
     uint32_t debug = 0;                  // RATTLE_POA_DEBUG: bit 0 full sort for ties, bit 1 traceback without the LDS chain, bit 2 ... without jump tables
@@ -3299,7 +2908,7 @@ struct poa_env {
     int streams = 0;                     // RATTLE_POA_STREAMS: streams the classes of a pass are dealt onto
     bool timing = false;                 // RATTLE_TIMING: one line per class and pass
     poa_env() {
-        timeline = getenv("RATTLE_POA_TIMELINE"); mode = getenv("RATTLE_POA_MODE"); profile_json = getenv("RATTLE_POA_PROFILE_JSON"); exp = getenv("RATTLE_POA_EXP");
+        timeline = getenv("RATTLE_POA_TIMELINE"); mode = getenv("RATTLE_POA_MODE"); profile_json = getenv("RATTLE_POA_PROFILE_JSON");
         if (const char *v = getenv("RATTLE_POA_NODE_CAP")) node_cap = (uint32_t)std::max(64, atoi(v));
         if (const char *v = getenv("RATTLE_POA_BUDGET_MB")) budget_mb = (uint64_t)atoll(v);
         if (const char *v = getenv("RATTLE_POA_DEBUG")) debug = (uint32_t)atoi(v);
@@ -3408,14 +3017,11 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // The kernel of a class is chosen per PASS from how full the device will be (round 3's verdict: one wavefront / column split
     // per class, chosen by read length only, collapsed to 0.08 of the issue roofline whenever fewer packs were resident than the
     // device has places -- 1e5 reads, the toyset, stages 2a / 3a / 3b, every rank of an 8-GPU job, the re-run of a few packs):
-    // `dense` = the form that keeps the most packs resident (seven or eight per CU: record words in the ring, 2 bytes per cell);
-    // `sparse` = the shortest time per row for a pack that has (most of) a CU to itself: the skewed pipeline with ready-made
-    // predecessor terms (4 bytes per cell of ring: four packs per CU at most, which is all a sparse pass has).
-    int exp_pick[4] = {-1, -1, -1, -1};
-    if (ENV.exp) sscanf(ENV.exp, "%d,%d,%d,%d", &exp_pick[0], &exp_pick[1], &exp_pick[2], &exp_pick[3]);
-    // tests / measurements: RATTLE_POA_MODE = dense | sparse | mt4 | mt2 | mt1 forces one form for the packed classes
+    // the barrier form keeps the most packs resident (seven or eight per CU: record words in the ring, 2 bytes per cell); the teams of
+    // wavefronts give a pack that has (most of) a CU to itself the shortest row there is (dp_rows_mt).
+    // tests / measurements: RATTLE_POA_MODE = dense | mt4 | mt2 | mt1 forces one form for the packed classes
     const char *mode_s = ENV.mode;
-    const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : mode_s[0] == 's' ? 2 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : !strcmp(mode_s, "mt4w") ? 6 : 0;
+    const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : 0;
     uint32_t live_per_cu = 1, chain_per_cu = 1;    // packs per CU the pass about to start will keep resident (all classes; the long-chain groups)
     auto choose_variants = [&]() {
         uint64_t live = 0, chains = 0;
@@ -3423,13 +3029,13 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         for (int c = 12; c < POA_GROUPS; ++c) chains += C[c].todo.size();
         live_per_cu = (uint32_t)std::max<uint64_t>(1, (live + n_cu - 1) / n_cu);
         chain_per_cu = (uint32_t)std::max<uint64_t>(1, (chains + n_cu - 1) / n_cu);
-        // by packs per CU: one -> four teams per pack (16 wavefronts: the CU is the pack's); two or three -> two teams; four -> the skewed
-        // pipeline with ready-made terms (LDS holds four such rings); more -> the barrier form with record words (seven or eight per CU)
-        // (in eighths of a pack per CU: 829 packs on 256 CUs are 3.2 per CU -- two teams at three per CU with a short queue, not the next form up)
+        // by packs per CU: about one -> four teams per pack (16 wavefronts: the CU is the pack's); up to four and a half -> two teams (two or
+        // three packs per CU and a short queue); more -> the barrier form with record words (seven or eight per CU)
+        // (in eighths of a pack per CU: 829 packs on 256 CUs are 3.2 per CU)
         const uint64_t l8 = live * 8 / n_cu;
         // measured (profiles/round5_forms_by_load.txt; 1024- / 1536-column class, GCUPS): one pack per CU -- four teams 303 / 494, two
-        // teams 313 / 463; two per CU -- two teams 557 / 750; three -- two teams 680 / 624 (a short queue), one team 544 / 697, pipeline
-        // 498 / 454, barrier form 441 / 529; four -- one team 631, pipeline 635 / 569, barrier 569 / 649; five and more: the barrier form
+        // teams 313 / 463; two per CU -- two teams 557 / 750; three -- two teams 680 / 624 (a short queue), one team 544 / 697, round 4's
+        // pipeline 498 / 454, barrier form 441 / 529; four -- one team 631, pipeline 635 / 569, barrier 569 / 649; five and more: the barrier form
         int mode = force_mode ? force_mode : l8 <= 10 ? 3 : l8 <= 36 ? 4 : 1;
         // near-chain graphs (POA #2 / #3, the caller says so): no row parallelism to find, and per alignment as much serial work as DP --
         // beyond two packs per CU the barrier form with everything resident wins (measured in the rank replay at 1e6 reads: 833 such
@@ -3440,12 +3046,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         for (int c = 0; c < POA_GROUPS; ++c) {
             C[c].V = &k_latency[poa_group_class(c)];
             if (c < 4) {
-                C[c].V = mode == 1 ? &k_dense[c] : mode == 2 ? &k_sparse[c] : mode == 3 ? &k_mt4[c] : mode == 4 ? &k_mt2[c] : mode == 6 ? (c == 0 ? &k_mt4w : &k_mt4[c]) : &k_mt1[c];
-#ifdef POA_EXPERIMENTS
-                if (exp_pick[c] >= 0 && exp_pick[c] < POA_EXP_MAX) C[c].V = &k_exp[c][exp_pick[c]];
-#endif
+                C[c].V = mode == 1 ? &k_dense[c] : mode == 3 ? &k_mt4[c] : mode == 4 ? &k_mt2[c] : &k_mt1[c];
             }
-            if (c >= 12) { const int gc = c - 12; C[c].V = force_mode == 1 ? &k_dense[gc] : force_mode == 2 ? &k_sparse[gc] : chain_mode == 3 ? &k_mt4[gc] : chain_mode == 4 ? &k_mt2[gc] : &k_mt1[gc]; }
+            if (c >= 12) { const int gc = c - 12; C[c].V = force_mode == 1 ? &k_dense[gc] : chain_mode == 3 ? &k_mt4[gc] : chain_mode == 4 ? &k_mt2[gc] : &k_mt1[gc]; }
         }
     };
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.

@@ -280,7 +280,7 @@ def test_correct_outputs_do_not_depend_on_scheduling(gpu_ctx, monkeypatch):
 
     base = run()
     variants = [{"RATTLE_POA_STREAMS": "1"}, {"RATTLE_POA_STREAMS": "12"}, {"RATTLE_BIG_CLUSTER_PACKS": "3", "RATTLE_BIG_MIN_PACKS": "0"},
-                {"RATTLE_POA_MODE": "sparse"}, {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_STREAMS": "2"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
+                {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_STREAMS": "2"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
                 {"RATTLE_POA_MODE": "dense"}]
     for env in variants:
         for k, v in env.items():

@@ -97,7 +97,7 @@ def test_length_classes_match_oracle(gpu_ctx, oracle, length, depth):
         assert got == want
 
 
-@pytest.mark.parametrize("mode", ["dense", "sparse", "mt4", "mt2", "mt1"])
+@pytest.mark.parametrize("mode", ["dense", "mt4", "mt2", "mt1"])
 @pytest.mark.parametrize("length,depth", [(700, 40), (1300, 30), (1800, 25), (2300, 20)])
 def test_packed_classes_in_every_form_of_the_row_loop(gpu_ctx, oracle, monkeypatch, length, depth, mode):
     """The four packed column classes under every form of the row loop (RATTLE_POA_MODE): barrier + record-word ring, skewed
@@ -126,7 +126,7 @@ def test_packed_classes_in_every_form_of_the_row_loop(gpu_ctx, oracle, monkeypat
 
 @pytest.mark.parametrize("env", [{"RATTLE_POA_DEBUG": "1"}, {"RATTLE_POA_DEBUG": "2"}, {"RATTLE_POA_DEBUG": "3"}, {"RATTLE_POA_DEBUG": "4"},
                                  {"RATTLE_POA_DEBUG": "4", "RATTLE_POA_MODE": "dense"},
-                                 {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_MODE": "sparse"}, {"RATTLE_POA_MODE": "dense"},
+                                 {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_MODE": "dense"},
                                  {"RATTLE_POA_MODE": "mt4"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
                                  {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_DEBUG": "3"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_NODE_CAP": "700"},
                                  {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "10"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_MT_SLOTS": "6"},
@@ -145,13 +145,13 @@ def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
         assert rows[p] == want, p
 
 
-@pytest.mark.parametrize("env", [{}, {"RATTLE_POA_MODE": "dense"}, {"RATTLE_POA_MODE": "sparse"}, {"RATTLE_POA_MODE": "mt4"},
+@pytest.mark.parametrize("env", [{}, {"RATTLE_POA_MODE": "dense"}, {"RATTLE_POA_MODE": "mt4"},
                                  {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"}, {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "9"}])
 def test_predecessors_hundreds_of_rows_back_and_many_in_edges(gpu_ctx, oracle, monkeypatch, env):
     """The row loop reads a COMPACT plan record: the distances to a row's first eight predecessor rows in a byte each, saturated
     at 255, the in-degree capped at 255 (poa.hip, round 4).  Reads that skip 300-600 bases of the others (an exon left out) give
     nodes whose predecessor lies far more than 255 rows back; reads that resume at many different places give one node more than
-    eight in-edges (the edge-list walk); both next to ordinary rows, in the dense and the sparse forms of the loop."""
+    eight in-edges (the edge-list walk); both next to ordinary rows, in the barrier form and the team forms of the loop."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(77)
