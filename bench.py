@@ -64,6 +64,44 @@ def device_state():
     return st or None
 
 
+class DeviceSampler:
+    """Samples device_state() every 100 ms on a thread while the timed region runs: the state before and after it is an idle device's
+    (sclk ~100 MHz) and says nothing about the clocks the kernels ran at.  summary(): mean / min / max of sclk, power, temperature."""
+
+    def __init__(self, period=0.1):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            st = device_state()
+            if st:
+                self.samples.append(st)
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._t.start()
+        return self
+
+    def summary(self):
+        self._stop.set()
+        self._t.join(timeout=2)
+        out = {"samples": len(self.samples)}
+        for key in ("sclk", "mclk", "power_w", "temp_c", "busy_percent"):
+            vals = []
+            for st in self.samples:
+                v = st.get(key)
+                if isinstance(v, str):
+                    v = "".join(ch for ch in v if ch.isdigit() or ch == ".")
+                    v = float(v) if v else None
+                if v is not None:
+                    vals.append(float(v))
+            if vals:
+                out[key] = {"mean": round(sum(vals) / len(vals), 1), "min": min(vals), "max": max(vals)}
+        return out
+
+
 def make_workload(n_reads, genes, seed, isoforms=1):
     # mean ~1 kb transcripts (8 exons of U[50,210]), 10 % error, both strands (cDNA); packed arrays
     return synth.reads_packed(n_reads, genes, isoforms, True, seed=seed, exon=(50, 210))
@@ -510,6 +548,7 @@ def main():
         except Exception:
             hold = False
     state0 = device_state() if rank == 0 else None
+    sampler = DeviceSampler().start() if rank == 0 else None
     barrier()
     t0 = time.time()
     last = None
@@ -525,6 +564,7 @@ def main():
         step_ms.append((time.time() - ts) * 1e3)
     barrier()
     dt = time.time() - t0
+    state_during = sampler.summary() if sampler is not None else None
     state1 = device_state() if rank == 0 else None
     tf = time.time()
     for h in held:
@@ -587,7 +627,7 @@ def main():
             # every timed step on its own (first-step vs steady state), the state of the device around the timed region, and what the
             # harness kept OUT of the timed region: a step's ~2 GB result is freed after the timer stops when the host has the memory
             # (`results_held`), which costs `result_free_ms` per step when it is done between steps instead
-            "step_ms": [round(x, 1) for x in step_ms], "device_state": {"before": state0, "after": state1},
+            "step_ms": [round(x, 1) for x in step_ms], "device_state": {"before": state0, "during": state_during, "after": state1},
             "results_held": bool(hold), "result_free_ms": free_ms,
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
             "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items() if v > 0},

@@ -2907,6 +2907,7 @@ struct poa_env {
     uint32_t mt_slots = 0;               // RATTLE_POA_MT_SLOTS: ring slots of the team kernels (tests: a short ring, many predecessors from HBM)
     int streams = 0;                     // RATTLE_POA_STREAMS: streams the classes of a pass are dealt onto
     bool timing = false;                 // RATTLE_TIMING: one line per class and pass
+    int head_start_us = 30;              // RATTLE_POA_HEAD_START_US: see poa_head_start (0: none)
     poa_env() {
         timeline = getenv("RATTLE_POA_TIMELINE"); mode = getenv("RATTLE_POA_MODE"); profile_json = getenv("RATTLE_POA_PROFILE_JSON");
         if (const char *v = getenv("RATTLE_POA_NODE_CAP")) node_cap = (uint32_t)std::max(64, atoi(v));
@@ -2915,8 +2916,22 @@ struct poa_env {
         if (const char *v = getenv("RATTLE_POA_MT_SLOTS")) mt_slots = (uint32_t)std::max(1, atoi(v));
         if (const char *v = getenv("RATTLE_POA_STREAMS")) streams = atoi(v);
         timing = getenv("RATTLE_TIMING") != nullptr;
+        if (const char *v = getenv("RATTLE_POA_HEAD_START_US")) head_start_us = std::max(0, std::min(1000, atoi(v)));
     }
 };
+
+// A pass launches its groups on several streams at once, and the device places their workgroups in whatever order the queues reach it.
+// A group of a few team workgroups that each need (most of) a CU's LDS -- the POA #3 chains of the largest clusters: ONE workgroup's work
+// for the whole stage -- loses that race one time in three: the barrier-form workgroups of the other groups take some LDS on every CU, and
+// the chain waits until a CU has emptied (0.2-0.3 s of a 0.65 s stage; profiles/round5_timeline_stage_noise.txt: it is one of the sources
+// of the +-5 % run-to-run spread of the whole job).  So the streams that start with a device-filling group first run this kernel: a lone
+// wavefront that sleeps for a few tens of microseconds -- the head start the few-workgroup groups need to be placed.
+// (Stage 1's own spread -- two device-filling groups, 3.6-3.9 s and a 4.6-4.8 s outlier in one run of ten -- is NOT such a race: with every
+// group given workgroups in proportion to its work, all resident from the start, it spread just as much, profiles/round5_ab_device_shares.txt.)
+__global__ void poa_head_start(uint32_t ticks) {
+    const uint64_t t0 = wall_clock64();           // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
 
 // Device-resident core: sequences, offsets and the per-base column output live in HBM; the host only
 // plans (lengths / pack boundaries) and reads back pack widths, statuses and counters.
@@ -3263,7 +3278,15 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 est[c] = std::max(longest, tot / P.n_slots);
                 order[n_run++] = c;
             }
-            std::sort(order, order + n_run, [&](int a, int b) { return est[a] != est[b] ? est[a] > est[b] : a > b; });
+            // groups of team workgroups that do not fill the device go first (and get a head start, see poa_head_start)
+            bool few[POA_GROUPS] = {false};
+            bool any_few = false, any_crowd = false;
+            for (int c = 0; c < POA_GROUPS; ++c) if (C[c].n_slots) {
+                few[c] = C[c].V->pk == 7 && C[c].n_slots < n_cu * (uint32_t)C[c].bpc;
+                (few[c] ? any_few : any_crowd) = true;
+            }
+            const bool head_start = any_few && any_crowd && ENV.head_start_us > 0;
+            std::sort(order, order + n_run, [&](int a, int b) { return few[a] != few[b] ? few[a] : est[a] != est[b] ? est[a] > est[b] : a > b; });
             // (hw_queues(), abi.hip: what the HIP runtime of this process was started with -- the library raises GPU_MAX_HW_QUEUES to
             // 12 when it is loaded before the runtime starts, so that every class gets a queue of its own; an application whose
             // runtime was already running with the default is dealt four streams)
@@ -3278,7 +3301,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 load[sidx] += est[c];
                 cls_plan &P = C[c];
                 hipStream_t cs = ctx->poa_st[sidx];
-                if (!used[sidx]) { e = hipStreamWaitEvent(cs, ctx->poa_go, 0); used[sidx] = true; }
+                if (!used[sidx]) {
+                    e = hipStreamWaitEvent(cs, ctx->poa_go, 0); used[sidx] = true;
+                    if (e == hipSuccess && head_start && !few[c]) { poa_head_start<<<1, 64, 0, cs>>>((uint32_t)ENV.head_start_us * 100u); e = hipGetLastError(); }
+                }
                 if (e != hipSuccess) break;
                 e = P.V->launch(P.A, P.n_slots, P.shm, cs);
             }
