@@ -263,7 +263,8 @@ def test_fix_msa_ends_trims_through_the_hip_path(gpu_ctx, oracle):
 def test_correct_outputs_do_not_depend_on_scheduling(gpu_ctx, monkeypatch):
     """Round 3's two-flow experiment (never merged) once showed ONE differing quality symbol between two schedules of the same job.
     Byte-exactness must not depend on how the device happens to run the packs: the same `correct` job is repeated with one POA
-    stream and with twelve, with the big-cluster stage split forced and not, with the skewed-pipeline variants of kernel C, and
+    stream and with twelve, with the big-cluster stage split forced and not, with every form of kernel C's row loop, with and without the head start of
+    the few-workgroup groups, and
     while a second context on a second host thread keeps the device busy with another job (its kernels interleave with this
     job's, its allocations move this job's buffers) -- every output byte, the skip list and the work counters must stay the
     same."""
@@ -281,7 +282,7 @@ def test_correct_outputs_do_not_depend_on_scheduling(gpu_ctx, monkeypatch):
     base = run()
     variants = [{"RATTLE_POA_STREAMS": "1"}, {"RATTLE_POA_STREAMS": "12"}, {"RATTLE_BIG_CLUSTER_PACKS": "3", "RATTLE_BIG_MIN_PACKS": "0"},
                 {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_STREAMS": "2"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
-                {"RATTLE_POA_MODE": "dense"}]
+                {"RATTLE_POA_MODE": "dense"}, {"RATTLE_POA_HEAD_START_US": "0"}, {"RATTLE_POA_HEAD_START_US": "200", "RATTLE_POA_STREAMS": "3"}]
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
