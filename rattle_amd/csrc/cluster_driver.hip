@@ -459,6 +459,7 @@ struct job {
     const uint32_t *subset = nullptr;     // local id -> loaded read id (nullptr = identity)
     uint32_t n = 0;
     bool inner_parallel = true;           // a lone job spreads its representative choice over the host threads
+    uint32_t longest = 0;                 // longest read of this job (start()): decides the seed batch
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     struct cl { cseq main; std::vector<cseq> seqs; };
@@ -519,14 +520,20 @@ struct job {
         // synchronisations) for twice the level-1 comparisons; measured on one box: 340 ms (512), 314 ms (1024), 337 ms (2048).
         // The many clusterings of the --iso level keep 512: a gene's reads fall into few isoforms and a batch that follows the
         // founders up to 1024 doubled the full comparisons there (10.5 M -> 20.9 M, 0.91 -> 1.28 s).  RATTLE_SEED_BATCH overrides both.
+        // Long reads: level 1's B^2 / 2 seed-against-seed comparisons are FULL comparisons of the longest reads of the round, and a round's
+        // full pass lasts as long as its longest pair.  5e5 mixed-length reads (150 nt - 98 kb, config 5), `cluster` on one box: 22.8 s
+        // (32), 20.7 (64), 19.4 (128), 20.4 (256), 23.3 (512), 32.9 (1024), 52.3 (2048) -- the step from 512 to 1024 was round 4's
+        // unexplained 22.8 -> 33.8 s (profiles/round5_bisect_config5_cluster.txt).  So 256 as soon as a read is beyond the packed classes.
         static const uint32_t forced = getenv("RATTLE_SEED_BATCH") ? (uint32_t)std::max(1, atoi(getenv("RATTLE_SEED_BATCH"))) : 0u;
-        return forced ? forced : inner_parallel ? 1024u : 512u;
+        return forced ? forced : longest > 4096u ? 256u : inner_parallel ? 1024u : 512u;
     }
 
     void start() {
         rq.counters = counters;
         items.resize(n);
         for (uint32_t i = 0; i < n; ++i) items[i] = i;
+        longest = 0;
+        for (uint32_t i = 0; i < n; ++i) longest = std::max(longest, rlen(i));
         stage = INITIAL;
         begin_pass(P->bv_threshold);
     }
