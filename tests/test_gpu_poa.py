@@ -100,9 +100,9 @@ def test_length_classes_match_oracle(gpu_ctx, oracle, length, depth):
 @pytest.mark.parametrize("mode", ["dense", "mt4", "mt2", "mt1"])
 @pytest.mark.parametrize("length,depth", [(700, 40), (1300, 30), (1800, 25), (2300, 20)])
 def test_packed_classes_in_every_form_of_the_row_loop(gpu_ctx, oracle, monkeypatch, length, depth, mode):
-    """The four packed column classes under every form of the row loop (RATTLE_POA_MODE): barrier + record-word ring, skewed
-    wavefront pipeline + ready-made ring, and the teams of wavefronts (4 / 2 / 1 teams: rows that do not depend on each other run
-    at the same time, poa.hip dp_rows_mt) -- all byte-identical to the oracle."""
+    """The four packed column classes under every form of the row loop (RATTLE_POA_MODE): barrier + record-word ring, and the teams of
+    wavefronts with the ready-made ring (4 / 2 / 1 teams: rows that do not depend on each other run at the same time, poa.hip
+    dp_rows_mt; one team = the lean pipeline without a row barrier) -- all byte-identical to the oracle."""
     monkeypatch.setenv("RATTLE_POA_MODE", mode)
     rng = np.random.default_rng(length + 1)
     acgt = np.frombuffer(b"ACGT", np.uint8)
@@ -134,7 +134,7 @@ def test_packed_classes_in_every_form_of_the_row_loop(gpu_ctx, oracle, monkeypat
 def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
     """The slow paths behind the fast ones stay exact: full topological sort for ties (bit 0), traceback without
     the LDS chain (bit 1), packs re-run with a larger arena after a node-capacity overflow; and every form of the row loop
-    (RATTLE_POA_MODE: the barrier form, the skewed wavefront pipeline, teams of wavefronts on 4 / 2 / 1 teams -- the last with
+    (RATTLE_POA_MODE: the barrier form, teams of wavefronts on 4 / 2 / 1 teams -- the last with
     rings so short that many predecessors come from the record in HBM)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
