@@ -25,3 +25,27 @@ import check_asm
 def test_bv_filter_scalar_banks_are_not_touched_before_their_wait(tmp_path):
     """(the same check gates the library's build: rattle_amd/csrc/Makefile, bv_filter.o)"""
     check_asm.check_bv_filter(check_asm.device_asm("bv_filter.hip", tmp_path))
+
+
+def test_bench_device_sampler_summarises_what_sysfs_says(monkeypatch):
+    """bench.py samples sysfs (clock lines like '2406Mhz', power in watts) on a thread during the timed region; the summary is part of the
+    driver's bench line, so the parsing must survive whatever the box says: strings with units, missing keys, nothing at all."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    script = iter([{"sclk": "2406Mhz", "mclk": "2000Mhz", "power_w": 900.0}, {"sclk": "1800Mhz", "power_w": 700.0, "temp_c": None}, None, {"sclk": "N/A"}])
+    monkeypatch.setattr(bench, "device_state", lambda: next(script, None))
+    s = bench.DeviceSampler(period=0.01).start()
+    time.sleep(0.15)
+    out = s.summary()
+    assert out["samples"] == 3                                   # the None sample is dropped
+    assert out["sclk"] == {"mean": 2103.0, "min": 1800.0, "max": 2406.0}
+    assert out["power_w"]["max"] == 900.0 and "temp_c" not in out
+    monkeypatch.setattr(bench, "device_state", lambda: None)
+    assert bench.DeviceSampler(period=0.01).start().summary() == {"samples": 0}
