@@ -70,9 +70,9 @@ void parallel_for(size_t n, int n_threads, F f) {
 
 // Growable device buffer (never shrinks; contents are not preserved across grow()).  Owns its
 // allocation and frees it on destruction, so early error returns do not leak HBM; borrow() makes a
+// non-owning view of another buffer (the child contexts of cluster_subsets share the parent's index).
 void dev_free(void *p);
 
-// non-owning view of another buffer (the child contexts of cluster_subsets share the parent's index).
 template <typename T>
 struct dbuf {
     T *p = nullptr;
@@ -181,6 +181,7 @@ struct exchange {
     // configured as rank r of R with rattle_hip_set_exchange(.., fn = NULL) under RATTLE_XCHG_REPLAY=<file> then runs its own share
     // alone: at every exchange it gets its own piece back plus the recorded whole (its peers' part of it).
     FILE *replay = nullptr;
+    std::string replay_path;            // ... the file `replay` was opened from (the gather's piece files live beside it)
     // staging of the RCCL all-gather-v, kept between calls: the sharded cluster driver exchanges a few KB per greedy round
     // (119 rounds at 1e6 reads) and three hipMalloc / hipFree pairs per exchange were three device-wide synchronisations each
     dbuf<uint64_t> d_sz;
@@ -190,6 +191,7 @@ struct exchange {
     void reset() {
         rank = 0; nranks = 1; fn = nullptr; user = nullptr; comm = nullptr; calls = 0; bytes = 0;      // the loader's handle (rccl) stays
         if (replay) { fclose(replay); replay = nullptr; }
+        replay_path.clear();
         d_sz.release(); d_send.release(); d_recv.release(); h_sz.release(); h_send.release(); h_recv.release();
     }
 };
@@ -217,7 +219,8 @@ void lpt_assign(const std::vector<uint64_t> &cost, int nranks, std::vector<uint3
 // all-gather of one byte string per rank (sizes first, then the payload)
 bool xchg_recording(const rattle_ctx *ctx);
 bool xchg_replaying(const rattle_ctx *ctx);
-int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all);
+// job_payload = false: a transport self-test (rattle_hip_comm_probe), kept out of the record / replay aid
+int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all, bool job_payload = true);
 
 // one rectangle of kernel A's launch: seeds [s_base, s_base+ns) x candidates [c_base, c_base+nc) of the uploaded
 // arrays, tiles [tile_base, ...), look-up table row at d_lut + lut_off

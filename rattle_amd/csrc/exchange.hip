@@ -96,18 +96,23 @@ int rccl_allgatherv(rattle_ctx *ctx, const uint8_t *d_send, uint8_t *d_recv, con
 
 // RATTLE_XCHG_RECORD (single rank): the file every exchange point appends the job's whole payload to
 static FILE *xchg_record_file() {
-    static FILE *f = getenv("RATTLE_XCHG_RECORD") ? fopen(getenv("RATTLE_XCHG_RECORD"), "wb") : nullptr;
+    static FILE *f = [] {
+        const char *path = getenv("RATTLE_XCHG_RECORD");
+        FILE *g = path ? fopen(path, "wb") : nullptr;
+        if (g) atexit([] { if (FILE *h = xchg_record_file()) fclose(h); });
+        return g;
+    }();
     return f;
 }
 bool xchg_recording(const rattle_ctx *ctx) { return ctx->xchg.nranks == 1 && xchg_record_file() != nullptr; }
 bool xchg_replaying(const rattle_ctx *ctx) { return ctx->xchg.replay != nullptr; }
 
-int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all) {
+int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vector<std::vector<uint8_t>> &all, bool job_payload) {
     exchange &X = ctx->xchg;
     all.assign((size_t)X.nranks, {});
     if (X.nranks == 1) {
         all[0] = mine;
-        if (FILE *f = xchg_record_file()) {
+        if (FILE *f = job_payload ? xchg_record_file() : nullptr) {
             const uint64_t n = mine.size();
             if (fwrite(&n, 8, 1, f) != 1 || (n && fwrite(mine.data(), 1, n, f) != n)) { set_error("exchange record: write failed"); return RATTLE_ERR_HIP; }
             fflush(f);
@@ -115,6 +120,7 @@ int xchg_allgatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, std::vect
         return 0;
     }
     ++X.calls;
+    if (X.replay && !job_payload) { all[(size_t)X.rank] = mine; return 0; }      // (a self-test has no entry in the record)
     if (X.replay) {
         // this rank's own piece, and the recorded whole of the single-rank job in the next rank's place (the caller drops what is its own in it)
         uint64_t n = 0;
@@ -180,7 +186,7 @@ static int xchg_gatherv(rattle_ctx *ctx, const std::vector<uint8_t> &mine, int r
     G.p.assign((size_t)X.nranks, nullptr); G.n.assign((size_t)X.nranks, 0);
     if (X.replay) {
         // the ranks' pieces travel through files beside the record: every rank leaves its piece, the root (run last) picks the others up
-        const std::string base = std::string(getenv("RATTLE_XCHG_REPLAY")) + ".gather.";
+        const std::string base = X.replay_path + ".gather.";
         if (X.rank != root) {
             FILE *f = fopen((base + std::to_string(X.rank)).c_str(), "wb");
             if (!f || (mine.size() && fwrite(mine.data(), 1, mine.size(), f) != mine.size())) { if (f) fclose(f); set_error("gather replay: cannot write this rank's piece"); return RATTLE_ERR_HIP; }
@@ -461,9 +467,11 @@ int rattle_hip_set_exchange(rattle_ctx *c, int rank, int nranks, rattle_allgathe
     if (!c || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn && !replay)) { set_error("bad exchange arguments"); return RATTLE_ERR_ARG; }
     if (c->xchg.comm) { set_error("an RCCL communicator is attached: rattle_hip_comm_destroy first"); return RATTLE_ERR_STATE; }
     if (c->xchg.replay) { fclose(c->xchg.replay); c->xchg.replay = nullptr; }
+    c->xchg.replay_path.clear();
     if (nranks > 1 && !fn) {
         c->xchg.replay = fopen(replay, "rb");
         if (!c->xchg.replay) { set_error(std::string("exchange replay: cannot open ") + replay); return RATTLE_ERR_ARG; }
+        c->xchg.replay_path = replay;
     }
     c->xchg.rank = rank; c->xchg.nranks = nranks; c->xchg.fn = fn; c->xchg.user = user;
     return 0;
@@ -525,8 +533,9 @@ int rattle_hip_comm_probe(rattle_ctx *c) {
         }
         return 0;
     };
+    if (X.replay) return 0;                    // the replay aid has no peers to probe
     std::vector<std::vector<uint8_t>> all;
-    RT_TRY(xchg_allgatherv(c, mine, all));
+    RT_TRY(xchg_allgatherv(c, mine, all, false));
     {
         std::vector<const uint8_t *> p; std::vector<size_t> n;
         for (const std::vector<uint8_t> &v : all) { p.push_back(v.data()); n.push_back(v.size()); }

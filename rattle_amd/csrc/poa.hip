@@ -1289,6 +1289,9 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
 #pragma unroll
                 for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
             }
+            // (lane 0 of a column block w > 0 reads the word LEFT of the block, hq[-1], from block w - 1's record: that store is ordered before
+            // this load only through the mailbox waits of earlier rows, which holds when ring_reach + 1 >= teams + ring_slack -- plan_class
+            // sizes the ring so, or takes the barrier form)
             auto far_fetch = [&](uint32_t prow) __attribute__((always_inline)) {
                 uint32_t x[NP];
                 const uint32_t cc = act ? c0 : 0u;
@@ -2278,7 +2281,7 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                 if (hit) { S.rowmax[r] = 1; if (pk_packed(PK) || PK == 3) atomicMin(&X.brow, r); }
                             }
                         } else {
-                            for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NW) {
+                            for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NT / 64) {
                                 const cell_t *Hr = (const cell_t *)S.H + (uint64_t)r * Lp;
                                 bool hit = false;
                                 for (uint32_t c = tid & 63; c < L; c += 64) hit |= (pk_packed(PK) ? (int32_t)(Hr[c] & 0x3FFF) : (int32_t)Hr[c]) == best;
@@ -3026,6 +3029,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         int bpc = 1;
         int rounds = 0;                            // passes this class has taken
         bool clamped = false;                      // cell_cap was cut to what one slot can get: packs that still fail are skipped
+        bool no_teams = false;                     // a pack of this group failed with POA_ERR_SYNC: its retries take the barrier form
         const poa_variant *V = nullptr;
     } C[POA_GROUPS];
     for (int c = 0; c < POA_GROUPS; ++c) { C[c].todo = by_class[c]; if (ENV.node_cap) C[c].node_cap = ENV.node_cap; }
@@ -3064,6 +3068,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 C[c].V = mode == 1 ? &k_dense[c] : mode == 3 ? &k_mt4[c] : mode == 4 ? &k_mt2[c] : &k_mt1[c];
             }
             if (c >= 12) { const int gc = c - 12; C[c].V = force_mode == 1 ? &k_dense[gc] : chain_mode == 3 ? &k_mt4[gc] : chain_mode == 4 ? &k_mt2[gc] : &k_mt1[gc]; }
+            if (C[c].no_teams && poa_group_class(c) < 4) C[c].V = &k_dense[poa_group_class(c)];
         }
     };
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
@@ -3104,6 +3109,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.debug = ENV.debug;
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         A.ring_slots = A.ring_reach = A.ring_slack = 0;
+        bool mt_ring_ok = true;
         if (P.V->pk == 7) {
             // dp_rows_mt: the ring takes the LDS a workgroup can have when `live_per_cu` packs share a CU (up to 24 slots); `slack` rows may be in flight behind the reader (two rounds of the teams when there is room, one otherwise),
             // `reach` = slots - slack rows back are served from the ring, the rest from the record in HBM
@@ -3118,7 +3124,13 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 if (slots >= slack + 6 || ppc == 1) break;
             }
             if (slots < slack + 2) { slots = slack + 2; }      // (the launch fails loudly if even that does not fit)
-            if (ENV.mt_slots) slots = std::max<uint32_t>(slack + 2, ENV.mt_slots);      // tests: a short ring, to exercise the record path
+            if (ENV.mt_slots) { slack = teams > 1 ? teams : 0; slots = std::max<uint32_t>(slack + 2, ENV.mt_slots); }      // tests: a short ring, to exercise the record path
+            // A row whose in-edge lies beyond the ring reads block w - 1's record word of the column left of its block (far_fetch, lane 0).  That
+            // store is ordered before the load only through the mailbox wait of this team's PREVIOUS row (row - teams), whose left neighbour had
+            // seen every row <= row - teams - slack final in block w - 1: far rows (row - prow > reach) are covered iff reach + 1 >= teams + slack.
+            // Less slack first; a ring too short even then takes the barrier form (round 5's advisor: retry passes with 16 x the nodes).
+            if (teams > 1 && slots - slack + 1 < teams + slack) slack = teams;
+            mt_ring_ok = teams == 1 || slots - slack + 1 >= teams + slack;
             A.ring_slots = slots; A.ring_slack = slack; A.ring_reach = slots - slack;
         }
         auto lds_bytes = [&](const poa_variant *V) {
@@ -3126,7 +3138,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             return (size_t)lds_seq + poa_region_bytes(ncap, (int)V->cpl, (int)V->ring, (int)V->nw, (int)V->pk) + 64;
         };
         // a retry pass with a huge graph: the node bitmaps leave no room for a ready-made ring -- fall back to the dense form (2 bytes per cell)
-        if (gc < 4 && P.V->pk != 1 && lds_bytes(P.V) > 158u * 1024) { P.V = &k_dense[gc]; A.ring_slots = A.ring_reach = A.ring_slack = 0; A.o_planm = take(0); }
+        if (gc < 4 && P.V->pk != 1 && (lds_bytes(P.V) > 158u * 1024 || !mt_ring_ok)) { P.V = &k_dense[gc]; A.ring_slots = A.ring_reach = A.ring_slack = 0; A.o_planm = take(0); }
         if ((gc == 4 || gc == 5 || gc == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[gc - 4];
         if (gc == POA_CLASSES - 1 && lds_bytes(P.V) > 158u * 1024) P.V = &k_long_noring;
         P.shm = lds_bytes(P.V);
@@ -3322,11 +3334,24 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             if (!P.n_slots) continue;
             ++P.rounds;
             std::vector<uint32_t> again;
+            bool sync_retry = false;
+            size_t cap_retry = 0;
             for (uint32_t p : P.todo) {
                 const uint32_t s = h_status[p];
                 if (s == POA_OK) continue;
+                if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) ++cap_retry;
                 if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) again.push_back(p);
-                else {
+                else if (s == POA_ERR_SYNC && !P.no_teams) {
+                    // a wavefront of the team kernels gave up a bounded wait (a debugger stop, a trap handler, a throttled device, or a
+                    // protocol error): the pack is dropped and run again in the barrier form, which cannot time out
+                    again.push_back(p); sync_retry = true;
+                    if (ENV.timing) {
+                        unsigned long long dbg[3] = {0, 0, 0};
+                        (void)hipMemcpy(dbg, d_cnt.p + 8, sizeof(dbg), hipMemcpyDeviceToHost);
+                        fprintf(stderr, "[rattle]     poa: pack %u gave up wait %llu of team %llu block %llu at row %llu (saw %d, wants %d): again in the barrier form\n", p, dbg[0] & 0xFF, (dbg[0] >> 8) & 0xFF,
+                                (dbg[0] >> 16) & 0xFF, dbg[0] >> 32, (int32_t)(dbg[1] & 0xFFFFFFFFu), (int32_t)(dbg[1] >> 32));
+                    }
+                } else {
                     std::string msg = "poa_kernel: pack " + std::to_string(p) + " failed with status " + std::to_string(s);
                     if (s == POA_ERR_SYNC) {       // a wavefront of dp_rows_mt gave up waiting: say who, for what, at which row
                         unsigned long long dbg[3] = {0, 0, 0};
@@ -3338,6 +3363,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 }
             }
             P.todo.swap(again);
+            if (sync_retry) { P.no_teams = true; if (cap_retry == 0) continue; }      // same capacities, another form
             if (!P.todo.empty()) {
                 if (P.clamped) { rc = give_up(P); continue; }
                 P.node_cap = std::min<uint32_t>(P.node_cap * 4, 1u << 20); P.cell_cap *= 8;

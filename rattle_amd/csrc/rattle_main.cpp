@@ -687,7 +687,7 @@ int mode_cluster(int argc, char **argv) {
             for (auto &s : c.seqs) s.seq_id = (int)order[s.seq_id];
         }
         write_clusters(gene, out_path);
-            team.close();
+        team.close();
         return EXIT_SUCCESS;
     }
     // main.cpp:281-323: second level per gene cluster with the iso parameters

@@ -129,7 +129,7 @@ def test_packed_classes_in_every_form_of_the_row_loop(gpu_ctx, oracle, monkeypat
                                  {"RATTLE_POA_NODE_CAP": "700"}, {"RATTLE_POA_MODE": "dense"},
                                  {"RATTLE_POA_MODE": "mt4"}, {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"},
                                  {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_DEBUG": "3"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_NODE_CAP": "700"},
-                                 {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "10"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_MT_SLOTS": "6"},
+                                 {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "11"}, {"RATTLE_POA_MODE": "mt2", "RATTLE_POA_MT_SLOTS": "6"},
                                  {"RATTLE_POA_MODE": "mt1", "RATTLE_POA_MT_SLOTS": "3"}])
 def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
     """The slow paths behind the fast ones stay exact: full topological sort for ties (bit 0), traceback without
@@ -146,7 +146,7 @@ def test_fallback_paths_match_oracle(gpu_ctx, oracle, monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", [{}, {"RATTLE_POA_MODE": "dense"}, {"RATTLE_POA_MODE": "mt4"},
-                                 {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"}, {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "9"}])
+                                 {"RATTLE_POA_MODE": "mt2"}, {"RATTLE_POA_MODE": "mt1"}, {"RATTLE_POA_MODE": "mt4", "RATTLE_POA_MT_SLOTS": "11"}])
 def test_predecessors_hundreds_of_rows_back_and_many_in_edges(gpu_ctx, oracle, monkeypatch, env):
     """The row loop reads a COMPACT plan record: the distances to a row's first eight predecessor rows in a byte each, saturated
     at 255, the in-degree capped at 255 (poa.hip, round 4).  Reads that skip 300-600 bases of the others (an exon left out) give
