@@ -162,7 +162,7 @@ typedef struct {
     uint32_t *width;        /* [n_packs]  MSA columns */
     uint64_t *row_offset;   /* [n_seqs+1] byte offset of each sequence's row in `rows` */
     char *rows;             /* rows of all packs back to back */
-    uint64_t counters[8];   /* DP cells, alignments, graph nodes (sum of final sizes), ... */
+    uint64_t counters[8];   /* DP cells, alignments, graph nodes (sum of final sizes), rows, DP cells computed, certified bands, failed band certificates */
 } rattle_msa_set;
 
 int rattle_hip_poa_msa(rattle_ctx *ctx, const uint8_t *seq_concat, const uint64_t *offsets, uint32_t n_seqs,
@@ -240,7 +240,9 @@ typedef struct {
 
 typedef struct {
     rattle_read_set corrected, uncorrected, consensi;
-    uint64_t counters[8];   /* [0] DP cells, [1] alignments, [2] packs queued, [3] packs skipped, [4] reads in skipped packs */
+    uint64_t counters[8];   /* [0] DP cells (the reference's count: graph rows x sequence columns of every alignment), [1] alignments, [2] packs queued,
+                             * [3] packs skipped, [4] reads in skipped packs, [5] DP cells the device computed (fewer where the exact band for
+                             * near-identical sequences was certified), [6] alignments with a certified band, [7] failed band certificates */
     rattle_skip_list skipped;
     /* global pack index of every corrected / uncorrected record (0xFFFFFFFF: member of a pack that never
      * entered the queue); what rattle_hip_correction_gather orders the merged result by */

@@ -221,6 +221,7 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     d_desc.release();
     counters[0] += h_cnt[0];
     counters[1] += h_cnt[1];
+    counters[5] += h_cnt[11]; counters[6] += h_cnt[12]; counters[7] += h_cnt[13];      // DP cells computed; alignments with a certified band / a failed certificate
     // layout of the row matrices and per-column arrays
     S.moff.assign(np, 0); S.coff.assign(np, 0);
     uint64_t cells = 0, cols = 0;
@@ -718,6 +719,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     for (std::vector<skip_t> *v : {&sk_2a, &sk_3a, &sk_2b, &sk_3b}) for (skip_t &x : *v) skips.push_back(std::move(x));
     counters[0] += cnt_main[0];
     counters[1] += cnt_main[1];
+    counters[5] += cnt_main[5]; counters[6] += cnt_main[6]; counters[7] += cnt_main[7];
     if (d2h.joinable()) d2h.join();
     d_os.release(); d_oq.release();
 #undef LOCAL_TRY

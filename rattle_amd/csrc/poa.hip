@@ -85,11 +85,12 @@ struct poa_args {
     uint32_t aln_cap, spill_cap, seq_cap;
     uint64_t o_planm;              // multi-team rows (dp_rows_mt): the row loop's own 32-byte record per row
     uint32_t ring_slots, ring_reach, ring_slack;      // ... and its ring, sized at launch: slots in LDS, rows a reader looks back, rows that may be in flight
+    uint32_t band;                 // PK == 8: bytes of LDS behind the graph walks' bitmaps and stack (the band's ring + selector table; tie labels and traceback tables between two DPs)
     uint32_t debug;                // tests: bit 0 = resolve ties with the full sort, bit 1 = traceback without the LDS fast path, bit 2 = ... without its jump tables
     uint32_t *out_col;             // per base: node id during the run, MSA column at the end
     uint32_t *out_width;           // per pack
     uint32_t *status;              // per pack: 0 ok, else error code
-    unsigned long long *counters;  // [0] DP cells, [1] alignments, [2] final nodes, [3] rows, [4..7] phase ticks
+    unsigned long long *counters;  // [0] DP cells (the reference's count: rows x columns), [1] alignments, [2] final nodes, [3] rows, [4..7] phase ticks, [8..10] dp_rows_mt's diagnosis, [11] DP cells computed, [12] / [13] alignments with a certified band / a failed certificate
     unsigned long long *timeline;  // RATTLE_POA_TIMELINE: per pack {start, end} of its workgroup's work on it (100 MHz wall clock), else null
     unsigned long long *prof;      // POA_PROFILE builds: per class [0] plan [1] DP [2] ties [3] traceback [4] add_alignment [5] merge_order [6] final sort + columns [7] whole packs
 };
@@ -100,7 +101,8 @@ struct poa_args {
 #define PT_NOW() 0ull
 #endif
 
-enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_ERR_ALN = 4, POA_ERR_SPILL = 5, POA_ERR_GRAPH = 6, POA_ERR_SYNC = 7 };
+enum { POA_OK = 0, POA_ERR_NODES = 1, POA_ERR_CELLS = 2, POA_ERR_EDGES = 3, POA_ERR_ALN = 4, POA_ERR_SPILL = 5, POA_ERR_GRAPH = 6, POA_ERR_SYNC = 7,
+       POA_ERR_BAND = 8 /* (PK == 8) an alignment of the pack has no certified band: the pack goes to the full-row kernels */ };
 
 struct poa_ws {                    // per-block workspace: global pointers + LDS + wave-uniform state
     uint4 *nrec, *nal, *plan, *planb, *planc, *pland;
@@ -150,6 +152,16 @@ __device__ __forceinline__ int32_t wave_scan_max(int32_t v, int32_t ident) {
     v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x143 /*row_bcast:31*/, 0xC, 0xF, false));
     return v;
 }
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /*row_shr:2*/, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /*row_shr:4*/, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /*row_shr:8*/, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /*row_bcast:15*/, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /*row_bcast:31*/, 0xC, 0xF, false);
+    return v;
+}
 // the same scan with the maximum fused into the DPP instruction (v_max_i32_dpp: a lane whose source lies outside its row
 // / is masked off keeps its own value, which is the identity of the scan): 6 VALU instructions instead of 18.  The s_nop
 // cover the VALU-write -> DPP-read hazard (2 wait states), which the assembler does not insert inside inline asm.
@@ -183,6 +195,12 @@ __device__ __forceinline__ void wave_sync() {
 // from the record on a rare path) gets an s_waitcnt vmcnt(0) before every use -- which also waits for the record stores
 // of the previous row, a full memory round trip per row.  So every vector load of the row loop is completed explicitly
 // where it is issued (rarely), and the hot path carries no vmcnt wait at all.
+// a wave-uniform 64-bit value as a scalar, whatever register class the compiler kept it in (readfirstlane of a scalar folds away): the
+// plan pointers go into inline asm with "s" constraints, and an input the register allocator had parked in vector registers made
+// the backend stop with "illegal VGPR to SGPR copy" -- which unrelated edits elsewhere in the kernel kept provoking (rounds 3-6)
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 __device__ __forceinline__ void drain_vector_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), expcnt / lgkmcnt untouched
 
 // Row barrier of the DP: only LDS traffic has to be ordered across the four waves, so global
@@ -218,13 +236,15 @@ __device__ __forceinline__ void st_refill(poa_ws &S) {
 }
 
 // ---- spoa Graph::topological_sort ----------------------------------------------------------------
+// (every helper of the kernel is force-inlined: one that stays a call takes the workspace by reference, which moves it -- and every pointer
+// in it -- to scratch memory: the band kernels' first build had 644 flat and 730 scratch accesses where the barrier form has 0 and 36)
 // mode 1: rank[] receives the MSA column of each node (final pass);  mode 2: srank[] receives
 // the spoa rank (tie-break of best rows).  The DP itself runs in the incrementally maintained
 // block order (see merge_order), which is a topological order with aligned groups contiguous.
 // mode 3: the marks of everything emitted before root `root0` are preset by the caller (tie_labels);
 // the sort resumes at root0 and stops at the first emitted node whose DP row is in tied[0..n_tied):
 // that row is returned in n_cols.
-__device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emit, uint32_t &n_cols, uint32_t root0 = 0,
+__device__ __forceinline__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emit, uint32_t &n_cols, uint32_t root0 = 0,
                          const uint32_t *tied = nullptr, uint32_t n_tied = 0) {
     const uint32_t n = S.n_nodes;
     if (mode != 3) {
@@ -297,7 +317,7 @@ __device__ void toposort(poa_ws &S, const poa_args &A, int mode, uint32_t &n_emi
 // Sweeps rows hi_start, hi_start-1, ... and returns the first row it did NOT process: it stops below
 // lo_stop (at a group boundary) -- a label is final once the sweep has reached its row, so the
 // labels of the tied rows only need the rows above the lowest of them.
-__device__ uint32_t tie_labels(poa_ws &S, uint16_t *lab, uint32_t hi_start, uint32_t lo_stop) {
+__device__ __forceinline__ uint32_t tie_labels(poa_ws &S, uint16_t *lab, uint32_t hi_start, uint32_t lo_stop) {
     const uint32_t lane = threadIdx.x;
     uint32_t in_group = 0;
     for (int32_t hi = (int32_t)hi_start; hi >= 1; hi -= 64) {
@@ -752,7 +772,7 @@ __device__ void dp_rows_v3(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint32
     // predecessor rows in a byte each): one s_load_dwordx4 per row instead of three, 4 + 4 plan registers instead of 12 + 12 (the
     // kernel spills SGPRs: reloads were v_readlane in the row loop), a distance compared with the ring length instead of a
     // subtraction per predecessor.  A predecessor beyond the ring (a few per cent) takes its row from planb / planc.
-    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc, ppd = (uint64_t)S.pland;
+    uint64_t ppa = uni64((uint64_t)S.plan), ppb = uni64((uint64_t)S.planb), ppc = uni64((uint64_t)S.planc), ppd = uni64((uint64_t)S.pland);
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc), "+s"(ppd) : : "memory");
     const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb, cpc = (cplan_t)ppc, cpd = (cplan_t)ppd;
 
@@ -1135,7 +1155,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
         dead = 1u;
     };
     // the plan through the scalar cache (see dp_rows_v3)
-    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb, ppc = (uint64_t)S.planc, ppm = (uint64_t)S.planm;
+    uint64_t ppa = uni64((uint64_t)S.plan), ppb = uni64((uint64_t)S.planb), ppc = uni64((uint64_t)S.planc), ppm = uni64((uint64_t)S.planm);
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb), "+s"(ppc), "+s"(ppm) : : "memory");
     const cplan_t cpb = (cplan_t)ppb, cpc = (cplan_t)ppc;
     (void)ppa;
@@ -1476,6 +1496,300 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
     if (sk_ld(p_abort)) { S.err = POA_ERR_SYNC; best = 0; multi = false; }      // (uniform: the barriers above have passed)
 }
 
+// ---- an EXACT band for near-chain graphs (PK == 8; POA #2 / #3 of `rattle correct`, correct.cpp:427-436,520-532) ------------------
+// The corrected reads of a pack and the pack consensi of a cluster are near-identical: their graph is (almost) a chain and the
+// alignment runs down one diagonal.  A local alignment path scores at most 5 per diagonal move and nothing for any other move, and
+// a path through cell (row i, column j) of an n-row graph in topological order has at most
+//     M(i, j) = min(c_i, j) + min(C - c_i, L - j)
+// diagonal moves, c_i = the MSA column of row i (rows in block order; the rows of an aligned group share a column), C = columns of the
+// graph: at most one diagonal move per sequence column, and at most one per graph column on either side of the cell, because every edge
+// leads to a strictly later column (checked for every in-edge while the rows' records are built: a graph that breaks it gets no band).
+// (Rows instead of columns would do for a chain, but every substitution a pack member adds is a row of its own in an existing column:
+// the POA #3 of a 550-pack cluster reaches 1600 rows for 1300 columns.)  So with tau = L - t every path that touches a cell with M < tau scores at most 5 (tau - 1):
+// if the best score S' found with those cells taken as H = 0, E = F = -inf is >= 5 tau - 4, then (i) every path of score >= S' lies
+// inside {M >= tau}, so S' is the true best score and the cells that reach it are the same; (ii) the traceback is the same: a test
+// `H[i][j] == H[p][j-1] + s` (or on F / E) that holds in the full matrices puts the tested cell on a path of total score S, which lies
+// inside and is therefore computed exactly; one that fails in the full matrices fails a fortiori on a lower bound (DESIGN.md §4,
+// tests/test_band_lemma.py for sequences and DAGs).  {M >= tau} is the parallelogram  max(1, c_i - s) <= j <= min(L, c_i + t),
+// s = C - L + t, of width C - L + 2 t + 1: it fits ONE wavefront -- 64 lanes x CPLB columns, no exchange between wavefronts, no
+// barrier, a record of 64 CPLB cells per row instead of L -- whenever C - L + 2 t + 1 <= 63 CPLB (CPLB = 2, 4 or 8).  The certificate is checked after the
+// rows; when it fails the alignment is run again wider (t from the score found: then it must hold) or over the full rows.
+// Layout: lane l of row i owns the column group G0(i) + l, G0(i) = max(0, c_i - s - 1) / CPLB (relative to the row's window; the row's
+// record carries it).  The ring
+// (LDS) holds ready-made predecessor terms per lane as in dp_rows_mt (A = H shifted by a column, B = max(H + g - e, F)); a reader
+// finds the terms of ITS columns in row p at lane l + G0(i) - G0(p): an address offset the plan record carries ready-made.  Behind the
+// 64 entries of a slot lie BAND_PAD neutral ones (what lies right of row p's window: H = 0), the first of them with the H of the
+// window's last column as its diagonal source.  Everything a lane keeps per column (score selectors, j e, g - (j+1) e) moves with
+// the window: an add and one LDS read every CPLB rows.
+#define BAND_PAD 16
+#define BD_MORE4 1u
+#define BD_SLOW 2u
+#define BD_NOBASE 4u
+__host__ __device__ constexpr uint32_t band_entry_bytes(int CPLB) { return 4u * (uint32_t)CPLB; }
+__host__ __device__ constexpr uint32_t band_slot_bytes(int CPLB) { return (64u + BAND_PAD) * band_entry_bytes(CPLB); }
+// first column group of the window of a row in column c (bsh = log2 CPLB)
+__device__ __forceinline__ uint32_t band_g0(uint32_t c, uint32_t bs, uint32_t bsh) { return c > bs + 1u ? (c - bs - 1u) >> bsh : 0u; }
+// LDS the band needs behind the ring base: slots, the selector table (a dword per column pair for Lp + 66 CPLB columns), junk words
+__host__ __device__ constexpr uint32_t band_lds_bytes(uint32_t slots, int CPLB, uint32_t Lp) {
+    return slots * band_slot_bytes(CPLB) + (Lp / (uint32_t)CPLB + 66u) * (uint32_t)(CPLB / 2) * 4u + 64u * 4u;
+}
+
+// STRIP = true: the same rows over a VERTICAL window -- the columns strip * 64 CPLB + 1 .. (strip + 1) * 64 CPLB of every row -- with real
+// values at its left edge instead of H = 0: strip after strip this is the full matrix, no certificate needed (what an alignment runs
+// whose band does not fit or whose certificate fails).  A cell depends on cells in its own or a smaller column only, so the strips can
+// be done one after the other; strip k leaves two numbers per row for strip k + 1 (a dword in lh[], double-buffered by strip parity, as
+// in dp_rows_longr): the H of its last column (the diagonal source of the next strip's first column) and the prefix maximum of u over
+// every column up to there (the horizontal gap).  Windows do not move: no lane shift, no pads.  Record: strip-major, (n + 1) rows of 64
+// CPLB cells per strip.
+template <int CPLB, bool STRIP = false>
+__device__ __forceinline__ void dp_rows_band(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t brs, uint32_t sel_off, uint32_t junk_off, int32_t &best, uint32_t strip = 0,
+                                             s16x2 mxa_in = (s16x2){0, 0}, s16x2 *mxa_out = nullptr) {
+    constexpr int NP = CPLB / 2;
+    constexpr uint32_t EB = band_entry_bytes(CPLB);
+    static_assert(CPLB == 2 || CPLB == 4 || CPLB == 8, "a ring entry is one 8- or 16-byte LDS access, or two of 16");
+    const int lane = threadIdx.x & 63;
+    const uint32_t ring0 = (uint32_t)(uintptr_t)(lds_p)S.ring;
+    const uint32_t rb = ring0 + (uint32_t)lane * EB;                          // this lane's entry of slot 0
+    const uint32_t va_sel = ring0 + sel_off + (uint32_t)lane * (NP * 4u);     // + group * NP * 4: the selectors of the lane's columns
+    const uint32_t a_pad = lane == 63 ? ring0 + 64u * EB : ring0 + junk_off + 4u * (uint32_t)lane;      // where lane 63's "H of the last column" goes (+ slot)
+    // the record: 64 * NP dwords per row.  Through pointers that carry the GLOBAL address space in their type: the kernel keeps its
+    // workspace pointers in scratch here, what comes back from there is a generic pointer to the compiler, and a flat_store counts on
+    // lgkmcnt as well -- the row's LDS wait then waited for the previous row's record store, a memory round trip per row (seen in the
+    // disassembly of the first build: 665 cycles per row)
+    typedef __attribute__((address_space(1))) uint32_t *gptr_t;
+    typedef __attribute__((address_space(1))) const uint16_t *gptr16_t;
+    const gptr_t Hrec = (gptr_t)(uintptr_t)S.H;
+    uint64_t ppm = uni64((uint64_t)S.planm), ppl = uni64((uint64_t)S.lh);
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppm), "+s"(ppl) : : "memory");
+    const cplanm_t cpm = (cplanm_t)ppm;
+    typedef const __attribute__((address_space(4))) uint32_t *cdw_t;
+    const cdw_t cin = (cdw_t)ppl + (strip & 1u);                              // STRIP: cin[4 * row] = what the strip to the left left for this row
+    typedef __attribute__((address_space(1))) uint32_t *gdw_t;
+    const gdw_t cout = (gdw_t)(uintptr_t)S.lh + ((strip + 1u) & 1u);
+
+    struct ent8 { u32x4 a, b; __device__ __forceinline__ uint32_t operator[](int i) const { return i < 4 ? a[i] : b[i - 4]; } };
+    typedef typename std::conditional<NP == 1, u32x2, typename std::conditional<NP == 2, u32x4, ent8>::type>::type ent_t;
+    auto issue = [&](const uint32_t off, ent_t &r) __attribute__((always_inline)) {
+        const uint32_t va = rb + off;
+        if constexpr (NP == 1) asm volatile("ds_read_b64 %0, %1" : "=&v"(r) : "v"(va) : "memory");
+        else if constexpr (NP == 2) asm volatile("ds_read_b128 %0, %1" : "=&v"(r) : "v"(va) : "memory");
+        else asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(r.a), "=&v"(r.b) : "v"(va) : "memory");
+    };
+    auto land4 = [&](ent_t &e0, ent_t &e1, ent_t &e2, ent_t &e3) __attribute__((always_inline)) {      // behind an s_waitcnt: the entries exist from here on
+        if constexpr (NP == 4) asm volatile("" : "+v"(e0.a), "+v"(e0.b), "+v"(e1.a), "+v"(e1.b), "+v"(e2.a), "+v"(e2.b), "+v"(e3.a), "+v"(e3.b));
+        else asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));
+    };
+    uint32_t SEL[NP];
+    s16x2 JE[NP], UC[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int j0 = ((int)(STRIP ? strip * 64u : 0u) + lane) * CPLB + 2 * u + 1, j1 = j0 + 1;
+        JE[u] = (s16x2){(short)(j0 * POA_E), (short)(j1 * POA_E)};
+        UC[u] = (s16x2){(short)(POA_G - (j0 + 1) * POA_E), (short)(POA_G - (j1 + 1) * POA_E)};
+        SEL[u] = ((const lds_p)(uintptr_t)(va_sel + (STRIP ? strip * 64u * (uint32_t)(NP * 4) : 0u)))[u];
+    }
+    s16x2 MXA = mxa_in;
+    uint32_t g0 = STRIP ? strip * 64u : 0u;                                   // first column group of the current window (wave-uniform)
+    uint32_t sbase = as_u(pk_splat(POA_G - POA_E));                           // u of the column left of the window (H = 0 there)
+    gptr_t hrow = Hrec + ((uint64_t)(STRIP ? strip * (n + 1u) : 0u) + 1u) * (64u * NP) + (uint32_t)lane * NP;      // row 1 (of this strip)
+    uint32_t cw_next = 0;                                                     // STRIP: the dword of the row after this one (a scalar load a row ahead)
+    if constexpr (STRIP) { if (strip) cw_next = cin[4]; }
+
+    auto step = [&](const uint32_t row, const u32x8 pd, u32x8 &nx) __attribute__((always_inline)) {
+        const uint32_t klo = pd[0], khi = pd[1];
+        const uint32_t o0 = pd[2] & 0xFFFFu, o1 = pd[2] >> 16, o2 = pd[3] & 0xFFFFu, o3 = pd[3] >> 16;
+        const uint32_t self_off = pd[4] & 0xFFFFu, ctl = (pd[5] >> 16) & 0xFFu;      // (pd[4] >> 16: the window's first column group, for whoever reads this row later)
+        const uint32_t dl = STRIP ? 0u : pd[5] & 0xFFu;
+        ent_t e0, e1, e2, e3;
+        issue(o0, e0); issue(o1, e1); issue(o2, e2); issue(o3, e3);
+        // STRIP: what the strip to the left says about this row: its last H (low half) and the prefix maximum of u up to there (high half)
+        uint32_t hl_row = 0, sb_row = sbase;
+        if constexpr (STRIP) {
+            if (strip) {
+                uint32_t cw = cw_next;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cw) : : "memory");
+                hl_row = cw << 16;                                           // as the high half of a pair word: the column left of lane 0's first
+                sb_row = (cw >> 16) | (cw & 0xFFFF0000u);
+                uint64_t pc = (uint64_t)(cin + 4 * (uint64_t)(row + 1u));
+                asm volatile("" : "+s"(pc));
+                cw_next = *(cdw_t)pc;
+            }
+        }
+        if (dl) {                                // the window moves on by dl column groups
+            g0 += dl;
+            const s16x2 dj = pk_splat((int)(dl * CPLB) * POA_E);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { JE[u] = JE[u] + dj; UC[u] = UC[u] - dj; }
+            const uint32_t va = va_sel + g0 * (uint32_t)(NP * 4);
+            if constexpr (NP == 1) asm volatile("ds_read_b32 %0, %1" : "=&v"(SEL[0]) : "v"(va) : "memory");
+            else if constexpr (NP == 2) { u32x2 t2; asm volatile("ds_read_b64 %0, %1" : "=&v"(t2) : "v"(va) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t2) : : "memory"); SEL[0] = t2.x; SEL[1] = t2.y; }
+            else { u32x4 t4; asm volatile("ds_read_b128 %0, %1" : "=&v"(t4) : "v"(va) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t4) : : "memory"); SEL[0] = t4.x; SEL[1] = t4.y; SEL[2] = t4.z; SEL[3] = t4.w; }
+            const uint32_t ub = (uint32_t)((int32_t)(g0 * CPLB + 1u) * -POA_E + POA_G) & 0xFFFFu;      // 0 + g - (c + 1) e, c = g0 * CPLB
+            sbase = ub | (ub << 16);
+        }
+        if constexpr (NP == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(SEL[0]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        land4(e0, e1, e2, e3);
+        s16x2 HM[NP], FM[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            HM[u] = pk_max(pk_max(as_pk(e0[u]), as_pk(e1[u])), pk_max(as_pk(e2[u]), as_pk(e3[u])));
+            FM[u] = pk_max(pk_max(as_pk(e0[NP + u]), as_pk(e1[NP + u])), pk_max(as_pk(e2[NP + u]), as_pk(e3[NP + u])));
+        }
+        if (ctl & BD_MORE4) {
+            issue(pd[6] & 0xFFFFu, e0); issue(pd[6] >> 16, e1); issue(pd[7] & 0xFFFFu, e2); issue(pd[7] >> 16, e3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            land4(e0, e1, e2, e3);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                HM[u] = pk_max(pk_max(HM[u], as_pk(e0[u])), pk_max(pk_max(as_pk(e1[u]), as_pk(e2[u])), as_pk(e3[u])));
+                FM[u] = pk_max(pk_max(FM[u], as_pk(e0[NP + u])), pk_max(pk_max(as_pk(e1[NP + u]), as_pk(e2[NP + u])), as_pk(e3[NP + u])));
+            }
+        }
+        {   // the record of the next row, behind this row's LDS wait (lgkmcnt counts scalar loads too)
+            uint64_t pp = (uint64_t)(cpm + row);
+            uint32_t dep = as_u(HM[0]);
+            asm volatile("" : "+s"(pp), "+v"(dep));
+            HM[0] = as_pk(dep);
+            nx = *(cplanm_t)pp;
+        }
+        if (ctl & BD_SLOW) {
+            // in-edges whose terms are not in the ring (too far back, or the window has moved on by more than the pad) and in-edges
+            // after the eighth: their record words from HBM, decoded into the ring's terms
+            const uint32_t farmask = (pd[5] >> 8) & 0xFFu;
+            uint32_t n_all = pd[5] >> 24;
+            if (n_all == 255u) { n_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)rd_nin(S.plan[row - 1].x)); drain_vector_loads(); }      // (the byte saturates)
+            if (ctl & BD_NOBASE) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { HM[u] = pk_splat(0); FM[u] = pk_splat(POA_G - POA_E); }
+            }
+            auto far_fetch = [&](const uint32_t prow) __attribute__((always_inline)) {
+                uint32_t gp = STRIP ? (strip ? cin[4 * (uint64_t)prow] : 0u) : cpm[prow - 1][4];      // (scalar load) row prow's record: its window's first group (STRIP: its dword from the left)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(gp));
+                const uint32_t dlt = STRIP ? 0u : g0 - (gp >> 16);                // (wave-uniform) the window has moved on by dlt groups since row prow
+                const uint32_t lp = (uint32_t)lane + dlt;
+                const bool in = lp < 64u;
+                const uint64_t prow_s = (uint64_t)prow + (STRIP ? (uint64_t)strip * (n + 1u) : 0u);
+                const gptr_t hq = Hrec + (prow_s * 64u + (in ? lp : 0u)) * NP;
+                const bool need_left = !STRIP && lane == 0 && dlt >= 1u && dlt <= 64u;
+                uint32_t hl16 = ((gptr16_t)Hrec)[need_left ? (prow_s * 64u + dlt) * CPLB - 1u : 0u];
+                if constexpr (STRIP) hl16 = gp & 0x3FFFu;                      // the H of row prow left of this strip
+                uint32_t x[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { const uint32_t v = hq[u]; x[u] = in ? v : 0x80008000u; }      // outside row prow's window: H = 0, H - F >= 2
+                const uint32_t wl = (need_left || STRIP) ? (hl16 & 0x3FFFu) << 16 : 0u;
+                drain_vector_loads();
+                uint32_t hp[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    hp[u] = x[u] & 0x3FFF3FFFu;
+                    u16x2 wu;
+                    __builtin_memcpy(&wu, &x[u], 4);
+                    const u16x2 d = __builtin_elementwise_min(wu >> (u16x2){14, 14}, (u16x2){2, 2});
+                    s16x2 ds;
+                    __builtin_memcpy(&ds, &d, 4);
+                    FM[u] = pk_max(FM[u], as_pk(hp[u]) - ds);
+                }
+                const uint32_t left = (uint32_t)wave_shr1((int32_t)hp[NP - 1], (int32_t)wl);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) HM[u] = pk_max(HM[u], pk_left(hp[u], u == 0 ? left : hp[u - 1]));
+            };
+            const cplan_t cpb = (cplan_t)uni64((uint64_t)S.planb), cpc = (cplan_t)uni64((uint64_t)S.planc);
+            for (uint32_t k = 0; k < 8 && k < n_all; ++k) {
+                if (!((farmask >> k) & 1u)) continue;
+                uint32_t prow = k >= 4 ? cpc[row - 1][k - 4] : cpb[row - 1][k];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(prow));
+                far_fetch(prow);
+            }
+            if (n_all > 8) {
+                uint32_t e = S.plan[row - 1].w;
+                e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+                drain_vector_loads();
+                for (uint32_t k = 8; k < n_all; ++k) {
+                    const uint2 ed = S.edges[e]; e = ed.y;
+                    const uint32_t prow = (uint32_t)__builtin_amdgcn_readfirstlane(S.rank[ed.x]) + 1;
+                    drain_vector_loads();
+                    far_fetch(prow);
+                }
+            }
+        }
+        s16x2 HNp[NP], EX[NP], FN[NP];
+        s16x2 RUN = pk_splat(-32768);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const s16x2 SC = as_pk(__builtin_amdgcn_perm(khi, klo, SEL[u]));
+            FN[u] = FM[u] + pk_splat(POA_E);
+            HNp[u] = pk_max(pk_max(HM[u] + SC, FN[u]), pk_splat(0));
+            const s16x2 v = pk_max(RUN, HNp[u] + UC[u]);
+            EX[u] = as_pk(__builtin_amdgcn_alignbit(as_u(v), as_u(RUN), 16));
+            RUN = pk_max(v, __builtin_shufflevector(v, v, 1, 0));
+        }
+        const uint32_t wincl = wave_scan_max_dup(as_u(RUN));
+        const uint32_t texcl = (uint32_t)wave_shr1((int32_t)wincl, (int32_t)0x80008000u);
+        const s16x2 BASE = pk_max(as_pk(texcl), as_pk(STRIP ? sb_row : sbase));
+        s16x2 HN[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) HN[u] = pk_max(HNp[u], pk_max(BASE, EX[u]) + JE[u]);
+        {
+            const uint32_t left = (uint32_t)wave_shr1((int32_t)as_u(HN[NP - 1]), (int32_t)hl_row);       // lane 0: the column left of the window holds H = 0 (STRIP: what the strip to the left computed)
+            uint32_t R[2 * NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                R[u] = as_u(pk_left(as_u(HN[u]), u == 0 ? left : as_u(HN[u - 1])));
+                R[NP + u] = as_u(pk_max(HN[u] - pk_splat(2), FN[u]));
+            }
+            if constexpr (NP == 1) { typedef __attribute__((address_space(3))) u32x2 *e2_p; u32x2 v; v.x = R[0]; v.y = R[1]; *(e2_p)(uintptr_t)(rb + self_off) = v; }
+            else {
+                typedef __attribute__((address_space(3))) u32x4 *e4_p;
+#pragma unroll
+                for (int q = 0; q < NP / 2; ++q) { u32x4 v; v.x = R[4 * q]; v.y = R[4 * q + 1]; v.z = R[4 * q + 2]; v.w = R[4 * q + 3]; ((e4_p)(uintptr_t)(rb + self_off))[q] = v; }
+            }
+            if constexpr (!STRIP) {
+                // the entry right of the window: its diagonal source is the H of this row's last column (lane 63; the others hit junk words)
+                *(volatile lds_p)(uintptr_t)(a_pad + (lane == 63 ? self_off : 0u)) = as_u(HN[NP - 1]) >> 16;
+            } else {
+                // for the strip to the right: this row's last H and the prefix maximum of u over every column so far (lane 63 stores)
+                const uint32_t tc = (uint32_t)max((int32_t)sb_row, __builtin_amdgcn_readlane((int32_t)wincl, 63));
+                if (lane == 63) cout[4 * (uint64_t)row] = (as_u(HN[NP - 1]) >> 16) | (tc << 16);
+            }
+            uint32_t W[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u)
+                asm("v_lshl_or_b32 %0, %1, 14, %2" : "=v"(W[u]) : "v"(as_u(pk_min(HN[u] - FN[u], pk_splat(3)))), "v"(as_u(HN[u])));
+            if constexpr (NP == 1) hrow[0] = W[0];
+            else if constexpr (NP == 2) { typedef __attribute__((address_space(1))) u32x2 *gptr2_t; u32x2 w2; w2.x = W[0]; w2.y = W[1]; *(gptr2_t)hrow = w2; }
+            else { typedef __attribute__((address_space(1))) u32x4 *gptr4_t; u32x4 w4; w4.x = W[0]; w4.y = W[1]; w4.z = W[2]; w4.w = W[3]; *(gptr4_t)hrow = w4; }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) MXA = pk_max(MXA, HN[u]);
+        }
+        hrow += 64u * NP;
+    };
+
+    {
+        u32x8 pa = cpm[0], pb = pa;
+        uint32_t row = 1;
+        drain_vector_loads();                    // nothing pending at the loop's entry: the compiler then has no reason for a vmcnt wait inside (which would wait for the record stores)
+        while (row <= n) {
+            step(row, pa, pb);
+            ++row;
+            if (row > n) break;
+            step(row, pb, pa);
+            ++row;
+        }
+    }
+    if constexpr (STRIP) { if (mxa_out) *mxa_out = MXA; drain_vector_loads(); }      // (the dwords for the next strip are in memory)
+    // best score and the lanes whose cells reach it (columns beyond the sequence score -1 per diagonal move: every such cell is smaller
+    // than some valid one, so they need no masking; their rows and columns come from a rescan of the record, kernel body)
+    const int32_t lbest = max((int32_t)(int16_t)(as_u(MXA) & 0xFFFFu), (int32_t)as_u(MXA) >> 16);
+    best = wave_last(wave_scan_max(lbest, 0));
+    if (lane == 0) { X.best[0] = best; X.brow = 0xFFFFFFFFu; X.multi = 1; X.ntl = 0; }
+    wave_sync();
+    if (best > 0 && lbest == best) {
+        const uint32_t slot = atomicAdd(&X.ntl, 1u);
+        if (slot < 16) X.tl[slot] = (uint32_t)lane;
+    }
+}
+
 // ---- rows of 2561 .. 8192 columns (PK == 3): 32-bit cells, up to SIXTEEN wavefronts per pack ------------------
 // A pack of long reads used to be one workgroup of four wavefronts with 16-32 columns per lane in 250-410 registers: one
 // wavefront per SIMD, one pack per CU, tens of seconds per pack while most of the device idled (config 5).  Here the row is
@@ -1504,7 +1818,7 @@ __device__ void dp_rows_wide(poa_ws &S, dp_xchg &X, uint32_t n, uint32_t L, uint
     int32_t lbest = 0;
     const int32_t je0 = ((int32_t)c0 + 1) * POA_E;                      // j * e of the thread's first column
 
-    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb;
+    uint64_t ppa = uni64((uint64_t)S.plan), ppb = uni64((uint64_t)S.planb);
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb) : : "memory");
     const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb;
 
@@ -1818,7 +2132,7 @@ __device__ void dp_rows_longr(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t 
     uint32_t *const lhr = (uint32_t *)S.lh_ring + wave;                // slot s of this wavefront: lhr[NW * s]
     int32_t lbest = 0;
     uint32_t lrow = 0, lcnt = 0;                     // first row in which this thread's columns reach lbest, and in how many (row, segment) steps they do
-    uint64_t ppa = (uint64_t)S.plan, ppb = (uint64_t)S.planb;
+    uint64_t ppa = uni64((uint64_t)S.plan), ppb = uni64((uint64_t)S.planb);
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(ppa), "+s"(ppb) : : "memory");
     const cplan_t cpa = (cplan_t)ppa, cpb = (cplan_t)ppb;
 
@@ -2019,7 +2333,7 @@ __device__ void dp_rows_longr(poa_ws &S, dp_xchg &X, const uint8_t *s, uint32_t 
 }
 
 // ---- graph update helpers (lane 0) --------------------------------------------------------------
-__device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
+__device__ __forceinline__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
     if (S.n_nodes >= A.node_cap) { S.err = POA_ERR_NODES; return 0; }
     S.nrec[S.n_nodes] = make_uint4(letter, 0, POA_NONE, POA_NONE);
     return S.n_nodes++;
@@ -2027,7 +2341,7 @@ __device__ uint32_t g_add_node(poa_ws &S, const poa_args &A, uint8_t letter) {
 
 // Graph::add_edge: nothing if begin->end exists, else append to end's in-edge list.  Called by
 // many threads at once for DISTINCT end nodes; edge slots come from an LDS counter.
-__device__ void g_add_edge(poa_ws &S, const poa_args &A, uint32_t b, uint32_t en, uint32_t *edge_counter, uint32_t *err) {
+__device__ __forceinline__ void g_add_edge(poa_ws &S, const poa_args &A, uint32_t b, uint32_t en, uint32_t *edge_counter, uint32_t *err) {
     uint4 nd = S.nrec[en];
     const uint32_t n_in = rd_nin(nd.x);
     if (n_in > 0) {
@@ -2051,7 +2365,7 @@ __device__ void g_add_edge(poa_ws &S, const poa_args &A, uint32_t b, uint32_t en
 }
 
 // Graph::add_sequence(b, e): fresh chain; returns first node or -1.  Records the path.
-__device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, uint32_t b, uint32_t e, uint32_t *path) {
+__device__ __forceinline__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, uint32_t b, uint32_t e, uint32_t *path) {
     if (b == e) return -1;
     const uint32_t first = g_add_node(S, A, s[b]);
     if (S.err) return -1;
@@ -2067,8 +2381,11 @@ __device__ int32_t g_add_chain(poa_ws &S, const poa_args &A, const uint8_t *s, u
 
 // PK: 0 = 32-bit registers + int16 record + nibbles (dp_rows), 1 = packed int16 pairs, record word H | min(H-F,3) << 14 (dp_rows_v3),
 // 2 = int32 segments (dp_rows_long / _longr), 3 = 32-bit cells on up to 16 wavefronts (dp_rows_wide),
-// 7 = the same record written by teams of wavefronts (dp_rows_mt): the RING template argument is the number of TEAMS, the ring is sized at launch
-__host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 7; }
+// 7 = the same record written by teams of wavefronts (dp_rows_mt): the RING template argument is the number of TEAMS, the ring is sized at launch,
+// 8 = the exact band for near-chain graphs ALONE (dp_rows_band on one wavefront, the record word of PK 1 in band layout): a light kernel of one or four
+//     wavefronts per pack for any length up to 2560; a pack with an alignment whose band cannot be certified fails with POA_ERR_BAND and is run again by
+//     the full-row kernels (the host's retry loop).  CPL and RING of a PK 8 instance mean nothing.
+__host__ __device__ constexpr bool pk_packed(int PK) { return PK == 1 || PK == 7 || PK == 8; }
 __host__ __device__ constexpr bool pk_readymade(int PK) { return PK == 7; }
 __host__ __device__ constexpr int pk_teams(int RING, int PK) { return PK == 7 ? RING : 1; }
 __host__ __device__ constexpr uint32_t mt_slot_bytes(int CPL, int NW) { return 64u * NW * CPL * 4u; }      // one ring slot of dp_rows_mt: 4 bytes per cell
@@ -2085,8 +2402,9 @@ __host__ __device__ constexpr uint32_t poa_region_bytes(uint32_t node_cap, int C
 // minimum wavefronts per SIMD the register allocation is held to (the kernel is bound by the latency of a row's dependent
 // instruction chain, hidden only by other resident wavefronts: occupancy first)
 constexpr int poa_min_waves(int CPL, int NW, int PK, int RING_OR_T = 1) {
-    return PK == 7 ? (RING_OR_T == 2 && CPL == 4 ? MT2_MINWAVES : 4)
-         : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : 1;
+    return PK == 8 ? 4
+         : PK == 7 ? (RING_OR_T == 2 && CPL == 4 ? MT2_MINWAVES : 4)
+         : PK == 3 ? (NW == 12 ? 3 : 4) : PK == 2 ? 1 : NW == 4 && CPL == 4 ? (PK ? POA_MW_4x4 : 5) : NW == 4 && CPL == 6 ? (PK ? POA_MW_4x6 : 4) : 1;      // (PK 8 as PK 1)
 }
 template <int CPL, int RING, int NW, int PK>
 __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW, PK, RING)) void poa_kernel(poa_args A) {
@@ -2117,10 +2435,10 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
         S.done = lds + A.seq_cap / 4; S.nocheck = S.done + bit_words; S.stack = S.nocheck + bit_words;
         S.hist = A.counters;
         S.ring = S.stack + POA_STACK;
-        S.lh_ring = (int32_t *)(S.ring + (size_t)(PK == 7 ? 0 : RING) * NT * poa_ring_words(CPL, NW, PK));
+        S.lh_ring = (int32_t *)(S.ring + (size_t)(PK == 7 || PK == 8 ? 0 : RING) * NT * poa_ring_words(CPL, NW, PK));
     }
     // bytes of the LDS ring (between two DPs: room for the tie labels and the traceback's chain)
-    const uint32_t ring_bytes = PK == 7 ? A.ring_slots * mt_slot_bytes(CPL, NW) : poa_ring_bytes(CPL, RING, NW, PK);
+    const uint32_t ring_bytes = PK == 8 ? A.band : PK == 7 ? A.ring_slots * mt_slot_bytes(CPL, NW) : poa_ring_bytes(CPL, RING, NW, PK);
 
     while (true) {
         __syncthreads();
@@ -2134,6 +2452,12 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
         S.n_nodes = 0; S.n_edges = 0; S.err = 0; S.sp = 0; S.spilled = 0;
         if (tid == 0) s_alpha = 0;
         unsigned long long cells = 0, rows = 0, t_topo = 0, t_dp = 0, t_tb = 0, t_add = 0, t_tie = 0, t_merge = 0;
+        // the exact band (PK == 8): cells really computed, alignments whose band was certified / whose certificate failed, the t of the last
+        // certified alignment of this pack (the next one asks for twice that), and the band of the alignment in hand
+        unsigned long long cells_done = 0;
+        uint32_t n_band_ok = 0, n_band_fail = 0, n_strip_aln = 0, bd_thist = 0, bd_sh = 0, bd_strip = 0;      // bd_strip != 0: the record is strip-major, bd_strip rows per strip
+        bool band_on = false;
+        (void)n_band_ok; (void)n_band_fail; (void)n_strip_aln; (void)bd_thist; (void)bd_sh; (void)bd_strip;
         (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add; (void)t_tie; (void)t_merge;
         const unsigned long long t_pack0 = PT_NOW();
         (void)t_pack0;
@@ -2160,7 +2484,7 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
             if (S.n_nodes > 0) {
                 const uint32_t n = S.n_nodes;
                 const uint32_t Lp = (L + CPL - 1) / CPL * CPL;
-                if ((uint64_t)(n + 1) * Lp > A.cell_cap || (PK != 2 && Lp > NTC * CPL)) { S.err = POA_ERR_CELLS; break; }
+                if (PK == 8 ? ((uint64_t)(n + 1) * 512u > A.cell_cap || L > 2560u) : ((uint64_t)(n + 1) * Lp > A.cell_cap || (PK != 2 && Lp > NTC * CPL))) { S.err = POA_ERR_CELLS; break; }
                 // ---- 1. rows are taken in the incrementally maintained block order (merge_order) ----
                 unsigned long long t0 = PT_NOW();
                 // ---- 2. plan + sequence to LDS (all threads) ----
@@ -2251,13 +2575,209 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                 // ---- 3. DP (4 waves) ----
                 int32_t best; uint32_t best_row;
                 bool multi = false;
-                if constexpr (PK == 2 && RING > 0) dp_rows_longr<CPL, RING, NW>(S, X, s, n, L, Lp, best, best_row, multi);
+                band_on = false; bd_strip = 0;
+                if constexpr (PK == 8) {
+                    // ---- 3a. the exact band (dp_rows_band): near-chain graphs, one wavefront, certificate checked behind the rows ----
+                    if (S.plain) {
+                        // ---- the MSA column of every row (block order: the rows of an aligned group are contiguous and share a column) ----
+                        // a row opens a column iff none of its group mates has a smaller row; columns = the running count.  col[] goes to
+                        // rowmax[] (idle until the rescan behind the DP), one flag byte per row to the band's LDS (idle until the attempt)
+                        uint8_t *flag = (uint8_t *)S.ring;
+                        int32_t *colr = S.rowmax;                       // colr[row], row = 1 .. n
+                        const uint32_t chunk = (n + NT - 1u) / NT;
+                        bool fits_flags = n <= ring_bytes;
+                        if (fits_flags) {
+                            for (uint32_t r = tid; r < n; r += NT) {
+                                const uint4 pl = S.plan[r];
+                                const uint32_t n_al = rd_nal(pl.x);
+                                uint32_t first = 1;
+                                if (n_al) {
+                                    const uint4 al = S.nal[pl.y];
+                                    for (uint32_t k = 0; k < n_al; ++k) if ((uint32_t)S.rank[u4_get(al, k)] < r) first = 0;
+                                }
+                                flag[r] = (uint8_t)first;
+                            }
+                            __syncthreads();
+                            uint32_t cnt = 0;
+                            for (uint32_t i = tid * chunk; i < min(n, (tid + 1u) * chunk); ++i) cnt += flag[i];
+                            const uint32_t incl = wave_scan_add(cnt);
+                            if ((tid & 63) == 63) s_bc[(tid >> 6) & 7] = incl;          // (NT / 64 <= 4 wavefronts)
+                            __syncthreads();
+                            uint32_t off = incl - cnt;
+                            for (uint32_t w = 0; w < (uint32_t)(tid >> 6); ++w) off += s_bc[w];
+                            uint32_t tot = 0;
+                            for (uint32_t w = 0; w < NT / 64u; ++w) tot += s_bc[w];
+                            for (uint32_t i = tid * chunk; i < min(n, (tid + 1u) * chunk); ++i) { off += flag[i]; colr[i + 1] = (int32_t)off; }
+                            __syncthreads();
+                            if (tid == 0) { s_bc[0] = tot; s_bc[1] = 0; }
+                            __syncthreads();
+                        }
+                        // (wave-uniform numbers the compiler cannot know to be uniform -- they come through LDS -- are declared so: the band's
+                        // row loop addresses its plan through the scalar cache)
+                        const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n), Lu = (uint32_t)__builtin_amdgcn_readfirstlane((int)L), rbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_bytes);
+                        const uint32_t Cu = fits_flags ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_bc[0]) : 0u;      // columns of the graph
+                        uint32_t t_want = max(8u, 2u * bd_thist + 4u);
+                        for (uint32_t bsh = 1; bsh <= 3u && !band_on && fits_flags; ++bsh) {
+                            const uint32_t cplb = 1u << bsh;
+                            const int32_t room = (int32_t)(63u * cplb) - 1 - ((int32_t)Cu - (int32_t)Lu);      // C - L + 2 t + 1 <= 63 cplb
+                            if (room < 0) continue;
+                            const uint32_t t = min((uint32_t)room >> 1, Lu - 1u);      // all the room there is: the window costs the same
+                            // (tau = L - t <= C: some path may have tau diagonal moves.)  Two columns per lane only when the room they leave is what the
+                            // last certified alignment of this pack needed twice over; four or eight columns per lane with whatever room there is
+                            if ((bsh == 1u && t < t_want) || (int32_t)Cu < (int32_t)Lu - (int32_t)t) continue;
+                            const uint32_t bs = Cu + t - Lu;
+                            const uint32_t Lpb = (Lu + cplb - 1u) & ~(cplb - 1u);
+                            uint32_t brs = 16;
+                            while (brs >= 2u && band_lds_bytes(brs, (int)cplb, Lpb) > rbu) brs >>= 1;
+                            if (brs < 2u) continue;
+                            const uint32_t eb = 4u * cplb, slotb = (64u + BAND_PAD) * eb, np = cplb >> 1;
+                            const uint32_t sel_off = brs * slotb, junk_off = sel_off + (Lpb / cplb + 66u) * np * 4u;
+                            // the rows' band records: ring offsets of the in-edges with the lane shift folded in (see dp_rows_band)
+                            for (uint32_t r = tid; r < n; r += NT) {
+                                const uint32_t row = r + 1u;
+                                const uint4 pl = S.plan[r], pb = S.planb[r], pc = S.planc[r];
+                                const uint32_t n_in = rd_nin(pl.x);
+                                const uint32_t cr = (uint32_t)colr[row];
+                                const uint32_t g = band_g0(cr, bs, bsh), gprev = row > 1u ? band_g0((uint32_t)colr[row - 1u], bs, bsh) : 0u;
+                                uint32_t po[8], farmask = 0, base = 0xFFFFFFFFu;
+                                bool bad = false;
+#pragma unroll
+                                for (uint32_t k = 0; k < 8; ++k) {
+                                    po[k] = 0xFFFFFFFFu;
+                                    if (k < n_in) {
+                                        const uint32_t prow = k < 4 ? u4_get(pb, k) : u4_get(pc, k - 4);
+                                        const uint32_t cp = (uint32_t)colr[prow];
+                                        bad |= cp >= cr;                       // an edge that does not lead to a later column: the bound above does not hold
+                                        const uint32_t d = g - band_g0(cp, bs, bsh);
+                                        if (row - prow <= brs && d <= BAND_PAD) { po[k] = (prow & (brs - 1u)) * slotb + d * eb; if (base == 0xFFFFFFFFu) base = po[k]; }
+                                        else farmask |= 1u << k;
+                                    }
+                                }
+                                if (n_in > 8) {
+                                    uint32_t e = pl.w;
+                                    for (uint32_t k = 8; k < n_in; ++k) { const uint2 ed = S.edges[e]; e = ed.y; bad |= (uint32_t)colr[(uint32_t)S.rank[ed.x] + 1u] >= cr; }
+                                }
+                                if (bad) s_bc[1] = 1;
+                                const bool nobase = base == 0xFFFFFFFFu;
+                                if (nobase) base = (row & (brs - 1u)) * slotb;
+#pragma unroll
+                                for (uint32_t k = 0; k < 8; ++k) if (po[k] == 0xFFFFFFFFu) po[k] = base;
+                                const uint32_t letter = rd_letter(pl.x), li = (letter >> 1) & 3u;
+                                const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));
+                                const uint32_t ctl = (n_in > 4 ? BD_MORE4 : 0u) | ((farmask || n_in > 8 || nobase) ? BD_SLOW : 0u) | (nobase ? BD_NOBASE : 0u);
+                                uint4 *pm = (uint4 *)(S.planm + 8 * (size_t)r);
+                                pm[0] = make_uint4(klo, khi, po[0] | po[1] << 16, po[2] | po[3] << 16);
+                                pm[1] = make_uint4(((row & (brs - 1u)) * slotb) | g << 16, min(g - gprev, 255u) | farmask << 8 | ctl << 16 | min(n_in, 255u) << 24, po[4] | po[5] << 16, po[6] | po[7] << 16);
+                            }
+                            __syncthreads();                             // (the flag bytes have been read: the ring's LDS may be written)
+                            // what lies right of a row's window (neutral terms), and the score selectors of every column pair
+                            for (uint32_t i = tid; i < brs * BAND_PAD * 2u * np; i += NT) {
+                                const uint32_t w = i % (2u * np), en = (i / (2u * np)) % BAND_PAD, sl = i / (2u * np * BAND_PAD);
+                                S.ring[(sl * slotb + (64u + en) * eb) / 4u + w] = w < np ? 0u : 0xFFFEFFFEu;      // A = 0, B = g - e
+                            }
+                            for (uint32_t i = tid; i < (Lpb / cplb + 66u) * np; i += NT) {
+                                const uint32_t c = 2u * i;
+                                const uint32_t ca = c < L ? S.sq[c] : 0u, cb = c + 1u < L ? S.sq[c + 1u] : 0u;
+                                const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
+                                const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
+                                S.ring[sel_off / 4u + i] = sa | (sb << 16);
+                            }
+                            __syncthreads();
+                            if (s_bc[1]) break;                          // (uniform) the columns do not order this graph's edges: no band
+                            if (w0) {
+                                int32_t bb = 0;
+                                if (bsh == 1u) dp_rows_band<2>(S, X, nu, brs, sel_off, junk_off, bb);
+                                else if (bsh == 2u) dp_rows_band<4>(S, X, nu, brs, sel_off, junk_off, bb);
+                                else dp_rows_band<8>(S, X, nu, brs, sel_off, junk_off, bb);
+                            }
+                            __syncthreads();
+                            const int32_t bb = __builtin_amdgcn_readfirstlane(X.best[0]);
+                            cells_done += (unsigned long long)n * 64u * cplb;
+                            if (bb >= 5 * (int32_t)(Lu - t) - 4) {      // the certificate: nothing outside the band can reach this score
+                                band_on = true; bd_sh = bsh;
+                                best = bb; best_row = 0; multi = true;
+                                bd_thist = (5u * Lu - (uint32_t)bb) / 5u;
+                                ++n_band_ok;
+                            } else {
+                                ++n_band_fail;
+                                t_want = bb > 0 ? (5u * Lu - (uint32_t)bb) / 5u : Lu;      // the smallest t whose certificate this score passes
+                                // the flag bytes are gone (the ring's LDS was used): the next, wider attempt needs only col[], which is in memory
+                            }
+                            __syncthreads();
+                        }
+                        // ---- 3b. no band: the full rows as vertical strips of 512 columns on the same row loop (dp_rows_band<8, true>), exact without a
+                        // certificate.  Only for a pack that HAS been running in the band (a pack of noisy reads belongs to the full-row kernels,
+                        // which spread a row over four to sixteen wavefronts); A.debug bit 3: always (tests)
+                        const bool strips_ok = (A.debug & 8u) || (n_band_ok >= 8u && 4u * n_band_ok >= (q - q0));
+                        const uint32_t n_strips = (Lu + 511u) >> 9;
+                        if (!band_on && strips_ok && !s_bc[1] && (uint64_t)n_strips * (nu + 1u) * 512u <= A.cell_cap) {
+                            const uint32_t Lpb = (Lu + 7u) & ~7u;
+                            uint32_t brs = 16;
+                            while (brs >= 2u && band_lds_bytes(brs, 8, Lpb) > rbu) brs >>= 1;
+                            if (brs >= 2u) {
+                                const uint32_t eb = 32u, slotb = (64u + BAND_PAD) * eb;
+                                const uint32_t sel_off = brs * slotb, junk_off = sel_off + (Lpb / 8u + 66u) * 16u;
+                                for (uint32_t r = tid; r < n; r += NT) {
+                                    const uint32_t row = r + 1u;
+                                    const uint4 pl = S.plan[r], pb = S.planb[r], pc = S.planc[r];
+                                    const uint32_t n_in = rd_nin(pl.x);
+                                    uint32_t po[8], farmask = 0, base = 0xFFFFFFFFu;
+#pragma unroll
+                                    for (uint32_t k = 0; k < 8; ++k) {
+                                        po[k] = 0xFFFFFFFFu;
+                                        if (k < n_in) {
+                                            const uint32_t prow = k < 4 ? u4_get(pb, k) : u4_get(pc, k - 4);
+                                            if (row - prow <= brs) { po[k] = (prow & (brs - 1u)) * slotb; if (base == 0xFFFFFFFFu) base = po[k]; }
+                                            else farmask |= 1u << k;
+                                        }
+                                    }
+                                    const bool nobase = base == 0xFFFFFFFFu;
+                                    if (nobase) base = (row & (brs - 1u)) * slotb;
+#pragma unroll
+                                    for (uint32_t k = 0; k < 8; ++k) if (po[k] == 0xFFFFFFFFu) po[k] = base;
+                                    const uint32_t letter = rd_letter(pl.x), li = (letter >> 1) & 3u;
+                                    const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));
+                                    const uint32_t ctl = (n_in > 4 ? BD_MORE4 : 0u) | ((farmask || n_in > 8 || nobase) ? BD_SLOW : 0u) | (nobase ? BD_NOBASE : 0u);
+                                    uint4 *pm = (uint4 *)(S.planm + 8 * (size_t)r);
+                                    pm[0] = make_uint4(klo, khi, po[0] | po[1] << 16, po[2] | po[3] << 16);
+                                    pm[1] = make_uint4((row & (brs - 1u)) * slotb, farmask << 8 | ctl << 16 | min(n_in, 255u) << 24, po[4] | po[5] << 16, po[6] | po[7] << 16);
+                                }
+                                for (uint32_t i = tid; i < (Lpb / 8u + 66u) * 4u; i += NT) {
+                                    const uint32_t c = 2u * i;
+                                    const uint32_t ca = c < L ? S.sq[c] : 0u, cb = c + 1u < L ? S.sq[c + 1u] : 0u;
+                                    const uint32_t ia = (ca >> 1) & 3u, ib = (cb >> 1) & 3u;
+                                    const uint32_t sa = ca ? (ia | ((ia + 4u) << 8)) : 0x0D0Du, sb = cb ? (ib | ((ib + 4u) << 8)) : 0x0D0Du;
+                                    S.ring[sel_off / 4u + i] = sa | (sb << 16);
+                                }
+                                __syncthreads();
+                                s16x2 mx = pk_splat(0);
+                                for (uint32_t k = 0; k < n_strips; ++k) {
+                                    if (w0) { int32_t bb = 0; dp_rows_band<8, true>(S, X, nu, brs, sel_off, junk_off, bb, k, mx, &mx); }
+                                    __syncthreads();
+                                }
+                                band_on = true; bd_sh = 3; bd_strip = nu + 1u;
+                                best = __builtin_amdgcn_readfirstlane(X.best[0]); best_row = 0; multi = true;
+                                cells_done += (unsigned long long)n * 512u * n_strips;
+                                ++n_strip_aln;
+                            }
+                        }
+                    }
+                }
+                if constexpr (PK == 8) {
+                    if (!band_on) {
+                        // (diagnosis for RATTLE_TIMING: which alignment lost the band, and by how much)
+                        if (tid == 0) { A.counters[14] = (unsigned long long)n | ((unsigned long long)L << 32); A.counters[15] = (unsigned long long)(q - q0) | ((unsigned long long)X.best[0] << 32); }
+                        S.err = POA_ERR_BAND; break;
+                    }
+                }
+                else if constexpr (PK == 2 && RING > 0) dp_rows_longr<CPL, RING, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 2) dp_rows_long<CPL, NW>(S, X, s, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 3) dp_rows_wide<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 7) dp_rows_mt<CPL, NW, RING>(S, X, A, n, L, Lp, best, best_row, multi);
                 else if constexpr (PK == 1) dp_rows_v3<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 else dp_rows<CPL, RING, NW>(S, X, n, L, Lp, best, best_row, multi);
                 cells += (unsigned long long)n * L;
+                if (PK != 8) cells_done += (unsigned long long)n * L;
                 rows += n;
                 unsigned long long t2 = PT_NOW();
                 t_dp += t2 - t1;
@@ -2270,7 +2790,28 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                         for (uint32_t r = 1 + tid; r <= n; r += NT) S.rowmax[r] = 0;
                         __syncthreads();
                         const uint32_t ntl = X.ntl;
-                        if (PK != 2 && ntl <= 16) {
+                        if (PK == 8 && band_on) {
+                            // the band record: 64 << bd_sh cells per row; lane t of a row holds its window's column group t
+                            const uint32_t cw = 1u << bd_sh;
+                            const uint16_t *Hh = (const uint16_t *)S.H;
+                            const uint32_t ns = bd_strip ? (L + 511u) >> 9 : 1u;      // (strips: a lane holds a column group in every strip)
+                            if (ntl <= 16) {
+                                for (uint32_t idx = tid; idx < n * ntl; idx += NT) {
+                                    const uint32_t r = idx / ntl + 1, t = X.tl[idx % ntl];
+                                    bool hit = false;
+                                    for (uint32_t k = 0; k < ns; ++k)
+                                        for (uint32_t u = 0; u < cw; ++u) hit |= (int32_t)(Hh[((((uint64_t)k * bd_strip + r) * 64u + t) << bd_sh) + u] & 0x3FFF) == best;
+                                    if (hit) { S.rowmax[r] = 1; atomicMin(&X.brow, r); }
+                                }
+                            } else {
+                                for (uint32_t r = 1 + (uint32_t)(tid >> 6); r <= n; r += NT / 64) {
+                                    bool hit = false;
+                                    for (uint32_t k = 0; k < ns; ++k)
+                                        for (uint32_t c = tid & 63; c < 64u * cw; c += 64) hit |= (int32_t)(Hh[((((uint64_t)k * bd_strip + r) * 64u) << bd_sh) + c] & 0x3FFF) == best;
+                                    if (hit) { S.rowmax[r] = 1; atomicMin(&X.brow, r); }
+                                }
+                            }
+                        } else if (PK != 2 && ntl <= 16) {
                             for (uint32_t idx = tid; idx < n * ntl; idx += NT) {
                                 const uint32_t r = idx / ntl + 1, t = X.tl[idx % ntl];
                                 int32_t v[CPL];
@@ -2401,6 +2942,15 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                     const cell_t *Hb = (const cell_t *)S.H + (uint64_t)best_row * Lp;
                     if (tid == 0) s_bc[5] = 0xFFFFFFFFu;
                     __syncthreads();
+                    if (PK == 8 && band_on && bd_strip) {
+                        const uint16_t *Hs = (const uint16_t *)S.H;
+                        for (uint32_t c = tid; c < L; c += NT)
+                            if ((int32_t)(Hs[(((uint64_t)(c >> 9) * bd_strip + best_row) * 64u << 3) + (c & 511u)] & 0x3FFF) == best) { atomicMin(&s_bc[5], c + 1); break; }
+                    } else if (PK == 8 && band_on) {
+                        const uint16_t *Hw = (const uint16_t *)S.H + (((uint64_t)best_row * 64u) << bd_sh);
+                        const uint32_t cfirst = (S.planm[8 * (size_t)(best_row - 1) + 4] >> 16) << bd_sh;        // 0-based column of the window's first cell (the row's record carries its first group)
+                        for (uint32_t c = tid; c < (64u << bd_sh); c += NT) if (cfirst + c < L && (int32_t)(Hw[c] & 0x3FFF) == best) { atomicMin(&s_bc[5], cfirst + c + 1); break; }
+                    } else
                     for (uint32_t c = tid; c < L; c += NT) if ((pk_packed(PK) ? (int32_t)(Hb[c] & 0x3FFF) : (int32_t)Hb[c]) == best) { atomicMin(&s_bc[5], c + 1); break; }
                     __syncthreads();
                     const uint32_t bj = s_bc[5];
@@ -2451,13 +3001,31 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                             const uint32_t t = (c - 1) / CPL, k = (c - 1) % CPL;
                             return (((const uint32_t *)S.E)[((uint64_t)r * NT + t) * NWD + k / 8] >> (4 * (k % 8))) & 0xFu;
                         };
+                        // the record word of row r >= 1, column c >= 1.  Band rows (PK == 8): 64 << bd_sh cells per row, the window's; a cell
+                        // outside the window reads H = 0, H - F = 3 (F = E = -inf there)
+                        auto recw = [&](uint32_t r, uint32_t c) -> int32_t {
+                            if constexpr (PK == 8) {
+                                if (band_on && bd_strip)       // strip-major full rows: 512 columns per strip, bd_strip rows per strip
+                                    return (int32_t)((const uint16_t *)S.H)[(((uint64_t)((c - 1u) >> 9) * bd_strip + r) * 64u << 3) + ((c - 1u) & 511u)];
+                                if (band_on) {
+                                    const uint32_t g = ((c - 1u) >> bd_sh) - (S.planm[8 * (size_t)(r - 1u) + 4] >> 16);      // (unsigned: a column left of the window wraps)
+                                    if (g >= 64u) return 0xC000;
+                                    return (int32_t)((const uint16_t *)S.H)[((((uint64_t)r * 64u + g)) << bd_sh) + ((c - 1u) & ((1u << bd_sh) - 1u))];
+                                }
+                            }
+                            return (int32_t)H[(uint64_t)r * Lp + c - 1];
+                        };
                         auto Hat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return 0;
+                            if constexpr (PK == 8) { return recw(r, c) & 0x3FFF; }
+                            else {
                             const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1];
                             return pk_packed(PK) ? (w & 0x3FFF) : w;
+                            }
                         };
                         auto Fat = [&](uint32_t r, uint32_t c) -> int32_t {
                             if (r == 0 || c == 0) return POA_NEG;
+                            if constexpr (PK == 8) { const int32_t w = recw(r, c); return (w & 0x3FFF) - ((w >> 14) & 3); }
                             if (pk_packed(PK)) { const int32_t w = (int32_t)H[(uint64_t)r * Lp + c - 1]; return (w & 0x3FFF) - ((w >> 14) & 3); }
                             return (int32_t)H[(uint64_t)r * Lp + c - 1] - (int32_t)(nib(r, c) & 3u);
                         };
@@ -2468,6 +3036,17 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                 // rebuilt from the row's H cells by the whole wavefront when the traceback asks for it -- only at
                                 // horizontal moves, a few dozen times per alignment, against a store per thread and row in the DP.
                                 int32_t m = POA_NEG;
+                                if constexpr (PK == 8) {
+                                    if (band_on) {
+                                        // (band rows: the cells of the window left of c, and the column left of the window with H = 0 in the place of column 0)
+                                        const uint32_t k0 = bd_strip ? 0u : (S.planm[8 * (size_t)(r - 1u) + 4] >> 16) << bd_sh;
+                                        for (uint32_t k = k0 + lane; k < c; k += 64) {
+                                            const int32_t h = k == k0 ? 0 : (recw(r, k) & 0x3FFF);
+                                            m = max(m, h - (int32_t)k * POA_E);
+                                        }
+                                        return wave_last(wave_scan_max(m, POA_NEG)) + POA_G + ((int32_t)c - 1) * POA_E;
+                                    }
+                                }
                                 const uint16_t *Hr = (const uint16_t *)S.H + (uint64_t)r * Lp;
                                 for (uint32_t k = lane; k < c; k += 64) {
                                     const int32_t h = k == 0 ? 0 : (int32_t)(Hr[k - 1] & 0x3FFFu);
@@ -2515,6 +3094,8 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                 // the row plan of my step travels with the cell: the step that fails is replayed by the general
                                 // code below, which then has its plan in lane m's registers instead of a second round trip
                                 if (in && my_i != 0) { fpl = S.plan[my_i - 1]; fplb = S.planb[my_i - 1]; }
+                                if constexpr (PK == 8) { if (in && my_next != 0 && my_j > 1) c = recw(my_next, my_j - 1) & 0x3FFF; }
+                                else
                                 if (in && my_next != 0 && my_j > 1) { c = (int32_t)H[(uint64_t)my_next * Lp + my_j - 2]; if (pk_packed(PK)) c &= 0x3FFF; }
                                 const int32_t hcur = wave_shr1(c, Hij);     // H of my step's own cell = the cell lane-1 fetched
                                 const int32_t mc = tlet[my_i] == (PK == 2 ? s[my_j - 1] : S.sq[my_j - 1]) ? POA_M : POA_N;
@@ -2554,9 +3135,15 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                 const uint32_t q0 = n_in ? plb.x : 0u, q1 = npred > 1 ? plb.y : q0, q2 = npred > 2 ? plb.z : q0, q3 = npred > 3 ? plb.w : q0;
                                 if constexpr (pk_packed(PK)) {
                                     const uint32_t qq[4] = {q0, q1, q2, q3};
+                                    if constexpr (PK == 8) {
+#pragma unroll
+                                        for (int k = 0; k < 4; ++k) if (qq[k] != 0 && (uint32_t)k < npred) wv[k] = recw(qq[k], j);
+                                        if (j > 1) wh = recw(i, j - 1);
+                                    } else {
 #pragma unroll
                                     for (int k = 0; k < 4; ++k) if (qq[k] != 0 && (uint32_t)k < npred) wv[k] = (int32_t)H[(uint64_t)qq[k] * Lp + j - 1];
                                     if (j > 1) wh = (int32_t)H[(uint64_t)i * Lp + j - 2];
+                                    }
                                 }
                                 const int32_t c0 = Hat(q0, j - 1), c1 = Hat(q1, j - 1), c2 = Hat(q2, j - 1), c3 = Hat(q3, j - 1);
                                 if (Hij == c0 + mc) { pi = q0; Hn = c0; found = true; }
@@ -2640,7 +3227,7 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
             //     (one per sequence position, distinct target nodes).
             unsigned long long t3 = PT_NOW();
             const uint32_t n_old = S.n_nodes;
-            enum { K_SKIP = 0, K_INS = 1, K_SAME = 2, K_SIB = 3, K_NEW = 4 };
+            enum { K_SKIP = 0, K_INS = 1, K_SAME = 2, K_SIB = 4, K_NEW = 3 };      // (bit 0: the pair creates a node -- what the sequential pass cannot skip)
             // the kind of every pair also goes to LDS (bitmap / stack area, idle here) so that the sequential
             // pass below touches global memory only for the pairs that create nodes
             uint8_t *kind = (uint8_t *)S.done;
@@ -2698,6 +3285,12 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                     uint32_t pb0 = 0, pbn = 0;                              // pending: current insertion run
                     for (uint32_t f = 0; f < n_aln && !S.err; ++f) {
                         if (use_kind) {
+                            // sixteen pairs at a time while nothing is pending and none of them creates a node (round 6: this loop over ~1000 reused
+                            // nodes, one LDS byte per trip, was a third of a near-chain alignment's time)
+                            if (pan + pbn == 0 && (f & 15u) == 0 && f + 16u <= n_aln) {
+                                const uint4 kk = *(const uint4 *)(kind + f);
+                                if (((kk.x | kk.y | kk.z | kk.w) & 0x01010101u) == 0) { f += 15u; continue; }
+                            }
                             const uint32_t k = kind[f];
                             if (k == K_SKIP) continue;
                             if ((k == K_SAME || k == K_SIB) && pan + pbn == 0) continue;
@@ -2828,14 +3421,21 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
             A.out_width[pk] = width;
             A.status[pk] = S.err;
             if (A.timeline) A.timeline[2 * pk + 1] = (unsigned long long)wall_clock64();
-            atomicAdd(&A.counters[0], cells);
-            atomicAdd(&A.counters[1], (unsigned long long)(q1 - q0));
+            // the reference's work is counted once, by the pass that finishes the pack (a pack that outgrows its slot or loses its band is run
+            // again from the start); what the device computed is counted every time
+            if (!S.err) {
+                atomicAdd(&A.counters[0], cells);
+                atomicAdd(&A.counters[1], (unsigned long long)(q1 - q0));
+#ifndef POA_PROFILE
+                atomicAdd(&A.counters[2], (unsigned long long)S.n_nodes);
+#endif
+                atomicAdd(&A.counters[3], rows);
+            }
 #ifdef POA_PROFILE
             atomicAdd(&A.counters[2], t_tie);          // tie resolution (part of counters[6])
-#else
-            atomicAdd(&A.counters[2], (unsigned long long)S.n_nodes);
 #endif
-            atomicAdd(&A.counters[3], rows);
+            atomicAdd(&A.counters[11], cells_done);
+            if constexpr (PK == 8) { atomicAdd(&A.counters[12], (unsigned long long)n_band_ok); atomicAdd(&A.counters[13], (unsigned long long)n_band_fail); atomicAdd(&A.counters[10], (unsigned long long)n_strip_aln); }
 #ifdef POA_PROFILE
             (void)t_topo; (void)t_dp; (void)t_tb; (void)t_add;                              // counters[4]: ties << 32 | ties that needed the exact sort
             atomicAdd(&A.counters[5], t_dp);           // DP rows
@@ -2849,6 +3449,10 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
     }
 }
 
+#ifdef POA_DEVICE_TEST      // (compile-time experiments: one instance, no host side)
+template __global__ void poa_kernel<POA_DEVICE_TEST>(poa_args);
+}  // namespace rattle
+#else
 // ---- host side ------------------------------------------------------------------------------------
 template <int CPL, int RING, int NW, int PK>
 static hipError_t launch_poa(const poa_args &A, uint32_t n_slots, size_t shm, hipStream_t st) {
@@ -2897,12 +3501,17 @@ static const poa_variant k_dense[4] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_V
 static const poa_variant k_mt4[4] = {POA_VARIANT(4, 4, 4, 7), POA_VARIANT(6, 4, 4, 7), POA_VARIANT(8, 4, 4, 7), POA_VARIANT(10, 4, 4, 7)};
 static const poa_variant k_mt2[4] = {POA_VARIANT(4, 2, 4, 7), POA_VARIANT(6, 2, 4, 7), POA_VARIANT(8, 2, 4, 7), POA_VARIANT(10, 2, 4, 7)};
 static const poa_variant k_mt1[4] = {POA_VARIANT(4, 1, 4, 7), POA_VARIANT(6, 1, 4, 7), POA_VARIANT(8, 1, 4, 7), POA_VARIANT(10, 1, 4, 7)};
+// near-chain graphs (POA #2 / #3: the caller says so): the exact band (dp_rows_band) for any length up to 2560.  Its rows run on ONE wavefront:
+// a crowded pass takes workgroups of one wavefront (sixteen packs per CU, each on its own), a sparse one workgroups of four (the plan, the
+// graph update and the tables of the traceback spread over 256 threads).  Packs whose band fails are run again by the forms above.
+static const poa_variant k_band1 = POA_VARIANT(4, 8, 1, 8), k_band4 = POA_VARIANT(4, 8, 4, 8);
 
 // Every switch kernel C's host side takes from the environment (tests and measurements only; read once per call, so a test may change
 // them between calls): one place, one struct.
 struct poa_env {
     const char *timeline = nullptr;      // RATTLE_POA_TIMELINE=<file>: when each pack's workgroup started and finished it
-    const char *mode = nullptr;          // RATTLE_POA_MODE = dense | mt4 | mt2 | mt1: one form of the row loop for the packed classes
+    const char *mode = nullptr;          // RATTLE_POA_MODE = dense | mt4 | mt2 | mt1 | band: one form of the row loop for the packed classes
+    int band = -1;                       // RATTLE_POA_BAND = 0 | 1: the exact band for near-chain graphs off / on for every call (default: on where the caller announces such graphs)
     const char *profile_json = nullptr;  // RATTLE_POA_PROFILE_JSON=<file> (POA_PROFILE builds): phase shares per class
     uint32_t node_cap = 0;               // RATTLE_POA_NODE_CAP: first-pass node capacity (tests lower it to force re-runs)
     uint64_t budget_mb = 0;              // RATTLE_POA_BUDGET_MB: arena budget (tests shrink it to exercise the skip path)
@@ -2916,6 +3525,7 @@ struct poa_env {
         if (const char *v = getenv("RATTLE_POA_NODE_CAP")) node_cap = (uint32_t)std::max(64, atoi(v));
         if (const char *v = getenv("RATTLE_POA_BUDGET_MB")) budget_mb = (uint64_t)atoll(v);
         if (const char *v = getenv("RATTLE_POA_DEBUG")) debug = (uint32_t)atoi(v);
+        if (const char *v = getenv("RATTLE_POA_BAND")) band = atoi(v) != 0;
         if (const char *v = getenv("RATTLE_POA_MT_SLOTS")) mt_slots = (uint32_t)std::max(1, atoi(v));
         if (const char *v = getenv("RATTLE_POA_STREAMS")) streams = atoi(v);
         timing = getenv("RATTLE_TIMING") != nullptr;
@@ -3030,6 +3640,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         int rounds = 0;                            // passes this class has taken
         bool clamped = false;                      // cell_cap was cut to what one slot can get: packs that still fail are skipped
         bool no_teams = false;                     // a pack of this group failed with POA_ERR_SYNC: its retries take the barrier form
+        bool no_band = false;                      // packs of this group failed with POA_ERR_BAND: what is left of the group takes the full rows
         const poa_variant *V = nullptr;
     } C[POA_GROUPS];
     for (int c = 0; c < POA_GROUPS; ++c) { C[c].todo = by_class[c]; if (ENV.node_cap) C[c].node_cap = ENV.node_cap; }
@@ -3040,7 +3651,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // wavefronts give a pack that has (most of) a CU to itself the shortest row there is (dp_rows_mt).
     // tests / measurements: RATTLE_POA_MODE = dense | mt4 | mt2 | mt1 forces one form for the packed classes
     const char *mode_s = ENV.mode;
-    const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : 0;
+    const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : !strcmp(mode_s, "band") ? 6 : 0;
+    // the exact band: where the caller announces near-chain graphs (POA #2 / #3), unless a form is forced; RATTLE_POA_BAND overrides both ways
+    const bool use_band = force_mode == 6 || (ENV.band >= 0 ? ENV.band == 1 && (force_mode == 0 || force_mode == 1) : force_mode == 0 && ctx->poa_shallow_graphs);
     uint32_t live_per_cu = 1, chain_per_cu = 1;    // packs per CU the pass about to start will keep resident (all classes; the long-chain groups)
     auto choose_variants = [&]() {
         uint64_t live = 0, chains = 0;
@@ -3055,13 +3668,13 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         // measured (profiles/round5_forms_by_load.txt; 1024- / 1536-column class, GCUPS): one pack per CU -- four teams 303 / 494, two
         // teams 313 / 463; two per CU -- two teams 557 / 750; three -- two teams 680 / 624 (a short queue), one team 544 / 697, round 4's
         // pipeline 498 / 454, barrier form 441 / 529; four -- one team 631, pipeline 635 / 569, barrier 569 / 649; five and more: the barrier form
-        int mode = force_mode ? force_mode : l8 <= 10 ? 3 : l8 <= 36 ? 4 : 1;
+        int mode = force_mode && force_mode != 6 ? force_mode : l8 <= 10 ? 3 : l8 <= 36 ? 4 : 1;
         // near-chain graphs (POA #2 / #3, the caller says so): no row parallelism to find, and per alignment as much serial work as DP --
         // beyond two packs per CU the barrier form with everything resident wins (measured in the rank replay at 1e6 reads: 833 such
         // packs took 0.46-0.53 s on two teams, 1667 of them 0.39 s in the barrier form)
-        if (!force_mode && ctx->poa_shallow_graphs && l8 > 18) mode = 1;
+        if ((!force_mode || force_mode == 6) && ctx->poa_shallow_graphs && l8 > 18) mode = 1;
         const uint64_t c8 = chains * 8 / n_cu;
-        const int chain_mode = force_mode >= 3 ? force_mode : c8 <= 10 ? 3 : 4;
+        const int chain_mode = force_mode >= 3 && force_mode != 6 ? force_mode : c8 <= 10 ? 3 : 4;
         for (int c = 0; c < POA_GROUPS; ++c) {
             C[c].V = &k_latency[poa_group_class(c)];
             if (c < 4) {
@@ -3069,6 +3682,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             }
             if (c >= 12) { const int gc = c - 12; C[c].V = force_mode == 1 ? &k_dense[gc] : chain_mode == 3 ? &k_mt4[gc] : chain_mode == 4 ? &k_mt2[gc] : &k_mt1[gc]; }
             if (C[c].no_teams && poa_group_class(c) < 4) C[c].V = &k_dense[poa_group_class(c)];
+            if (use_band && !C[c].no_band && (c < 4 || c >= 12)) C[c].V = (c >= 12 ? c8 : l8) > 32 ? &k_band1 : &k_band4;      // (packs per CU in eighths: more than four -> one wavefront per pack)
         }
     };
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
@@ -3095,7 +3709,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_rank = take((uint64_t)ncap * 4); A.o_order = take((uint64_t)ncap * 4); A.o_order2 = take((uint64_t)ncap * 4);
         A.o_srank = take((uint64_t)ncap * 4); A.o_rowmax = take(((uint64_t)ncap + 1) * 16); A.o_lh = take(((uint64_t)ncap + 1) * 16); A.o_nn = take(((uint64_t)qcap + 16) * 8);
         A.o_plan = take((uint64_t)ncap * 16); A.o_planb = take((uint64_t)ncap * 16); A.o_planc = take((uint64_t)ncap * 16); A.o_pland = take((uint64_t)ncap * 16);
-        A.o_planm = take(P.V->pk == 7 ? ((uint64_t)ncap + 8) * 32 : 0);
+        A.o_planm = take(P.V->pk == 7 || P.V->pk == 8 ? ((uint64_t)ncap + 8) * 32 : 0);
         const uint64_t cell_bytes = long_rows ? 4 : 2;
         if (pk_packed(P.V->pk)) {          // H words carry F's two bits, E's two bits per column sit in a per-thread array
             A.o_H = take(ccap * 2); A.o_F = take(0); A.o_E = take(0);      // E is rebuilt on demand by the traceback
@@ -3107,6 +3721,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         A.o_aln = take((uint64_t)acap * 8); A.o_ainfo = take((uint64_t)acap * 16); A.o_spill = take((uint64_t)scap * 4);
         P.per_slot = o;
         A.debug = ENV.debug;
+        A.band = 0;
         const uint32_t lds_seq = long_rows ? 16u : qcap;
         A.ring_slots = A.ring_reach = A.ring_slack = 0;
         bool mt_ring_ok = true;
@@ -3133,12 +3748,21 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             mt_ring_ok = teams == 1 || slots - slack + 1 >= teams + slack;
             A.ring_slots = slots; A.ring_slack = slack; A.ring_reach = slots - slack;
         }
+        if (P.V->pk == 8) {
+            // the band's LDS behind the bitmaps and the stack: 8 ring slots of 4 columns per lane (4 when eight do not leave ten workgroups of one
+            // wavefront a place on a CU), the selector table, junk words; between two DPs the tie labels and the traceback's tables
+            const uint32_t fixed = lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + 64u + 1024u;
+            uint32_t slots = 8;
+            if (P.V->nw == 1 && 10u * (fixed + band_lds_bytes(slots, 4, qcap)) > 160u * 1024) slots = 4;
+            A.band = std::max(band_lds_bytes(slots, 4, qcap), band_lds_bytes(2, 8, qcap));      // (eight columns per lane: the last resort, with a ring of two rows)
+        }
         auto lds_bytes = [&](const poa_variant *V) {
+            if (V->pk == 8) return (size_t)lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + (size_t)A.band + 64;
             if (V->pk == 7) return (size_t)lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + (size_t)A.ring_slots * mt_slot_bytes((int)V->cpl, (int)V->nw) + 64;
             return (size_t)lds_seq + poa_region_bytes(ncap, (int)V->cpl, (int)V->ring, (int)V->nw, (int)V->pk) + 64;
         };
         // a retry pass with a huge graph: the node bitmaps leave no room for a ready-made ring -- fall back to the dense form (2 bytes per cell)
-        if (gc < 4 && P.V->pk != 1 && (lds_bytes(P.V) > 158u * 1024 || !mt_ring_ok)) { P.V = &k_dense[gc]; A.ring_slots = A.ring_reach = A.ring_slack = 0; A.o_planm = take(0); }
+        if (gc < 4 && P.V->pk != 1 && P.V->pk != 8 && (lds_bytes(P.V) > 158u * 1024 || !mt_ring_ok)) { P.V = &k_dense[gc]; A.ring_slots = A.ring_reach = A.ring_slack = 0; A.o_planm = take(0); A.band = 0; }
         if ((gc == 4 || gc == 5 || gc == 6) && lds_bytes(P.V) > 158u * 1024) P.V = &k_noring[gc - 4];
         if (gc == POA_CLASSES - 1 && lds_bytes(P.V) > 158u * 1024) P.V = &k_long_noring;
         P.shm = lds_bytes(P.V);
@@ -3170,6 +3794,12 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
                 // the DP record is the arena: 7 nodes per base of the longest read (measured: ~4.5 at the end of a 200-read pack
                 // at 10 % error), not a fixed floor -- a third of the memory, and of the seconds the allocation takes
                 P.cell_cap = (uint64_t)(std::min<uint64_t>(std::max<uint64_t>(7ull * tl, 2048), tb + 1) + 64) * (tl + 32);
+                if (P.V->pk == 8) {
+                    // near-chain graphs: a few nodes beyond the longest sequence (3 x covers every pack of the bench's POA #2 / #3 four times over;
+                    // a graph that outgrows it is no chain, and its pack goes to the full rows anyway); the record is the band's: 256 cells per row
+                    P.node_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(3ull * tl, 1024), 1u << 20);
+                    P.cell_cap = ((uint64_t)std::min<uint64_t>(P.node_cap, tb + 1) + 64) * (((uint64_t)tl + 511) / 512 * 512);      // (the band needs 512 cells per row at most; the full rows as strips of 512 columns the whole width)
+                }
                 if (poa_group_class(c) >= 4) {
                     // long reads: rows by depth, pack by pack (x 1.25 of the measured growth; a pack that still outgrows its slot is re-run)
                     uint64_t nmax = 0, cmax = 0;
@@ -3334,13 +3964,15 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             if (!P.n_slots) continue;
             ++P.rounds;
             std::vector<uint32_t> again;
-            bool sync_retry = false;
+            bool sync_retry = false, band_retry = false;
             size_t cap_retry = 0;
+            const bool was_band = P.V->pk == 8;
             for (uint32_t p : P.todo) {
                 const uint32_t s = h_status[p];
                 if (s == POA_OK) continue;
                 if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) ++cap_retry;
                 if (s == POA_ERR_NODES || s == POA_ERR_CELLS || s == POA_ERR_SPILL || s == POA_ERR_ALN) again.push_back(p);
+                else if (s == POA_ERR_BAND) { again.push_back(p); band_retry = true; }
                 else if (s == POA_ERR_SYNC && !P.no_teams) {
                     // a wavefront of the team kernels gave up a bounded wait (a debugger stop, a trap handler, a throttled device, or a
                     // protocol error): the pack is dropped and run again in the barrier form, which cannot time out
@@ -3364,6 +3996,17 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             }
             P.todo.swap(again);
             if (sync_retry) { P.no_teams = true; if (cap_retry == 0) continue; }      // same capacities, another form
+            if (band_retry || (was_band && cap_retry)) {
+                // what is left of this group runs over the full rows from here on, with the capacities of a first pass of those forms
+                if (ENV.timing) {
+                    unsigned long long dbg[2] = {0, 0};
+                    (void)hipMemcpy(dbg, d_cnt.p + 14, sizeof(dbg), hipMemcpyDeviceToHost);
+                    fprintf(stderr, "[rattle]     poa: %zu pack(s) of group %d have an alignment without a certified band (or outgrew the band's slot): again over the full rows (the last one: sequence %llu of its pack, %llu nt against %llu rows, best score in the band %llu)\n",
+                            P.todo.size(), c, dbg[1] & 0xFFFFFFFFu, dbg[0] >> 32, dbg[0] & 0xFFFFFFFFu, dbg[1] >> 32);
+                }
+                P.no_band = true; P.rounds = 0; P.node_cap = ENV.node_cap ? ENV.node_cap : 10240u; P.cell_cap = 24ull << 20;
+                continue;
+            }
             if (!P.todo.empty()) {
                 if (P.clamped) { rc = give_up(P); continue; }
                 P.node_cap = std::min<uint32_t>(P.node_cap * 4, 1u << 20); P.cell_cap *= 8;
@@ -3495,7 +4138,11 @@ int poa_msa_run(rattle_ctx *ctx, const uint8_t *seq, const uint64_t *off, uint32
         }
     });
     for (int i = 0; i < 8; ++i) R->counters[i] = h_cnt[i];
+#if !defined(POA_PROFILE) && !defined(POA_PREDSTAT)
+    R->counters[4] = h_cnt[11]; R->counters[5] = h_cnt[12]; R->counters[6] = h_cnt[13];      // DP cells computed; alignments with a certified band / a failed certificate
+#endif
     return 0;
 }
 
 }  // namespace rattle
+#endif

@@ -177,3 +177,120 @@ def test_predecessors_hundreds_of_rows_back_and_many_in_edges(gpu_ctx, oracle, m
     for got, p in zip(rows, (pack, pack[::-1])):
         want, _ = oracle.poa_msa(p)
         assert got == want
+
+
+# ---- the exact band for near-chain graphs (dp_rows_band; RATTLE_POA_BAND=1 turns it on for this entry point) ----
+def _mutate(rng, s, sub=0.0, ins=0.0, dele=0.0):
+    out = bytearray()
+    for c in s:
+        r = rng.random()
+        if r < dele:
+            continue
+        out.append(int(rng.choice(list(b"ACGT"))) if r < dele + sub else c)
+        if rng.random() < ins:
+            out.append(int(rng.choice(list(b"ACGT"))))
+    return bytes(out)
+
+
+def _near_identical_pack(rng, length, depth, err, trunc=0.10):
+    base = bytes(rng.choice(list(b"ACGT"), length).astype(np.uint8))
+    pack = []
+    for _ in range(depth):
+        cut = int(rng.random() * trunc * length)
+        pack.append(_mutate(rng, base[cut:], err * 0.4, err * 0.3, err * 0.3))
+    pack.sort(key=lambda s: -len(s))
+    return pack
+
+
+@pytest.mark.parametrize("length,err", [(700, 0.0), (1000, 0.004), (1450, 0.01), (2300, 0.003), (520, 0.02)])
+def test_band_on_near_identical_packs_matches_oracle(gpu_ctx, oracle, monkeypatch, length, err):
+    """What POA #2 / #3 of `rattle correct` see (correct.cpp:427-436,520-532): near-identical sequences, 5'-truncated.  With the band
+    on, the MSA is byte-identical to the oracle's full matrices, most alignments are certified, and the device computes a fraction
+    of the reference's cells."""
+    monkeypatch.setenv("RATTLE_POA_BAND", "1")
+    rng = np.random.default_rng(length)
+    packs = [_near_identical_pack(rng, length, 24, err) for _ in range(3)]
+    rows, width, counters = gpu_ctx.poa_msa(packs)
+    cells = 0
+    for p, pack in enumerate(packs):
+        want, c = oracle.poa_msa(pack)
+        cells += c
+        assert rows[p] == want, p
+    assert int(counters[0]) == cells                      # the reference's count, whatever was computed
+    n_aln = sum(len(p) - 1 for p in packs)
+    # alignments with a certified band: nearly all while the graph stays a chain; with more errors the graph outgrows the band (its
+    # width is rows - columns + 2 t + 1: every bubble node counts) and the full rows take over -- never a wrong answer, never a failed call
+    # (a pack with ONE alignment that has no certified band is run again over the full rows, from the start: its computed cells then exceed the reference's)
+    if err <= 0.004 and length < 2000:
+        assert int(counters[5]) >= 0.8 * n_aln, counters
+        assert int(counters[4]) < 0.5 * cells, counters   # cells really computed
+    else:
+        assert int(counters[5]) >= 1, counters
+
+
+def test_band_off_computes_every_cell(gpu_ctx, oracle, monkeypatch):
+    monkeypatch.setenv("RATTLE_POA_BAND", "0")
+    rng = np.random.default_rng(3)
+    packs = [_near_identical_pack(rng, 800, 12, 0.003)]
+    rows, _, counters = gpu_ctx.poa_msa(packs)
+    want, c = oracle.poa_msa(packs[0])
+    assert rows[0] == want
+    assert int(counters[4]) == c == int(counters[0]) and int(counters[5]) == 0 and int(counters[6]) == 0
+
+
+def _band_failure_packs():
+    rng = np.random.default_rng(77)
+    base = bytes(rng.choice(list(b"ACGT"), 1200).astype(np.uint8))
+    other = bytes(rng.choice(list(b"ACGT"), 1150).astype(np.uint8))
+    cases = {}
+    # an indel longer than any band: the alignment jumps by 300 columns
+    cases["long_deletion"] = [base, base, base[:500] + base[800:], base[:450] + base[700:], base]
+    cases["long_insertion"] = [base, base[:600] + other[:260] + base[600:], base, base[:600] + other[:260] + base[600:]]
+    # a sequence that has nothing to do with the pack: score far below 5 (L - t)
+    cases["unrelated"] = [base, base, other, base[30:], other[10:]]
+    # a bubble right at the band's edge: the same insertion in many members widens the graph until n - L eats the room
+    ins = [base[:300] + other[k * 40:k * 40 + 38] + base[300:] for k in range(6)]
+    cases["growing_graph"] = [base] + ins + [base[40:], base[80:], base]
+    # two rows that tie for the best score: a tandem duplication (the end of the sequence matches two places equally well)
+    rep = base[:400] + base[300:400] + base[400:900]
+    cases["tied_rows"] = [rep, rep, base[:400] + base[400:900], base[:400], rep[50:]]
+    # everything shifted to the far corner of the band: maximal 5' truncation against a long first read
+    cases["band_corner"] = [base, base[118:], base[119:], base[120:], base[:1080], base[60:1100]]
+    return cases
+
+
+@pytest.mark.parametrize("strips", [False, True])
+@pytest.mark.parametrize("name", sorted(_band_failure_packs()))
+def test_band_certificate_failures_fall_back_to_the_full_rows(gpu_ctx, oracle, monkeypatch, name, strips):
+    """Where the certificate must fail (or the band cannot be tried at all) the full rows run and the result is the oracle's: over the
+    full-row kernels after the pack was handed back (strips = False: such a young pack has not earned the strips), or in place as
+    vertical strips on the band's row loop (strips = True)."""
+    monkeypatch.setenv("RATTLE_POA_BAND", "1")
+    if strips:
+        monkeypatch.setenv("RATTLE_POA_DEBUG", "8")
+    pack = _band_failure_packs()[name]
+    rows, _, counters = gpu_ctx.poa_msa([pack])
+    want, c = oracle.poa_msa(pack)
+    assert rows[0] == want, name
+    assert int(counters[0]) == c
+    if name == "unrelated":
+        assert int(counters[6]) >= 1, counters            # a failed certificate ...
+    if name in ("long_deletion", "long_insertion", "unrelated") and not strips:
+        assert int(counters[4]) >= int(counters[0])       # ... the pack lost its band at some alignment and was run again over the full rows
+
+
+@pytest.mark.parametrize("mode", ["band", "band+strips", "dense", "mt2"])
+def test_band_noisy_packs_every_form(gpu_ctx, oracle, monkeypatch, mode):
+    """Noisy reads (POA #1's input): the band cannot hold (graphs of 4-5 nodes per base) and must never be wrong about that.  `band+strips`:
+    every alignment that gets no band runs the full rows as vertical strips of 512 columns on the band's own row loop (RATTLE_POA_DEBUG bit 3:
+    also for packs that never had a band) -- the path a near-chain pack takes for the odd alignment that does not fit."""
+    if mode == "band+strips":
+        mode = "band"
+        monkeypatch.setenv("RATTLE_POA_DEBUG", "8")
+    monkeypatch.setenv("RATTLE_POA_MODE", mode)
+    monkeypatch.setenv("RATTLE_POA_BAND", "1")
+    packs = _packs_from_synth(300, 8, seed=23, max_pack=24)
+    rows, _, counters = gpu_ctx.poa_msa(packs)
+    for p, pack in enumerate(packs):
+        want, _ = oracle.poa_msa(pack)
+        assert rows[p] == want, p
