@@ -77,6 +77,7 @@ class DeviceSampler:
         while not self._stop.is_set():
             st = device_state()
             if st:
+                st["t"] = time.time()
                 self.samples.append(st)
             self._stop.wait(self.period)
 
@@ -84,13 +85,19 @@ class DeviceSampler:
         self._t.start()
         return self
 
-    def summary(self):
+    def stop(self):
         self._stop.set()
         self._t.join(timeout=2)
-        out = {"samples": len(self.samples)}
-        for key in ("sclk", "mclk", "power_w", "temp_c", "busy_percent"):
+
+    def summary(self, t0=None, t1=None, keys=("sclk", "mclk", "power_w", "temp_c", "busy_percent")):
+        """mean / min / max of what sysfs said while the timed region ran, or (t0, t1 given) while one step of it ran"""
+        if t0 is None:
+            self.stop()
+        sel = [st for st in self.samples if t0 is None or t0 <= st.get("t", 0) <= t1]
+        out = {"samples": len(sel)}
+        for key in keys:
             vals = []
-            for st in self.samples:
+            for st in sel:
                 v = st.get(key)
                 if isinstance(v, str):
                     v = "".join(ch for ch in v if ch.isdigit() or ch == ".")
@@ -197,16 +204,19 @@ def cpu_baseline(cat, qcat, off, tid, correct_reads=1800, cluster_reads=5000):
                       f"({n_s} reads in {dt_s:.1f} s with scalar rows); value = harmonic sum"}
 
 
-def cpu_baseline_all_cores(cat, qcat, off, tid):
+def cpu_baseline_all_cores(cat, qcat, off, tid, whole=False, what="transcripts (6..100 reads each)"):
     """The same oracle on every host core: one task per whole transcript on a process pool
     (oracle/par_baseline.py, run as a separate process so the pool forks without a HIP runtime).
-    Transcripts are clustered separately, which spares the CPU the cross-transcript filter tests."""
+    Transcripts are clustered separately, which spares the CPU the cross-transcript filter tests.
+    whole = True: every group of `tid` (the toyset: one task per cluster of the reference's own clusters.out)."""
     import subprocess
     import tempfile
     cores = os.cpu_count() or 1
     counts = np.bincount(tid)
     rng = np.random.default_rng(2)
     keep = [int(g) for g in rng.permutation(len(counts)) if 6 <= counts[g] <= 100][:max(8, cores)]      # bounded: ~20-30 s of wall time
+    if whole:
+        keep = list(range(len(counts)))
     sel = np.nonzero(np.isin(tid, keep))[0]
     lens = (off[sel + 1] - off[sel]).astype(np.int64)
     o2 = np.zeros(len(sel) + 1, np.uint64)
@@ -225,7 +235,7 @@ def cpu_baseline_all_cores(cat, qcat, off, tid):
         return {"error": r.stderr[-300:]}
     j = json.loads(r.stdout.strip().splitlines()[-1])
     return {"value": j["reads"] / j["seconds"], "unit": "reads/s", "cores": int(min(cores, j["tasks"])), "nproc": cores, "cpu": model, "kind": "port", "poa_rows": "AVX2 int16" if j.get("avx2") else "scalar",
-            "sample": f"{j['reads']} reads = every read of {j['tasks']} transcripts (6..100 reads each), one oracle task per transcript, {j['seconds']:.1f} s"}
+            "sample": f"{j['reads']} reads = every read of {j['tasks']} {what}, one oracle task per group, {j['seconds']:.1f} s"}
 
 
 def _latest(*names):
@@ -235,12 +245,12 @@ def _latest(*names):
     return os.path.join("profiles", names[-1])
 
 
-PMC_FILE = _latest("round5_pmc_poa.json", "round4_pmc_poa.json", "round3_pmc_poa.json")      # kernel C (tools/gpu_pmc_only.sh); `pmc_stale` says whether it matches the tree
-PMC_100K_FILE = _latest("round5_pmc_poa_100k.json", "round4_pmc_poa.json")      # ... at 1e5 reads: the under-filled device runs other forms of the row loop (teams of wavefronts)
-PMC_ISO_FILE = _latest("round5_pmc_iso.json", "round4_pmc_iso.json", "round3_pmc_iso.json")      # kernel B in the --iso flow (tools/gpu_pmc_iso.sh)
+PMC_FILE = _latest("round6_pmc_poa.json", "round5_pmc_poa.json", "round4_pmc_poa.json", "round3_pmc_poa.json")      # kernel C (tools/gpu_pmc_only.sh); `pmc_stale` says whether it matches the tree
+PMC_100K_FILE = _latest("round6_pmc_poa_100k.json", "round5_pmc_poa_100k.json", "round4_pmc_poa.json")      # ... at 1e5 reads: the under-filled device runs other forms of the row loop (teams of wavefronts)
+PMC_ISO_FILE = _latest("round6_pmc_iso.json", "round5_pmc_iso.json", "round4_pmc_iso.json", "round3_pmc_iso.json")      # kernel B in the --iso flow (tools/gpu_pmc_iso.sh)
 
 
-def toyset_line(ctx_cls, device):
+def toyset_line(ctx_cls, device, cpu_too=True):
     """The reference's own data set (toyset/rna, 8306 real ONT reads, recovered into tests/golden/) through the HIP path:
     `cluster --rna` + `correct`, timed beside the synthetic headline (the only published reference timings are for this set:
     README.md:400-403, 16 s / 76 s on 1 thread, 759 reads/s for `correct` on 24 threads).  The clusters are checked against
@@ -269,7 +279,21 @@ def toyset_line(ctx_cls, device):
     same = [((m[0], m[1]), [(x[0], x[1]) for x in mem]) for m, mem in best[2].as_list()] == [((m[0], m[1]), [(x[0], x[1]) for x in mem]) for m, mem in want]
     ctx.close()
     n = len(seqs)
-    return {"reads": n, "cluster_s": best[0], "correct_s": best[1], "poa_dp_cells": int(best[3][3][0]), "cluster_reads_per_s": n / best[0], "correct_reads_per_s": n / best[1],
+    # the same 8306 reads through the oracle on every host core of THIS box: one task per cluster of the reference's clusters.out
+    # (cluster_reads + correct of its members; the cross-cluster filter tests are spared the CPU, so the ratio is conservative)
+    cpu = None
+    if cpu_too:
+        try:
+            grp = np.zeros(n, np.int64)
+            for ci, (m, mem) in enumerate(want):
+                for x in mem:
+                    grp[x[0]] = ci
+            cpu = cpu_baseline_all_cores(cat, qcat, off, grp, whole=True, what="clusters of the reference's clusters.out")
+            if "value" in cpu:
+                cpu["gpu_over_cpu"] = (n / (best[0] + best[1])) / cpu["value"]
+        except Exception as e:
+            cpu = {"error": str(e)[:200]}
+    return {"reads": n, "cpu_all_cores": cpu, "cluster_s": best[0], "correct_s": best[1], "poa_dp_cells": int(best[3][3][0]), "cluster_reads_per_s": n / best[0], "correct_reads_per_s": n / best[1],
             "reads_per_s": n / (best[0] + best[1]), "clusters": int(len(best[2].main_id)), "clusters_equal_reference_fixture": bool(same),
             "consensi": int(best[3][2]), "reference_published": "README.md:400-403: cluster 16 s, correct 76 s on 1 thread (516 / 109 reads/s); correct 759 reads/s on 24 threads",
             "note": "small input: ~550 packs do not fill one MI355X (a pass lasts as long as its largest pack)"}
@@ -294,6 +318,7 @@ def pmc_reference(path=None):
     return d
 
 
+ALG_VALU_PER_CELL = (19 + 2 * 2.18) / 128 + 10 / (64 * 5)      # see poa_roofline
 KNAMES = {K_KMER: "kmer_extract", K_FILTER: "bv_filter", K_SCORE: "pair_score", K_POA: "poa_align", K_POST: "post_msa"}
 
 
@@ -312,9 +337,10 @@ def iso_roofline(kst):
                     "kernel B from the committed PMC passes of the same flow (tools/gpu_pmc_iso.sh), per launch"}
 
 
-def poa_roofline(kst, cells, steps, per_gpu=1, copy_gbs=None, pmc_file=None):
+def poa_roofline(kst, cells, steps, per_gpu=1, copy_gbs=None, pmc_file=None, cells_reference=None):
     """kernel C: exact DP cells over its HIP-event time, priced in wave64 VALU instructions per second (it is bound by VALU issue /
-    per-row latency, not by HBM: SURVEY 8d, profiles/) against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; `cells` = per step"""
+    per-row latency, not by HBM: SURVEY 8d, profiles/) against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles; `cells` = the cells the device
+    COMPUTED per step (the PMC constants are per computed cell too), `cells_reference` = rows x columns of every alignment"""
     ms, launches, alg = kst["poa_align"]
     gcups = cells / per_gpu / (ms / steps * 1e-3) / 1e9 if ms > 0 else 0.0
     hbm6 = 6.0 * gcups
@@ -330,6 +356,12 @@ def poa_roofline(kst, cells, steps, per_gpu=1, copy_gbs=None, pmc_file=None):
         "frac_practical": ach / VALU_PRACTICAL_TINSTR if ach else None, "peak_practical": VALU_PRACTICAL_TINSTR,
         "salu_wave_instr_per_cell": spc, "salu_frac": gcups * 1e9 * spc / 1e12 / SALU_PEAK_TINSTR if spc else None,
         "valu_wave_instr_per_cell": ipc, "gcups": gcups, "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+        "gcups_reference_cells": (cells_reference / per_gpu / (ms / steps * 1e-3) / 1e9) if cells_reference and ms > 0 else None,
+        # the recurrence's own instruction count: per column PAIR and row 19 packed operations + 2 per in-edge (ready-made
+        # terms), i.e. (19 + 2 x 2.18) / 128 wave64 instructions per cell, + the row's scan and bookkeeping (~10 per wavefront and row over
+        # 64 x 5 columns): what a kernel with NO overhead would issue.  frac_alg prices the achieved cell rate with THAT count, so it
+        # falls when the kernel gets slower and does not rise when it wastes instructions
+        "alg_valu_per_cell": ALG_VALU_PER_CELL, "frac_alg": gcups * 1e9 * ALG_VALU_PER_CELL / 1e12 / VALU_PEAK_TINSTR,
         "cells_per_launch": cells * steps / max(launches, 1),
         # HBM view: SURVEY 8(d)'s 6 B per DP cell (three int16 matrices) and what the kernel really stores
         "hbm": {"achieved_6B_per_cell_gbs": hbm6, "peak_gbs": 8000.0, "frac_6B_per_cell": hbm6 / 8000.0, "measured_copy_gbs": copy_gbs,
@@ -399,7 +431,8 @@ def side_config(device, n_reads, iso, steps=2):
         assert (cluster_digest(cl), res.digest()) == dg_w, "result differs between passes"
         rec["workload"] = f"{n} synthetic cDNA reads, {genes} transcripts, `rattle cluster` k=10 gene level + `rattle correct` (BASELINE configs[1] size)"
         rec["clusters"], rec["packs"], rec["cluster_reads_per_s"] = int(len(cl.main_id)), int(counters[2]), n / (t_cluster / steps)
-        rec["roofline"] = poa_roofline(kst, int(counters[0]), steps, pmc_file=PMC_100K_FILE)
+        rec["poa_dp_cells_reference"], rec["poa_dp_cells_computed"] = int(counters[0]), int(counters[5]) or int(counters[0])
+        rec["roofline"] = poa_roofline(kst, int(counters[5]) or int(counters[0]), steps, pmc_file=PMC_100K_FILE, cells_reference=int(counters[0]))
     rec["digest_equal_across_steps"] = True
     for o in outs:
         if o[2] is not None:
@@ -553,6 +586,9 @@ def main():
     t0 = time.time()
     last = None
     step_ms = []
+    step_detail = []
+    if not a.iso:
+        ctx.stage_ms()                          # (reset: the stage times below are the timed steps')
     for _ in range(a.steps):
         if last is not None and not a.iso:
             if hold:
@@ -560,11 +596,21 @@ def main():
             else:
                 last[1].free()
         ts = time.time()
+        c0 = PHASES["cluster"]
         last = step()
-        step_ms.append((time.time() - ts) * 1e3)
+        te = time.time()
+        step_ms.append((te - ts) * 1e3)
+        # which stage a slow step was slow in (the library keeps its stages' host wall time), and what the device reported meanwhile
+        step_detail.append({"ms": round((te - ts) * 1e3, 1), "cluster_ms": round((PHASES["cluster"] - c0) * 1e3, 1),
+                            "correct_stage_ms": {} if a.iso else {k: round(v, 1) for k, v in ctx.stage_ms().items()}, "t": (ts, te)})
     barrier()
     dt = time.time() - t0
     state_during = sampler.summary() if sampler is not None else None
+    for d in step_detail:
+        ts, te = d.pop("t")
+        if sampler is not None:
+            sm = sampler.summary(ts, te, keys=("sclk", "power_w"))
+            d["sclk_mhz"], d["power_w"], d["samples"] = sm.get("sclk"), sm.get("power_w"), sm.get("samples")
     state1 = device_state() if rank == 0 else None
     tf = time.time()
     for h in held:
@@ -627,7 +673,7 @@ def main():
             # every timed step on its own (first-step vs steady state), the state of the device around the timed region, and what the
             # harness kept OUT of the timed region: a step's ~2 GB result is freed after the timer stops when the host has the memory
             # (`results_held`), which costs `result_free_ms` per step when it is done between steps instead
-            "step_ms": [round(x, 1) for x in step_ms], "device_state": {"before": state0, "during": state_during, "after": state1},
+            "step_ms": [round(x, 1) for x in step_ms], "step_detail": step_detail, "device_state": {"before": state0, "during": state_during, "after": state1},
             "results_held": bool(hold), "result_free_ms": free_ms,
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
             "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items() if v > 0},
@@ -646,13 +692,18 @@ def main():
         else:
             n_cor, n_unc, n_cons, counters = res.counts()
             cells = int(counters[0])
+            cells_done = int(counters[5]) or cells   # what the device computed: fewer where the exact band of POA #2 / #3 was certified
             per_gpu = world if sharded else 1      # several ranks on one job: `cells` is the job's total, the kernel time this GPU's
             out["config"] = {"workload": f"{n_reads} synthetic cDNA reads (mean 1 kb, 10% err, both strands, {genes} transcripts, Zipf abundance), "
                                          "`rattle cluster` k=10 gene level + `rattle correct` (BASELINE metric size; configs[1]/[3] shape)"
                                          + (" per GPU" if a.weak else ", ONE job over all GPUs"),
-                             "reads": n_reads, "clusters": int(len(cl.main_id)), "poa_dp_cells_per_step": cells, "poa_alignments_per_step": int(counters[1]),
+                             "reads": n_reads, "clusters": int(len(cl.main_id)), "poa_dp_cells_per_step": cells, "poa_dp_cells_reference": cells,
+                             "poa_dp_cells_computed": cells_done, "poa_alignments_per_step": int(counters[1]),
+                             "poa_band": {"alignments_certified": int(counters[6]), "failed_certificates": int(counters[7]),
+                                          "note": "POA #2 / #3 (near-identical sequences) run inside an exact band on one wavefront, certified per alignment; "
+                                                  "`reference` = rows x columns of every alignment, what the reference's engine fills"},
                              "packs": int(counters[2]), "parallelism": par}
-            out["roofline"] = poa_roofline(kst, cells, a.steps, per_gpu, copy_gbs)
+            out["roofline"] = poa_roofline(kst, cells_done, a.steps, per_gpu, copy_gbs, cells_reference=cells)
             if not a.no_cpu_baseline:
                 try:
                     out["toyset"] = toyset_line(Context, local)
@@ -666,6 +717,20 @@ def main():
                             out["configs"][name] = side_config(local, nr, iso)
                         except Exception as e:
                             out["configs"][name] = {"error": str(e)[:300]}
+                if world == 1 and not a.no_configs and not a.no_stage:
+                    # the PCIe-inclusive rate (never `value`): the same step with the reads handed over as host buffers in every call
+                    try:
+                        c2 = Context(local)
+                        w2 = run_step(c2, cat, qcat, off, None); w2[1].free()
+                        torch.cuda.synchronize(); tn = time.time()
+                        w2 = run_step(c2, cat, qcat, off, None)
+                        torch.cuda.synchronize(); dtn = time.time() - tn
+                        ok = (cluster_digest(w2[0]), w2[1].digest()) == (checks["cluster_digest"], checks["correct_digest"])
+                        w2[1].free(); c2.close()
+                        out["no_stage"] = {"value": n_reads / dtn, "unit": "reads/s", "ms_per_step": dtn * 1e3, "steps": 1, "digest_equal_to_staged_run": bool(ok),
+                                           "note": "reads and qualities (2 x ~1 GB) uploaded inside the timed step; the headline has them resident in HBM"}
+                    except Exception as e:
+                        out["no_stage"] = {"error": str(e)[:300]}
                 out["cpu_baseline"] = cpu_baseline(cat, qcat, off, tid)
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cat, qcat, off, tid)
         print(json.dumps(out))

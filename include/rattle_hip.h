@@ -328,6 +328,12 @@ int rattle_hip_debug_phred_symbol(double p, int *table_value, int *libm_value);
  */
 int rattle_hip_kernel_stats(rattle_ctx *ctx, int kernel, double *total_ms, uint64_t *launches, uint64_t *alg_bytes);
 int rattle_hip_kernel_stats_reset(rattle_ctx *ctx);
+/* (ABI 4) Host wall time of the stages of the calls made on this context since the last reset, in milliseconds:
+ * [0] reserved, [1] `correct` stage 1 (POA #1 + correction of every pack, correct.cpp:395-426), [2] stage 2a (POA #2 of the packs of the
+ * many-pack clusters, :427-470), [3] stage 2b + 3a (POA #2 of the other packs beside POA #3 of the many-pack clusters, :489-556),
+ * [4] stage 3b (POA #3 of the other clusters), [5..7] reserved.  A measurement aid for the benchmark harness (which stage a slow
+ * step was slow in); the reference has no counterpart. */
+int rattle_hip_stage_ms(rattle_ctx *ctx, double ms_out[8], int reset);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,7 @@ SIGNATURES = {
     "rattle_hip_lpt_assign": (C.c_int, [_u64p, C.c_uint32, C.c_int, _u32p]),
     "rattle_hip_kernel_stats": (C.c_int, [C.c_void_p, C.c_int, _f64p, _u64p, _u64p]),
     "rattle_hip_kernel_stats_reset": (C.c_int, [C.c_void_p]),
+    "rattle_hip_stage_ms": (C.c_int, [C.c_void_p, _f64p, C.c_int]),
 }
 
 _lib = None

@@ -453,6 +453,12 @@ class Context:
     def reset_stats(self):
         check(self.lib.rattle_hip_kernel_stats_reset(self.h))
 
+    def stage_ms(self, reset: bool = True):
+        """Host wall time of `correct`'s stages since the last reset: {stage: ms} (rattle_hip_stage_ms)."""
+        ms = (C.c_double * 8)()
+        check(self.lib.rattle_hip_stage_ms(self.h, ms, 1 if reset else 0))
+        return {"1": ms[1], "2a": ms[2], "2b+3a": ms[3], "3b": ms[4]}
+
 
 def min_common_lut(thr: float) -> np.ndarray:
     """min_common_lut[m] = smallest c with float(c)/float(m) >= thr (cluster.cpp:19,43); 0xFFFF = never."""

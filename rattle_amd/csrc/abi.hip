@@ -66,7 +66,7 @@ static int use_device(rattle_ctx *c) {
 extern "C" {
 
 const char *rattle_hip_last_error(void) { return g_err.c_str(); }
-int rattle_hip_abi_version(void) { return 3; }
+int rattle_hip_abi_version(void) { return 4; }
 
 int rattle_hip_ctx_create(int device, rattle_ctx **out) {
     if (!out) { set_error("out is null"); return RATTLE_ERR_ARG; }
@@ -532,6 +532,12 @@ int rattle_hip_kernel_stats(rattle_ctx *c, int kernel, double *ms, uint64_t *lau
 int rattle_hip_kernel_stats_reset(rattle_ctx *c) {
     if (!c) { set_error("null ctx"); return RATTLE_ERR_ARG; }
     for (int i = 0; i < K_COUNT; ++i) c->stats[i] = kstat();
+    return 0;
+}
+
+int rattle_hip_stage_ms(rattle_ctx *c, double *ms_out, int reset) {
+    if (!c || !ms_out) { set_error("null argument"); return RATTLE_ERR_ARG; }
+    for (int i = 0; i < 8; ++i) { ms_out[i] = c->stage_ms[i]; if (reset) c->stage_ms[i] = 0; }
     return 0;
 }
 

@@ -21,13 +21,15 @@ struct phase_timer {
     const char *name;
     std::chrono::steady_clock::time_point t0;
     bool on;
-    explicit phase_timer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {
+    double *keep = nullptr;             // where the elapsed milliseconds are ADDED when the timer stops (rattle_hip_stage_ms), with or without RATTLE_TIMING
+    explicit phase_timer(const char *n, double *k = nullptr) : name(n), t0(std::chrono::steady_clock::now()), keep(k) {
         static const bool enabled = getenv("RATTLE_TIMING") != nullptr;
         on = enabled;
     }
     void stop() {
-        if (on) fprintf(stderr, "[rattle] %-28s %8.1f ms\n", name,
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (keep) { *keep += ms; keep = nullptr; }
+        if (on) fprintf(stderr, "[rattle] %-28s %8.1f ms\n", name, ms);
         on = false;
     }
     ~phase_timer() { stop(); }
@@ -297,6 +299,7 @@ struct rattle_ctx {
     uint8_t *poa_arena = nullptr;
     size_t poa_arena_bytes = 0;
     hipStream_t poa_st[16] = {};     // one per column class: classes run concurrently
+    double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // host wall time of the last calls' stages, summed until read (rattle_hip_stage_ms): [0] cluster, [1] correct stage 1, [2] 2a, [3] 2b+3a, [4] 3b
     int poa_shallow_graphs = 0;      // hint of the caller for the next poa_device_run: near-identical sequences (POA #2 / #3), graphs that are almost chains
     hipEvent_t poa_ev[16] = {};
     hipEvent_t poa_go = nullptr;

@@ -459,7 +459,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             desc[q] = gather_desc{off[X.r[q].rid], X.S.off[q], len, X.r[q].rev};
             X.S.off[q + 1] = X.S.off[q] + len;
         }
-        phase_timer T("correct: stage 1");
+        phase_timer T("correct: stage 1", &ctx->stage_ms[1]);
         RT_TRY(run_stage(ctx, X.S, desc, {gather_part{0, n1, dev_seq, dev_qual}}, 1, P, order, cnt));
         RT_HIP(hipMemcpyAsync(X.olen.data(), X.S.olen.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
         RT_HIP(hipMemcpyAsync(X.tfront.data(), X.S.tfront.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
@@ -599,7 +599,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
     auto cons_pass = [&](rattle_ctx *cx, const char *name, const std::vector<uint32_t> &slots2, const std::vector<uint32_t> &clusters3,
                          std::vector<uint8_t> &bytes, std::vector<skip_t> &sk, uint64_t *cnt) -> int {
         if (slots2.empty() && clusters3.empty()) return 0;
-        phase_timer T(name);
+        phase_timer T(name, !strcmp(name, "correct: stage 2a") ? &ctx->stage_ms[2] : !strcmp(name, "correct: stage 2b+3a") ? &ctx->stage_ms[3] : !strcmp(name, "correct: stage 3b") ? &ctx->stage_ms[4] : nullptr);
         cons_stage C;
         stage &S = C.S;
         std::vector<gather_desc> d;

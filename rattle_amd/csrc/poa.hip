@@ -1525,6 +1525,7 @@ __device__ void dp_rows_mt(poa_ws &S, dp_xchg &X, const poa_args &A, uint32_t n,
 #define BD_MORE4 1u
 #define BD_SLOW 2u
 #define BD_NOBASE 4u
+#define BD_CHAIN 8u                                // the row's one in-edge comes from the row before it, with the window where it was: that row's terms are still in registers
 __host__ __device__ constexpr uint32_t band_entry_bytes(int CPLB) { return 4u * (uint32_t)CPLB; }
 __host__ __device__ constexpr uint32_t band_slot_bytes(int CPLB) { return (64u + BAND_PAD) * band_entry_bytes(CPLB); }
 // first column group of the window of a row in column c (bsh = log2 CPLB)
@@ -1592,6 +1593,9 @@ __device__ __forceinline__ void dp_rows_band(poa_ws &S, dp_xchg &X, uint32_t n, 
     uint32_t g0 = STRIP ? strip * 64u : 0u;                                   // first column group of the current window (wave-uniform)
     uint32_t sbase = as_u(pk_splat(POA_G - POA_E));                           // u of the column left of the window (H = 0 there)
     gptr_t hrow = Hrec + ((uint64_t)(STRIP ? strip * (n + 1u) : 0u) + 1u) * (64u * NP) + (uint32_t)lane * NP;      // row 1 (of this strip)
+    s16x2 PA[NP], PB[NP];                                                     // the previous row's terms (what it wrote to the ring)
+#pragma unroll
+    for (int u = 0; u < NP; ++u) { PA[u] = pk_splat(0); PB[u] = pk_splat(POA_G - POA_E); }
     uint32_t cw_next = 0;                                                     // STRIP: the dword of the row after this one (a scalar load a row ahead)
     if constexpr (STRIP) { if (strip) cw_next = cin[4]; }
 
@@ -1600,14 +1604,18 @@ __device__ __forceinline__ void dp_rows_band(poa_ws &S, dp_xchg &X, uint32_t n, 
         const uint32_t o0 = pd[2] & 0xFFFFu, o1 = pd[2] >> 16, o2 = pd[3] & 0xFFFFu, o3 = pd[3] >> 16;
         const uint32_t self_off = pd[4] & 0xFFFFu, ctl = (pd[5] >> 16) & 0xFFu;      // (pd[4] >> 16: the window's first column group, for whoever reads this row later)
         const uint32_t dl = STRIP ? 0u : pd[5] & 0xFFu;
+        // A chain row (one in-edge, from the row before: nearly every row of POA #2 / #3) takes its predecessor's terms from REGISTERS -- the
+        // ring entry the previous row has just written would be an LDS write and read back to back on the critical path of every row
+        // (measured: ~560 cycles per row for ~70 instructions).  (A row whose window has moved on since -- one in CPLB -- reads the ring: taking
+        // the terms from the neighbour lane by DPP, with lane 63's from its own last H, did not get through this compiler.)
+        const bool chain = (ctl & BD_CHAIN) != 0u;
         ent_t e0, e1, e2, e3;
-        issue(o0, e0); issue(o1, e1); issue(o2, e2); issue(o3, e3);
+        if (!chain) { issue(o0, e0); issue(o1, e1); issue(o2, e2); issue(o3, e3); }
         // STRIP: what the strip to the left says about this row: its last H (low half) and the prefix maximum of u up to there (high half)
         uint32_t hl_row = 0, sb_row = sbase;
         if constexpr (STRIP) {
             if (strip) {
-                uint32_t cw = cw_next;
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cw) : : "memory");
+                const uint32_t cw = cw_next;                                 // (it arrived before the previous row's LDS writes: see the wait there)
                 hl_row = cw << 16;                                           // as the high half of a pair word: the column left of lane 0's first
                 sb_row = (cw >> 16) | (cw & 0xFFFF0000u);
                 uint64_t pc = (uint64_t)(cin + 4 * (uint64_t)(row + 1u));
@@ -1627,14 +1635,20 @@ __device__ __forceinline__ void dp_rows_band(poa_ws &S, dp_xchg &X, uint32_t n, 
             const uint32_t ub = (uint32_t)((int32_t)(g0 * CPLB + 1u) * -POA_E + POA_G) & 0xFFFFu;      // 0 + g - (c + 1) e, c = g0 * CPLB
             sbase = ub | (ub << 16);
         }
-        if constexpr (NP == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(SEL[0]) : : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        land4(e0, e1, e2, e3);
         s16x2 HM[NP], FM[NP];
+        if (chain) {
+            // (no wait at all: this row's record arrived before the previous row's LDS writes went out, see below)
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            HM[u] = pk_max(pk_max(as_pk(e0[u]), as_pk(e1[u])), pk_max(as_pk(e2[u]), as_pk(e3[u])));
-            FM[u] = pk_max(pk_max(as_pk(e0[NP + u]), as_pk(e1[NP + u])), pk_max(as_pk(e2[NP + u]), as_pk(e3[NP + u])));
+            for (int u = 0; u < NP; ++u) { HM[u] = PA[u]; FM[u] = PB[u]; }
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the ring entries (and, when the window moved, the selectors)
+            if constexpr (NP == 1) asm volatile("" : "+v"(SEL[0]));
+            land4(e0, e1, e2, e3);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                HM[u] = pk_max(pk_max(as_pk(e0[u]), as_pk(e1[u])), pk_max(as_pk(e2[u]), as_pk(e3[u])));
+                FM[u] = pk_max(pk_max(as_pk(e0[NP + u]), as_pk(e1[NP + u])), pk_max(as_pk(e2[NP + u]), as_pk(e3[NP + u])));
+            }
         }
         if (ctl & BD_MORE4) {
             issue(pd[6] & 0xFFFFu, e0); issue(pd[6] >> 16, e1); issue(pd[7] & 0xFFFFu, e2); issue(pd[7] >> 16, e3);
@@ -1737,7 +1751,12 @@ __device__ __forceinline__ void dp_rows_band(poa_ws &S, dp_xchg &X, uint32_t n, 
             for (int u = 0; u < NP; ++u) {
                 R[u] = as_u(pk_left(as_u(HN[u]), u == 0 ? left : as_u(HN[u - 1])));
                 R[NP + u] = as_u(pk_max(HN[u] - pk_splat(2), FN[u]));
+                PA[u] = as_pk(R[u]); PB[u] = as_pk(R[NP + u]);       // ... and for the next row, should it be a chain row
             }
+            // Scalar loads return out of order: whoever uses one waits for lgkmcnt(0), LDS operations included.  So the record of the next
+            // row (requested behind this row's predecessor terms) is waited for HERE, a row's worth of instructions after its request and
+            // before this row's LDS writes go out -- the next row then starts without a wait, instead of sitting out these writes
+            __builtin_amdgcn_s_waitcnt(0xC07F);
             if constexpr (NP == 1) { typedef __attribute__((address_space(3))) u32x2 *e2_p; u32x2 v; v.x = R[0]; v.y = R[1]; *(e2_p)(uintptr_t)(rb + self_off) = v; }
             else {
                 typedef __attribute__((address_space(3))) u32x4 *e4_p;
@@ -2664,7 +2683,8 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                 for (uint32_t k = 0; k < 8; ++k) if (po[k] == 0xFFFFFFFFu) po[k] = base;
                                 const uint32_t letter = rd_letter(pl.x), li = (letter >> 1) & 3u;
                                 const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));
-                                const uint32_t ctl = (n_in > 4 ? BD_MORE4 : 0u) | ((farmask || n_in > 8 || nobase) ? BD_SLOW : 0u) | (nobase ? BD_NOBASE : 0u);
+                                uint32_t ctl = (n_in > 4 ? BD_MORE4 : 0u) | ((farmask || n_in > 8 || nobase) ? BD_SLOW : 0u) | (nobase ? BD_NOBASE : 0u);
+                                if (n_in == 1u && row > 1u && pb.x == row - 1u && !farmask && g == gprev) ctl |= BD_CHAIN;
                                 uint4 *pm = (uint4 *)(S.planm + 8 * (size_t)r);
                                 pm[0] = make_uint4(klo, khi, po[0] | po[1] << 16, po[2] | po[3] << 16);
                                 pm[1] = make_uint4(((row & (brs - 1u)) * slotb) | g << 16, min(g - gprev, 255u) | farmask << 8 | ctl << 16 | min(n_in, 255u) << 24, po[4] | po[5] << 16, po[6] | po[7] << 16);
@@ -2737,7 +2757,8 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                                     for (uint32_t k = 0; k < 8; ++k) if (po[k] == 0xFFFFFFFFu) po[k] = base;
                                     const uint32_t letter = rd_letter(pl.x), li = (letter >> 1) & 3u;
                                     const uint32_t klo = 0xFCFCFCFCu ^ (0xF9u << (8u * li)), khi = 0xFFFFFFFFu ^ (0xFFu << (8u * li));
-                                    const uint32_t ctl = (n_in > 4 ? BD_MORE4 : 0u) | ((farmask || n_in > 8 || nobase) ? BD_SLOW : 0u) | (nobase ? BD_NOBASE : 0u);
+                                    uint32_t ctl = (n_in > 4 ? BD_MORE4 : 0u) | ((farmask || n_in > 8 || nobase) ? BD_SLOW : 0u) | (nobase ? BD_NOBASE : 0u);
+                                    if (n_in == 1u && row > 1u && pb.x == row - 1u && !farmask) ctl |= BD_CHAIN;
                                     uint4 *pm = (uint4 *)(S.planm + 8 * (size_t)r);
                                     pm[0] = make_uint4(klo, khi, po[0] | po[1] << 16, po[2] | po[3] << 16);
                                     pm[1] = make_uint4((row & (brs - 1u)) * slotb, farmask << 8 | ctl << 16 | min(n_in, 255u) << 24, po[4] | po[5] << 16, po[6] | po[7] << 16);
@@ -3924,7 +3945,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             bool few[POA_GROUPS] = {false};
             bool any_few = false, any_crowd = false;
             for (int c = 0; c < POA_GROUPS; ++c) if (C[c].n_slots) {
-                few[c] = C[c].V->pk == 7 && C[c].n_slots * 8u <= n_cu;      // a handful: the chains.  (Two team groups that each take half the device are a crowd:
+                few[c] = (C[c].V->pk == 7 || (C[c].V->pk == 8 && c >= 12)) && C[c].n_slots * 8u <= n_cu;      // a handful: the chains.  (Two team groups that each take half the device are a crowd:
                                                                              // with the smaller one sent ahead, stage 1 of a rank of eight went from 0.9 to 1.08 s)
                 (few[c] ? any_few : any_crowd) = true;
             }
@@ -4034,6 +4055,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error(std::string("poa readback: ") + hipGetErrorString(e)); rc = RATTLE_ERR_HIP; }
     }
+    if (rc == 0 && ENV.timing && (h_cnt[12] || h_cnt[13] || h_cnt[10]))
+        fprintf(stderr, "[rattle]     poa band: %llu alignments with a certified band, %llu failed certificates, %llu alignments over the full rows as strips; cells computed %.3g of %.3g\n", h_cnt[12], h_cnt[13], h_cnt[10],
+                (double)h_cnt[11], (double)h_cnt[0]);
     if (rc == 0 && tl_path) {
         std::vector<unsigned long long> tl(2 * (size_t)n_packs);
         if (hipMemcpy(tl.data(), d_tl.p, 16 * (size_t)n_packs, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.rattle_hip_abi_version() == 3
+    assert lib.rattle_hip_abi_version() == 4
 
 
 def test_header_is_plain_c():

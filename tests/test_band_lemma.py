@@ -1,10 +1,10 @@
-"""The lemma behind DESIGN.md §8's "exact band for the chains" (an idea for kernel C's POA #3 groups, NOT in the product): for spoa's local
-alignment scores (match 5, mismatch -4, gap of length k: -8 - 6 (k - 1)), sequence against sequence, a band of half-width w around the
-diagonals that a gapless alignment of the full shorter sequence can use is EXACT whenever the best score found inside it exceeds
-5 (L - w - 1), L = the shorter length: a path that visits a cell t > w diagonals outside has at most L - t diagonal steps or pays for
-2 t gap positions, so it scores at most 5 (L - t) <= 5 (L - w - 1).  Checked here on random pairs with plain Python DP matrices: same best
-score, same set of best cells, same traceback from the first of them.  A pair with an indel longer than the band must fail the condition
-(the caller then runs the full rows)."""
+"""The lemma behind kernel C's exact band for near-chain graphs (dp_rows_band, DESIGN.md §4: POA #2 / #3 of `rattle correct`,
+correct.cpp:427-436,520-532): for spoa's local alignment scores (match 5, mismatch -4, gap of length k: -8 - 6 (k - 1)) a band around the
+diagonals a path with at least tau = L - t diagonal moves can use is EXACT whenever the best score found inside it is >= 5 tau - 4: a path
+that touches a cell outside has fewer than tau diagonal moves and scores at most 5 (tau - 1).  Checked here on plain Python DP matrices --
+sequence against sequence first (round 5's groundwork), then sequence against a DAG with aligned groups, insertions and skip edges, the
+band placed by the rows' MSA columns as the kernel does: same best score, same set of best cells, same traceback from them.  A pair with
+an indel longer than the band must fail the condition (the kernel then runs the full rows)."""
 import numpy as np
 
 M, N, G, E = 5, -4, -8, -6
@@ -108,3 +108,145 @@ def test_an_indel_longer_than_the_band_fails_the_condition():
     sf, _ = best_cells(dp(a, b)[0])
     assert sb <= 5 * (L - w - 1)                                  # the band cannot vouch for itself: full rows
     assert sf >= sb
+
+
+# ---- the same for a DAG (kernel C's dp_rows_band, round 6): rows in block order, the rows of an aligned group share an MSA column ----
+# A path through cell (row i, column j) has at most M(i, j) = min(c_i, j) + min(C - c_i, L - j) diagonal moves (c_i = the row's MSA
+# column, C = columns of the graph), provided every edge leads to a strictly later column.  With tau = L - t the band is
+# {M >= tau} = {max(1, c_i - (C - L + t)) <= j <= min(L, c_i + t)}, cells outside read H = 0 / F = E = -inf, and the certificate is
+# best_in_band >= 5 tau - 4.
+def random_near_chain_dag(rng, length, subs, inss, skips):
+    """rows (block order): dict(letter, preds [rows], col); a backbone chain, substitution siblings (same column), insertion nodes
+    (a column of their own between two backbone columns), skip edges (deletions)."""
+    cols = []                                            # list of columns, each a list of (letter, kind)
+    for k in range(length):
+        cols.append([int(rng.integers(0, 4))])
+        if rng.random() < subs:
+            cols[-1].append((cols[-1][0] + 1 + int(rng.integers(0, 3))) % 4)
+        if rng.random() < inss:
+            cols.append([int(rng.integers(0, 4)), "ins"])
+    rows, col_rows = [], []
+    for c, members in enumerate(cols):
+        is_ins = members[-1] == "ins"
+        letters = [m for m in members if m != "ins"]
+        here = []
+        for letter in letters:
+            rows.append({"letter": letter, "preds": [], "col": c + 1, "ins": is_ins})
+            here.append(len(rows))                       # 1-based row
+        col_rows.append(here)
+    # edges: every row from every row of the previous non-insertion column and from a preceding insertion column; insertion rows from the column before
+    for c in range(1, len(cols)):
+        prev = c - 1
+        for r in col_rows[c]:
+            for p in col_rows[prev]:
+                rows[r - 1]["preds"].append(p)
+            if rows[col_rows[prev][0] - 1]["ins"] and prev >= 1:          # the insertion is optional: also straight from the column before it
+                for p in col_rows[prev - 1]:
+                    rows[r - 1]["preds"].append(p)
+            if c >= 3 and rng.random() < skips:                            # a deletion seen before: skip two columns
+                rows[r - 1]["preds"].append(col_rows[c - 3][0])
+    return rows, len(cols)
+
+
+def dag_dp(rows, b, band=None):
+    n, m = len(rows), len(b)
+    H = [[0] * (m + 1) for _ in range(n + 1)]
+    F = [[NEG] * (m + 1) for _ in range(n + 1)]
+    Ee = [[NEG] * (m + 1) for _ in range(n + 1)]
+    for i in range(1, n + 1):
+        preds = rows[i - 1]["preds"] or [0]
+        lo, hi = (1, m) if band is None else band(i)
+        for j in range(1, m + 1):
+            if j < lo or j > hi:
+                continue                                  # outside: H = 0, F = E = -inf
+            s = M if rows[i - 1]["letter"] == b[j - 1] else N
+            d = max(H[p][j - 1] + s for p in preds)
+            F[i][j] = max(max(H[p][j] + G, F[p][j] + E) for p in preds)
+            Ee[i][j] = max(H[i][j - 1] + G, Ee[i][j - 1] + E)
+            H[i][j] = max(0, d, F[i][j], Ee[i][j])
+    return H, F, Ee
+
+
+def dag_trace(rows, b, H, F, Ee, start):
+    """spoa's order: diagonal (in-edges in order), vertical (F extension before opening), horizontal; affine runs followed inside F / E"""
+    i, j = start
+    out = []
+    while H[i][j] != 0:
+        preds = rows[i - 1]["preds"] or [0]
+        s = M if rows[i - 1]["letter"] == b[j - 1] else N
+        nxt, ext_up, ext_left = None, False, False
+        for p in preds:
+            if H[i][j] == H[p][j - 1] + s:
+                nxt = (p, j - 1); break
+        if nxt is None:
+            for p in preds:
+                if H[i][j] == F[p][j] + E:
+                    nxt, ext_up = (p, j), True; break
+                if H[i][j] == H[p][j] + G:
+                    nxt = (p, j); break
+        if nxt is None:
+            if H[i][j] == Ee[i][j - 1] + E:
+                nxt, ext_left = (i, j - 1), True
+            elif H[i][j] == H[i][j - 1] + G:
+                nxt = (i, j - 1)
+        assert nxt is not None
+        out.append((i if nxt[0] != i else -1, j if nxt[1] != j else -1))
+        i, j = nxt
+        if ext_left:
+            while True:
+                out.append((-1, j)); j -= 1
+                if Ee[i][j] + E != Ee[i][j + 1]:
+                    break
+        elif ext_up:
+            while i != 0:
+                stop, np_ = False, 0
+                for p in (rows[i - 1]["preds"] or [0]):
+                    if F[i][j] == H[p][j] + G:
+                        stop, np_ = True, p; break
+                    if F[i][j] == F[p][j] + E:
+                        np_ = p; break
+                out.append((i, -1)); i = np_
+                if stop:
+                    break
+    return out
+
+
+def test_band_on_a_dag_is_exact_when_its_best_score_clears_the_bound():
+    rng = np.random.default_rng(21)
+    held = failed = 0
+    for case in range(80):
+        rows, C = random_near_chain_dag(rng, int(rng.integers(40, 80)), 0.15, 0.08, 0.1)
+        for r in rows:                                    # the premise the kernel checks while it builds the rows' records
+            assert all(rows[p - 1]["col"] < r["col"] for p in r["preds"])
+        # a sequence along one path of the graph, cut at the 5' end, with a few errors
+        path, c = [], 0
+        by_col = {}
+        for i, r in enumerate(rows):
+            by_col.setdefault(r["col"], []).append(i)
+        for col in sorted(by_col):
+            if rows[by_col[col][0]]["ins"] and rng.random() < 0.7:
+                continue
+            path.append(rows[int(rng.choice(by_col[col]))]["letter"])
+        b = mutate(rng, path[int(rng.integers(0, 8)):], float(rng.choice([0.0, 0.03, 0.08])))
+        L = len(b)
+        if L < 10:
+            continue
+        t = int(rng.choice([2, 4, 8, 12]))
+        tau, s = L - t, C - L + t
+        if C < tau:
+            continue
+        band = lambda i: (max(1, rows[i - 1]["col"] - s), min(L, rows[i - 1]["col"] + t))
+        Hb, Fb, Eb = dag_dp(rows, b, band)
+        sb, cb = best_cells(Hb)
+        Hf, Ff, Ef = dag_dp(rows, b)
+        sf, cf = best_cells(Hf)
+        if sb < 5 * tau - 4:
+            failed += 1
+            assert sf >= sb                               # a failed certificate only means: run the full rows
+            continue
+        held += 1
+        assert sf == sb and cf == cb, (case, sf, sb)
+        # spoa takes the first best cell in ITS rank order; whichever it is, the traceback from it is the same
+        for start in cf[:3]:
+            assert dag_trace(rows, b, Hf, Ff, Ef, start) == dag_trace(rows, b, Hb, Fb, Eb, start), case
+    assert held >= 25 and failed >= 3                     # both branches of the kernel's logic are exercised

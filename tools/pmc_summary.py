@@ -23,9 +23,10 @@ for d in dirs:
             e["dispatches"] += 1
             e["sum"] += float(row["Counter_Value"])
 bench = json.loads([l for l in open(bench_path) if l.startswith("{")][-1])
-cells = bench["config"]["poa_dp_cells_per_step"] * (bench["steps"] + bench["warmup"])
+# per COMPUTED cell (round 6: POA #2 / #3 run inside an exact band; bench.py prices its roofline with the computed cells as well)
+cells = bench["config"].get("poa_dp_cells_computed", bench["config"]["poa_dp_cells_per_step"]) * (bench["steps"] + bench["warmup"])
 poa = {c: sum(v["sum"] for k, v in ks.items() if "poa_kernel" in k) for c, ks in sums.items()}
-res = {"workload": bench["config"]["workload"], "dp_cells_profiled": cells, "counters_by_kernel": sums, "poa_kernels_total": poa}
+res = {"workload": bench["config"]["workload"], "dp_cells_profiled": cells, "dp_cells_reference": bench["config"]["poa_dp_cells_per_step"] * (bench["steps"] + bench["warmup"]), "counters_by_kernel": sums, "poa_kernels_total": poa}
 if "SQ_INSTS_VALU" in poa:
     res["valu_wave_instr_per_cell"] = poa["SQ_INSTS_VALU"] / cells
     res["salu_wave_instr_per_cell"] = poa.get("SQ_INSTS_SALU", 0) / cells
