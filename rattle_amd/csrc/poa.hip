@@ -2726,9 +2726,9 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                             __syncthreads();
                         }
                         // ---- 3b. no band: the full rows as vertical strips of 512 columns on the same row loop (dp_rows_band<8, true>), exact without a
-                        // certificate.  Only for a pack that HAS been running in the band (a pack of noisy reads belongs to the full-row kernels,
+                        // certificate.  Only for a pack three quarters of whose alignments so far HAD a band (a pack of noisy reads belongs to the full-row kernels,
                         // which spread a row over four to sixteen wavefronts); A.debug bit 3: always (tests)
-                        const bool strips_ok = (A.debug & 8u) || (n_band_ok >= 8u && 4u * n_band_ok >= (q - q0));
+                        const bool strips_ok = (A.debug & 8u) || (n_band_ok >= 8u && 4u * n_band_ok >= 3u * (q - q0));
                         const uint32_t n_strips = (Lu + 511u) >> 9;
                         if (!band_on && strips_ok && !s_bc[1] && (uint64_t)n_strips * (nu + 1u) * 512u <= A.cell_cap) {
                             const uint32_t Lpb = (Lu + 7u) & ~7u;
@@ -3501,14 +3501,20 @@ struct poa_variant {
 };
 #define POA_VARIANT(CPL, RING, NW, PK) {CPL, RING, NW, PK, &launch_poa<CPL, RING, NW, PK>, &max_blocks_per_cu<CPL, RING, NW, PK>}
 #define POA_CLASSES 8
-#define POA_GROUPS 16                          // + the shallow packs of classes 4 .. 7 and the LONG-CHAIN packs of classes 0 .. 3 as groups of their own (poa_device_run)
+#define POA_GROUPS 24                          // + the shallow packs of classes 4 .. 7 (8 .. 11), the LONG-CHAIN packs of classes 0 .. 3 (12 .. 15) and the packs of
+                                               // classes 0 .. 3 the exact band is tried on (16 .. 19; long chains: 20 .. 23) as groups of their own (poa_device_run)
+#ifndef POA_BAND_SPREAD
+#define POA_BAND_SPREAD 400                    // the band holds columns - length + 2 t + 1 <= 504 cells per row: a pack whose lengths differ by more than this cannot stay in it
+#endif
 #ifndef POA_CHAIN_SEQS
 #define POA_CHAIN_SEQS 256                      // a pack of more sequences than any read pack has (split: 200) is a POA #3 group: hundreds of alignments one after the other
 #endif
 #ifndef POA_SHALLOW_READS
 #define POA_SHALLOW_READS 40
 #endif
-static inline int poa_group_class(int g) { return g < POA_CLASSES ? g : g < 12 ? g - 4 : g - 12; }
+static inline int poa_group_class(int g) { return g < POA_CLASSES ? g : g < 12 ? g - 4 : g < 16 ? g - 12 : g < 20 ? g - 16 : g - 20; }
+static inline bool poa_group_chain(int g) { return (g >= 12 && g < 16) || g >= 20; }
+static inline bool poa_group_band(int g) { return g >= 16; }
 static const uint32_t k_class_cols[POA_CLASSES - 1] = {1024, 1536, 2048, 2560, 4096, 6144, 8192};
 static const poa_variant k_latency[POA_CLASSES] = {POA_VARIANT(4, POA_RING_4x4, 4, 1), POA_VARIANT(6, POA_RING_4x6, 4, 1), POA_VARIANT(8, 8, 4, 1), POA_VARIANT(10, 8, 4, 1),
                                                    POA_VARIANT(8, POA_WIDE_RING, 8, 3), POA_VARIANT(8, POA_WIDE_RING, 12, 3), POA_VARIANT(8, POA_WIDE_RING, 16, 3),
@@ -3581,13 +3587,21 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     if (n_packs == 0 || n_seqs == 0) { for (uint32_t p = 0; p < n_packs; ++p) h_width_out[p] = 0; return 0; }
     if (pack_first[0] != 0 || pack_first[n_packs] != n_seqs) { set_error("pack_first must cover [0, n_seqs]"); return RATTLE_ERR_ARG; }
 
+    const char *mode_s = ENV.mode;
+    const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : !strcmp(mode_s, "band") ? 6 : 0;
+    // the exact band: where the caller announces near-chain graphs (POA #2 / #3), unless a form is forced; RATTLE_POA_BAND overrides both ways
+    const bool use_band = force_mode == 6 || (ENV.band >= 0 ? ENV.band == 1 && (force_mode == 0 || force_mode == 1) : force_mode == 0 && ctx->poa_shallow_graphs);
     // length class of each pack: 1024 / 1536 / 2048 / 2560 / 4096 / 6144 columns, or longer (segmented int32 rows)
     std::vector<uint64_t> pbases(n_packs);
     std::vector<uint32_t> pmaxL(n_packs);
     std::vector<uint32_t> by_class[POA_GROUPS];      // groups 0 .. 7: the column classes; 8 .. 11: the SHALLOW packs of classes 4 .. 7 (smaller slots, more of them)
     for (uint32_t p = 0; p < n_packs; ++p) {
-        uint32_t m = 0;
-        for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) m = std::max<uint32_t>(m, (uint32_t)(off[q + 1] - off[q]));
+        uint32_t m = 0, mn = 0xFFFFFFFFu;
+        for (uint32_t q = pack_first[p]; q < pack_first[p + 1]; ++q) {
+            const uint32_t len = (uint32_t)(off[q + 1] - off[q]);
+            m = std::max<uint32_t>(m, len);
+            if (len) mn = std::min(mn, len);
+        }
         pbases[p] = off[pack_first[p + 1]] - off[pack_first[p]];
         pmaxL[p] = m;
         if (m > POA_MAX_LEN) {
@@ -3604,7 +3618,9 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         // a POA #3 group of a many-pack cluster (hundreds of pack consensi, correct.cpp:520-532) is ONE workgroup's serial work for the
         // whole pass (0.8 s at 1e6 reads in round 4, beside thousands of POA #2 packs in the dense form): such packs form groups of their
         // own, whose form is chosen by THEIR number -- teams of wavefronts, the shortest row there is -- not by the crowd's
+        const bool band_pack = use_band && cls < 4 && m - std::min(m, mn) <= POA_BAND_SPREAD;      // (lengths only: what the graphs look like the kernel finds out)
         if (cls < 4 && pack_first[p + 1] - pack_first[p] > POA_CHAIN_SEQS) cls += 12;
+        if (band_pack) cls += cls >= 12 ? 8 : 16;
         by_class[cls].push_back(p);
     }
 
@@ -3644,7 +3660,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         }
     }
     dbuf<uint32_t> d_heads;
-    RT_TRY(d_heads.reserve(16));
+    RT_TRY(d_heads.reserve(32));
     // RATTLE_POA_TIMELINE=<file>: when each pack's workgroup started and finished it (measurement aid: how full the device is over a pass)
     const char *tl_path = ENV.timeline;
     dbuf<unsigned long long> d_tl;
@@ -3671,15 +3687,10 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
     // the barrier form keeps the most packs resident (seven or eight per CU: record words in the ring, 2 bytes per cell); the teams of
     // wavefronts give a pack that has (most of) a CU to itself the shortest row there is (dp_rows_mt).
     // tests / measurements: RATTLE_POA_MODE = dense | mt4 | mt2 | mt1 forces one form for the packed classes
-    const char *mode_s = ENV.mode;
-    const int force_mode = !mode_s ? 0 : mode_s[0] == 'd' ? 1 : !strcmp(mode_s, "mt4") ? 3 : !strcmp(mode_s, "mt2") ? 4 : !strcmp(mode_s, "mt1") ? 5 : !strcmp(mode_s, "band") ? 6 : 0;
-    // the exact band: where the caller announces near-chain graphs (POA #2 / #3), unless a form is forced; RATTLE_POA_BAND overrides both ways
-    const bool use_band = force_mode == 6 || (ENV.band >= 0 ? ENV.band == 1 && (force_mode == 0 || force_mode == 1) : force_mode == 0 && ctx->poa_shallow_graphs);
     uint32_t live_per_cu = 1, chain_per_cu = 1;    // packs per CU the pass about to start will keep resident (all classes; the long-chain groups)
     auto choose_variants = [&]() {
         uint64_t live = 0, chains = 0;
-        for (int c = 0; c < 12; ++c) live += C[c].todo.size();
-        for (int c = 12; c < POA_GROUPS; ++c) chains += C[c].todo.size();
+        for (int c = 0; c < POA_GROUPS; ++c) (poa_group_chain(c) ? chains : live) += C[c].todo.size();
         live_per_cu = (uint32_t)std::max<uint64_t>(1, (live + n_cu - 1) / n_cu);
         chain_per_cu = (uint32_t)std::max<uint64_t>(1, (chains + n_cu - 1) / n_cu);
         // by packs per CU: about one -> four teams per pack (16 wavefronts: the CU is the pack's); up to four and a half -> two teams (two or
@@ -3698,12 +3709,11 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
         const int chain_mode = force_mode >= 3 && force_mode != 6 ? force_mode : c8 <= 10 ? 3 : 4;
         for (int c = 0; c < POA_GROUPS; ++c) {
             C[c].V = &k_latency[poa_group_class(c)];
-            if (c < 4) {
-                C[c].V = mode == 1 ? &k_dense[c] : mode == 3 ? &k_mt4[c] : mode == 4 ? &k_mt2[c] : &k_mt1[c];
-            }
-            if (c >= 12) { const int gc = c - 12; C[c].V = force_mode == 1 ? &k_dense[gc] : chain_mode == 3 ? &k_mt4[gc] : chain_mode == 4 ? &k_mt2[gc] : &k_mt1[gc]; }
-            if (C[c].no_teams && poa_group_class(c) < 4) C[c].V = &k_dense[poa_group_class(c)];
-            if (use_band && !C[c].no_band && (c < 4 || c >= 12)) C[c].V = (c >= 12 ? c8 : l8) > 32 ? &k_band1 : &k_band4;      // (packs per CU in eighths: more than four -> one wavefront per pack)
+            const int gc = poa_group_class(c);
+            if (gc < 4 && !poa_group_chain(c)) C[c].V = mode == 1 ? &k_dense[gc] : mode == 3 ? &k_mt4[gc] : mode == 4 ? &k_mt2[gc] : &k_mt1[gc];
+            if (poa_group_chain(c)) C[c].V = force_mode == 1 ? &k_dense[gc] : chain_mode == 3 ? &k_mt4[gc] : chain_mode == 4 ? &k_mt2[gc] : &k_mt1[gc];
+            if (C[c].no_teams && gc < 4) C[c].V = &k_dense[gc];
+            if (poa_group_band(c) && !C[c].no_band) C[c].V = (poa_group_chain(c) ? c8 : l8) > 32 ? &k_band1 : &k_band4;      // (packs per CU in eighths: more than four -> one wavefront per pack)
         }
     };
     // pass 0: many slots with a modest arena; later passes: failed packs with larger arenas.
@@ -3751,7 +3761,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             // `reach` = slots - slack rows back are served from the ring, the rest from the record in HBM
             const uint32_t teams = P.V->ring, slotb = mt_slot_bytes((int)P.V->cpl, (int)P.V->nw);
             const uint32_t fixed = lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + 64u + 3072u;      // + the kernel's static LDS
-            uint32_t ppc = std::max<uint32_t>(1, std::min<uint32_t>(c >= 12 ? chain_per_cu : live_per_cu, teams == 4 ? 1u : teams == 2 ? (MT2_MINWAVES >= 6 && P.V->cpl == 4 ? 3u : 2u) : 4u));      // (registers: 16 wavefronts of 128 per CU)
+            uint32_t ppc = std::max<uint32_t>(1, std::min<uint32_t>(poa_group_chain(c) ? chain_per_cu : live_per_cu, teams == 4 ? 1u : teams == 2 ? (MT2_MINWAVES >= 6 && P.V->cpl == 4 ? 3u : 2u) : 4u));      // (registers: 16 wavefronts of 128 per CU)
             uint32_t slots = 0, slack = 0;
             for (; ppc >= 1; --ppc) {
                 const uint32_t room = 160u * 1024 / ppc;
@@ -3901,7 +3911,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             }
             ctx->poa_arena_bytes = take_bytes;
         }
-        hipError_t e = hipMemsetAsync(d_heads.p, 0, 64, st);
+        hipError_t e = hipMemsetAsync(d_heads.p, 0, 128, st);
         uint64_t aoff = 0;
         uint32_t qoff = 0;
         for (int c = 0; c < POA_GROUPS && e == hipSuccess; ++c) {
@@ -3917,7 +3927,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             qoff += (uint32_t)P.todo.size();
             if (ENV.timing)
                 fprintf(stderr, "[rattle]     poa class %s%u cols (%u waves x %u, %s %u%s) pass %d: %zu packs, %u slots x %.1f MB, %d blocks/CU\n",
-                        poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : c >= 12 ? "(long chains) " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl,
+                        poa_group_class(c) == POA_CLASSES - 1 ? "> 8192: segments of " : poa_group_band(c) ? (poa_group_chain(c) ? "(band, long chains) " : "(band) ") : c >= 12 ? "(long chains) " : c >= POA_CLASSES ? "(shallow packs) " : "", 64 * P.V->nw * P.V->cpl, P.V->nw, P.V->cpl,
                         P.V->pk == 7 ? "teams" : "ring", P.V->ring, P.V->pk == 7 ? (", ring " + std::to_string(A.ring_slots) + " reach " + std::to_string(A.ring_reach)).c_str() : "", pass, P.todo.size(), P.n_slots,
                         P.per_slot / 1e6, P.bpc);
         }
@@ -3945,7 +3955,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             bool few[POA_GROUPS] = {false};
             bool any_few = false, any_crowd = false;
             for (int c = 0; c < POA_GROUPS; ++c) if (C[c].n_slots) {
-                few[c] = (C[c].V->pk == 7 || (C[c].V->pk == 8 && c >= 12)) && C[c].n_slots * 8u <= n_cu;      // a handful: the chains.  (Two team groups that each take half the device are a crowd:
+                few[c] = (C[c].V->pk == 7 || (C[c].V->pk == 8 && poa_group_chain(c))) && C[c].n_slots * 8u <= n_cu;      // a handful: the chains.  (Two team groups that each take half the device are a crowd:
                                                                              // with the smaller one sent ahead, stage 1 of a rank of eight went from 0.9 to 1.08 s)
                 (few[c] ? any_few : any_crowd) = true;
             }
@@ -3955,7 +3965,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             // 12 when it is loaded before the runtime starts, so that every class gets a queue of its own; an application whose
             // runtime was already running with the default is dealt four streams)
             const int hwq = hw_queues();
-            const int n_streams = std::max(1, std::min(POA_GROUPS, ENV.streams ? ENV.streams : hwq));
+            const int n_streams = std::max(1, std::min(16, ENV.streams ? ENV.streams : hwq));
             double load[16] = {0};
             bool used[16] = {false};
             for (int i = 0; i < n_run && e == hipSuccess; ++i) {
