@@ -61,6 +61,9 @@ namespace rattle {
 #ifndef POA_RING_4x6
 #define POA_RING_4x6 4
 #endif
+#ifndef POA_CHAIN_SEQS
+#define POA_CHAIN_SEQS 256                      // a pack of more sequences than any read pack has (split: 200) is a POA #3 group: hundreds of alignments one after the other
+#endif
 #define POA_MAX_LEN (1u << 20)           // H <= 5 * length must stay far below 2^28 (POA_NEG)
 
 // node record (uint4): x = letter | n_al << 8 | n_in << 16, y = first in-edge's begin node,
@@ -2636,7 +2639,7 @@ __global__ __launch_bounds__(64 * NW * pk_teams(RING, PK), poa_min_waves(CPL, NW
                         const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n), Lu = (uint32_t)__builtin_amdgcn_readfirstlane((int)L), rbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)ring_bytes);
                         const uint32_t Cu = fits_flags ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_bc[0]) : 0u;      // columns of the graph
                         uint32_t t_want = max(8u, 2u * bd_thist + 4u);
-                        for (uint32_t bsh = 1; bsh <= 3u && !band_on && fits_flags; ++bsh) {
+                        for (uint32_t bsh = 1; bsh <= 3u && !band_on && fits_flags && !(A.debug & 16u); ++bsh) {
                             const uint32_t cplb = 1u << bsh;
                             const int32_t room = (int32_t)(63u * cplb) - 1 - ((int32_t)Cu - (int32_t)Lu);      // C - L + 2 t + 1 <= 63 cplb
                             if (room < 0) continue;
@@ -3506,9 +3509,6 @@ struct poa_variant {
 #ifndef POA_BAND_SPREAD
 #define POA_BAND_SPREAD 400                    // the band holds columns - length + 2 t + 1 <= 504 cells per row: a pack whose lengths differ by more than this cannot stay in it
 #endif
-#ifndef POA_CHAIN_SEQS
-#define POA_CHAIN_SEQS 256                      // a pack of more sequences than any read pack has (split: 200) is a POA #3 group: hundreds of alignments one after the other
-#endif
 #ifndef POA_SHALLOW_READS
 #define POA_SHALLOW_READS 40
 #endif
@@ -3786,6 +3786,7 @@ int poa_device_run(rattle_ctx *ctx, const uint8_t *d_seq_in, const uint64_t *d_o
             uint32_t slots = 8;
             if (P.V->nw == 1 && 10u * (fixed + band_lds_bytes(slots, 4, qcap)) > 160u * 1024) slots = 4;
             A.band = std::max(band_lds_bytes(slots, 4, qcap), band_lds_bytes(2, 8, qcap));      // (eight columns per lane: the last resort, with a ring of two rows)
+            if (const char *v = getenv("RATTLE_POA_BAND_LDS")) A.band = (uint32_t)atoi(v);      // (measurements)
         }
         auto lds_bytes = [&](const poa_variant *V) {
             if (V->pk == 8) return (size_t)lds_seq + (2u * poa_bit_words(ncap) + POA_STACK) * 4u + (size_t)A.band + 64;

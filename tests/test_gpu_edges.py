@@ -100,6 +100,29 @@ def test_reads_longer_than_the_register_classes(gpu_ctx, oracle):
         assert rows[p] == want, p
 
 
+def test_reads_of_three_segments(gpu_ctx, oracle):
+    """Reads beyond 16 384 nt: three segments of 8192 columns per row in the segmented int32 rows (config 5's long tail; the
+    reference aligns whatever passes --upper-length, correct.cpp:395-405).  Byte for byte against the oracle's full matrices."""
+    rng = np.random.default_rng(23)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    tx = acgt[rng.integers(0, 4, 18600)]
+    pack = []
+    for _ in range(3):
+        r = rng.random(len(tx))
+        s = tx.copy()
+        sub = (r >= 0.01) & (r < 0.03)
+        s[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        s = s[r >= 0.01]
+        pos = np.sort(rng.integers(0, len(s) + 1, int(0.01 * len(s))))
+        pack.append(np.insert(s, pos, acgt[rng.integers(0, 4, len(pos))]).tobytes())
+    pack.sort(key=lambda x: -len(x))
+    assert min(len(x) for x in pack) > 2 * 8192 + 1000
+    rows, width, counters = gpu_ctx.poa_msa([pack])
+    want, cells = oracle.poa_msa(pack)
+    assert rows[0] == want
+    assert int(counters[0]) == cells
+
+
 def test_absurdly_long_sequence_is_an_error(gpu_ctx):
     from rattle_amd._lib import RattleError
     with pytest.raises(RattleError):
