@@ -249,6 +249,9 @@ typedef struct {
     uint32_t *corrected_pack, *uncorrected_pack;
 } rattle_correction;
 
+/* (A context that clustered its reads holds their k-mer index, 12-20 bytes per base.  `correct` does not use it and sizes its arena by
+ * the free memory: when the index exceeds 24 GB it is released here, and the next rattle_hip_cluster_reads without a new
+ * rattle_hip_load_reads returns RATTLE_ERR_STATE "no reads loaded".  rattle_hip_cluster_unsorted loads by itself and is unaffected.) */
 int rattle_hip_correct_reads(rattle_ctx *ctx, const uint8_t *seq_concat, const uint8_t *qual_concat,
                              const uint64_t *offsets, uint32_t n_reads, uint32_t n_clusters,
                              const uint32_t *cluster_offsets, const int32_t *member_id, const uint8_t *member_rev,

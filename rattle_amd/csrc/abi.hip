@@ -198,6 +198,7 @@ int rattle_hip_cluster_reads(rattle_ctx *c, const rattle_cluster_params *P, ratt
     if (!c || !P || !out) { set_error("null argument"); return RATTLE_ERR_ARG; }
     *out = nullptr;
     RT_TRY(use_device(c));
+    if (c->idx.k == 0) { set_error("no reads loaded"); return RATTLE_ERR_STATE; }      // (never loaded, or the index made room for a big `correct`)
     if (!P->is_rna && !c->idx.both) { set_error("cDNA mode needs the reads loaded with both_strands=1"); return RATTLE_ERR_STATE; }
     // cluster.cpp:42: `if (is_rna) return {-1,false}` comes before the reverse test, so a both-strand index would over-cluster
     if (P->is_rna && c->idx.both) { set_error("--rna mode needs the reads loaded with both_strands=0"); return RATTLE_ERR_STATE; }
@@ -475,6 +476,23 @@ int rattle_hip_correct_reads(rattle_ctx *c, const uint8_t *seq, const uint8_t *q
     }
     *out = nullptr;
     RT_TRY(use_device(c));
+    {
+        // A context that clustered its reads still holds their k-mer index (12-20 bytes per base) and kernel B's work lists; `correct`
+        // uses none of it and sizes its arena by what is free.  Beyond 24 GB the index goes first (3e6 mixed reads: 72 GB of it beside the
+        // arena ran stage 2 out of memory); the reads must then be loaded again before the next cluster call, which is what every
+        // caller of the big jobs does anyway (RATTLE_ERR_STATE "no reads loaded" otherwise).
+        read_index &X = c->idx;
+        const uint64_t held = 4ull * (X.uh.cap + X.kh[0].cap + X.kh[1].cap + X.kp[0].cap + X.kp[1].cap) + 8ull * (X.bv[0].cap + X.bv[1].cap);
+        const char *keep_mb = getenv("RATTLE_INDEX_KEEP_MB");            // (tests lower the bound to see the index go)
+        if (held > (keep_mb ? (uint64_t)strtoull(keep_mb, nullptr, 10) << 20 : 24ull << 30)) {
+            X.uh.release(); X.kh[0].release(); X.kh[1].release(); X.kp[0].release(); X.kp[1].release(); X.bv[0].release(); X.bv[1].release();
+            X.pc[0].release(); X.pc[1].release(); X.seq.release(); X.off.release(); X.koff.release(); X.len.release();
+            X.n = 0; X.k = 0; X.total_bases = X.total_kmers = 0;
+            c->d_surv.release(); c->d_surv2.release(); c->d_sort_tmp.release(); c->d_pi.release(); c->d_pj.release(); c->d_ps.release();
+            c->d_pi2.release(); c->d_pj2.release(); c->d_slot2.release(); c->d_ps2.release(); c->d_res.release(); c->d_var.release();
+            c->d_scratch.release(); c->d_pass.release();
+        }
+    }
     int rc = correct_driver(c, seq, qual, off, n_reads, n_clusters, coff, mid, mrev, P, out);
     if (rc != 0 && *out) { rattle_hip_correction_free(*out); *out = nullptr; }
     return rc;

@@ -16,6 +16,33 @@ def test_empty_and_single_read_sets(gpu_ctx, oracle):
     assert gpu_ctx.cluster_reads().as_list() == oracle.cluster_reads(one, k=10)[0] == [((0, 0, -1), [(0, 0, -1)])]
 
 
+def test_a_big_correct_takes_the_room_of_the_cluster_index(gpu_ctx, oracle, monkeypatch):
+    """A context that clustered its reads keeps their k-mer index (12-20 bytes per base); `correct` needs none of it and sizes its arena by
+    the free memory, so beyond 24 GB the index is released at its entry (abi.hip; config 5 at 3e6 reads ran out of memory in stage 2 with
+    72 GB of index beside the arena).  With the bound lowered to nothing: `correct` gives the oracle's bytes, the next cluster call says the
+    reads are gone instead of reading freed memory, and after loading them again the clusters are the same."""
+    from rattle_amd import synth
+    from rattle_amd._lib import RattleError
+    from rattle_amd.api import cluster_command, correct_command
+    seqs, quals, _, _ = synth.reads(400, 4, 1, True, seed=5)
+    order = sorted(range(len(seqs)), key=lambda i: -len(seqs[i]))
+    reads = [seqs[i] for i in order]
+    headers = [b"@r%d" % i for i in range(len(seqs))]
+    clusters, _ = cluster_command(gpu_ctx, seqs, list(range(len(seqs))))
+    gpu_ctx.load_reads(reads, 10, True)
+    before = gpu_ctx.cluster_reads().as_list()
+    monkeypatch.setenv("RATTLE_INDEX_KEEP_MB", "0")
+    got = correct_command(gpu_ctx, headers, seqs, quals, clusters)
+    monkeypatch.delenv("RATTLE_INDEX_KEEP_MB")
+    from rattle_amd import hps
+    want = oracle.correct(headers, seqs, quals, hps.encode(clusters))
+    assert (got[0], got[1], got[2]) == (want[0], want[1], want[2])
+    with pytest.raises(RattleError, match="no reads loaded"):
+        gpu_ctx.cluster_reads()
+    gpu_ctx.load_reads(reads, 10, True)
+    assert gpu_ctx.cluster_reads().as_list() == before
+
+
 def test_identical_reverse_and_short_reads(gpu_ctx, oracle):
     rng = np.random.default_rng(3)
     base = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 600)].tobytes()
