@@ -41,9 +41,11 @@ mem = HbmPeak(); mem.start()
 ctx.stage_reads(cat, qcat, off)
 mem.phase = "cluster"
 t0 = time.time(); cl = ctx.cluster_unsorted_packed(cat, off, is_rna=True); t1 = time.time()
+print(f"cluster: {t1 - t0:.1f} s, {len(cl.main_id)} clusters, HBM in use at most {mem.peak.get('cluster', 0) / 1e9:.1f} GB", flush=True)
 mem.phase = "correct"
 res = ctx.correct_packed(cat, qcat, off, cl, max_pack_cells=(6 * cap + 64) * cap, keep=True); t2 = time.time()
 n_cor, n_unc, n_cons, counters = res.counts()
+print(f"correct: {t2 - t1:.1f} s, {n_cor} corrected, {n_unc} uncorrected, {n_cons} consensi, HBM in use at most {mem.peak.get('correct', 0) / 1e9:.1f} GB", flush=True)
 assert n_cor + n_unc == n
 R = res.ptr.contents
 cons = [R.consensi.seq[int(R.consensi.off[i]):int(R.consensi.off[i + 1])] for i in range(R.consensi.n)]
