@@ -250,3 +250,98 @@ def test_band_on_a_dag_is_exact_when_its_best_score_clears_the_bound():
         for start in cf[:3]:
             assert dag_trace(rows, b, Hf, Ff, Ef, start) == dag_trace(rows, b, Hb, Fb, Eb, start), case
     assert held >= 25 and failed >= 3                     # both branches of the kernel's logic are exercised
+
+
+def longest_paths(rows):
+    """a[i] = nodes on the longest path ENDING at row i (i included), b[i] = nodes on the longest path AFTER row i (rows 1-based, in
+    topological order)."""
+    n = len(rows)
+    a, b = [0] * (n + 1), [0] * (n + 2)
+    for i in range(1, n + 1):
+        a[i] = 1 + max((a[p] for p in rows[i - 1]["preds"]), default=0)
+    for i in range(n, 0, -1):
+        for p in rows[i - 1]["preds"]:
+            b[p] = max(b[p], b[i] + 1)
+    return a, b
+
+
+def add_ragged_ends(rng, rows, C, starts, ends):
+    """What the POA #3 of many pack consensi looks like: alternative START chains that join the backbone a few
+    columns in and alternative END chains that leave it a few columns before its end.  Every such chain takes columns of its own in the
+    block order -- the MSA has 10-20 columns more per chain -- while no path visits two of them: the longest path barely grows."""
+    by_col = {}
+    for i, r in enumerate(rows):
+        by_col.setdefault(r["col"], []).append(i + 1)
+    out = [dict(r, preds=list(r["preds"])) for r in rows]
+    # rebuild in block order with the new chains spliced in: a start chain right before the column it joins, an end chain at the very end
+    joins = sorted(int(rng.integers(2, 8)) for _ in range(starts))
+    leaves = sorted(C - int(rng.integers(2, 8)) for _ in range(ends))
+    new_rows, remap, col = [], {}, 0
+    cols_sorted = sorted(by_col)
+    for c in cols_sorted:
+        for jn in [j for j in joins if j == c]:
+            prev = 0
+            for _ in range(int(rng.integers(4, 12))):
+                col += 1
+                new_rows.append({"letter": int(rng.integers(0, 4)), "preds": [prev] if prev else [], "col": col, "ins": False})
+                prev = len(new_rows)
+            remap.setdefault(("join", c), []).append(prev)
+        col += 1
+        for r in by_col[c]:
+            new_rows.append({"letter": out[r - 1]["letter"], "preds": [("old", p) for p in out[r - 1]["preds"]] + remap.get(("join", c), []), "col": col, "ins": out[r - 1]["ins"]})
+            remap[("old", r)] = len(new_rows)
+    for lv in leaves:
+        prev = remap[("old", by_col[lv][0])]
+        for _ in range(int(rng.integers(4, 12))):
+            col += 1
+            new_rows.append({"letter": int(rng.integers(0, 4)), "preds": [prev], "col": col, "ins": False})
+            prev = len(new_rows)
+    for r in new_rows:
+        r["preds"] = [remap[p] if isinstance(p, tuple) else p for p in r["preds"]]
+    return new_rows, col
+
+
+def test_band_by_longest_paths_is_exact_and_narrower_than_the_band_by_columns():
+    """The same lemma with the tightest bounds it admits (not built into the kernel: DESIGN.md section 8 item 2): a path through cell (i, j) has
+    at most min(a_i, j) + min(b_i, L - j) diagonal moves, a_i / b_i the longest paths ending at / leaving row i.  The band
+    L - t - b_i <= j <= a_i + t is exact under the same certificate (best score inside >= 5 (L - t) - 4) -- same best cells, same traceback --
+    and on graphs with ragged start / end chains it is narrower than the band by MSA columns, which pays for every chain's own columns."""
+    rng = np.random.default_rng(33)
+    held = failed = narrower = 0
+    for case in range(60):
+        rows, C = random_near_chain_dag(rng, int(rng.integers(40, 70)), 0.12, 0.05, 0.08)
+        rows, C = add_ragged_ends(rng, rows, C, int(rng.integers(2, 6)), int(rng.integers(2, 6)))
+        for r in rows:
+            assert all(rows[p - 1]["col"] < r["col"] for p in r["preds"])
+        a, bb = longest_paths(rows)
+        P = max(a)
+        assert P < C                                       # the chains cost columns, not path length
+        # a sequence along ONE longest path, cut at the 5' end, with a few errors
+        i, path = a.index(P), []
+        while i:
+            path.append(rows[i - 1]["letter"])
+            i = next((p for p in rows[i - 1]["preds"] if a[p] == a[i] - 1), 0)
+        path.reverse()
+        b = mutate(rng, path[int(rng.integers(0, 6)):], float(rng.choice([0.0, 0.03, 0.06])))
+        L = len(b)
+        if L < 10:
+            continue
+        t = int(rng.choice([2, 4, 8]))
+        tau = L - t
+        band = lambda i: (max(1, tau - bb[i]), min(L, a[i] + t))
+        width_paths = max(hi - lo + 1 for lo, hi in (band(i) for i in range(1, len(rows) + 1)) if hi >= lo)
+        width_cols = C - L + 2 * t + 1
+        narrower += width_paths < width_cols
+        Hb, Fb, Eb = dag_dp(rows, b, band)
+        sb, cb = best_cells(Hb)
+        Hf, Ff, Ef = dag_dp(rows, b)
+        sf, cf = best_cells(Hf)
+        if sb < 5 * tau - 4:
+            failed += 1
+            assert sf >= sb
+            continue
+        held += 1
+        assert sf == sb and cf == cb, (case, sf, sb)
+        for start in cf[:3]:
+            assert dag_trace(rows, b, Hf, Ff, Ef, start) == dag_trace(rows, b, Hb, Fb, Eb, start), case
+    assert held >= 20 and narrower >= 40, (held, failed, narrower)
