@@ -190,6 +190,21 @@ struct stage {
 // where a run of gather descriptors reads from
 struct gather_part { uint32_t begin, count; const uint8_t *src_seq, *src_qual; };
 
+// The POA arena is cached in the context between stages and sized by what was free when its pass began (85 % of it).  The buffers the
+// stages allocate BESIDE it grow with the job: the MSA rows of a stage (two bytes per cell) and the compacted corrected reads (two bytes per
+// base, + 25 % of dbuf's slack).  At 5e6 mixed reads (10 Gb) the corrected reads no longer fitted beside a 230 GB arena.  So before a
+// large allocation: if it does not fit into what is free, the idle arena goes (the next POA pass allocates one that fits; ~20 ms per GB).
+static void make_room(rattle_ctx *ctx, uint64_t bytes) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const uint64_t need = bytes + bytes / 4 + (1ull << 30);
+    static const bool always = getenv("RATTLE_MAKE_ROOM_ALWAYS") != nullptr;      // (tests: the arena goes at every such point)
+    if ((free_b >= need && !always) || !ctx->poa_arena) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ctx->poa_arena);
+    ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
+}
+
 // gather the stage's sequences (descriptors built by the caller, dst offsets = st.off) and run POA + kernel D
 int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, const std::vector<gather_part> &parts,
               int mode, const rattle_correct_params *P, const char *order, uint64_t *counters) {
@@ -200,6 +215,7 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     S.skipped.assign(np, 0);
     if (np == 0) return 0;
     dbuf<gather_desc> d_desc;
+    make_room(ctx, (uint64_t)(n + 1) * sizeof(gather_desc) + (mode == 1 ? 3 : 2) * (total + 64));
     RT_TRY(d_desc.reserve(n + 1));
     RT_TRY(S.seq.reserve(total + 64)); RT_TRY(S.d_off.reserve(n + 1)); RT_TRY(S.col.reserve(total + 64));
     RT_TRY(S.d_width.reserve(np)); RT_TRY(S.d_first.reserve(np + 1));
@@ -232,6 +248,7 @@ int run_stage(rattle_ctx *ctx, stage &S, const std::vector<gather_desc> &desc, c
     }
     S.cells = cells; S.cols = cols;
     phase_timer T("  stage: post-MSA kernel");
+    make_room(ctx, (mode == 1 ? 2 : 1) * (cells + 64) + 4 * (cols + 64) + 20ull * (n + 1));
     RT_TRY(S.rowc.reserve(cells + 64)); RT_TRY(S.d_moff.reserve(np)); RT_TRY(S.d_coff.reserve(np));
     RT_TRY(S.rfirst.reserve(n + 1)); RT_TRY(S.rlast.reserve(n + 1)); RT_TRY(S.ccons.reserve(cols + 64));
     if (mode == 1) {
@@ -512,6 +529,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             }
             C.off[nc] = tot;
             if (nc) {
+                make_room(ctx, 2 * (tot + 64) + od[0].size() * sizeof(gather_desc));
                 RT_TRY(d_os.reserve(tot + 64)); RT_TRY(d_oq.reserve(tot + 64));
                 for (int g = 0; g < 1; ++g) {
                     if (od[g].empty()) continue;
@@ -628,6 +646,7 @@ int correct_driver(rattle_ctx *ctx, const uint8_t *seq, const uint8_t *qual, con
             S.first.push_back((uint32_t)S.off.size() - 1);
         }
         dbuf<uint8_t> d_in;
+        make_room(cx, C.h_in.size() + 64);
         RT_TRY(d_in.reserve(C.h_in.size() + 64));
         if (!C.h_in.empty()) RT_HIP(hipMemcpyAsync(d_in.p, C.h_in.data(), C.h_in.size(), hipMemcpyHostToDevice, cx->stream));
         RT_TRY(run_stage(cx, S, d, {gather_part{0, n3, d_in.p, nullptr}, gather_part{n3, (uint32_t)d.size() - n3, X ? X->S.rowc.p : nullptr, nullptr}}, 2, P, order, cnt));

@@ -43,6 +43,33 @@ def test_a_big_correct_takes_the_room_of_the_cluster_index(gpu_ctx, oracle, monk
     assert gpu_ctx.cluster_reads().as_list() == before
 
 
+def test_correct_gives_up_its_cached_arena_when_a_stage_needs_the_room():
+    """`correct` keeps the POA arena between stages (85 % of what was free when a pass began); the stages' own buffers -- MSA rows, the
+    compacted corrected reads -- grow with the job, and at 5e6 mixed reads they no longer fitted beside it.  correct_driver.hip: make_room
+    frees the idle arena before a large allocation that would not fit; the next POA pass allocates one that does.  Here with
+    RATTLE_MAKE_ROOM_ALWAYS=1 (a fresh process: the switch is read once): every stage re-allocates, the three outputs are the oracle's."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'oracle'))
+import oracle as orc_mod
+from rattle_amd import synth, hps
+from rattle_amd.api import Context, cluster_command, correct_command
+seqs, quals, _, _ = synth.reads(500, 4, 1, True, seed=12)
+headers = [b'@r%%d' %% i for i in range(len(seqs))]
+ctx = Context(0)
+clusters, _ = cluster_command(ctx, seqs, list(range(len(seqs))))
+got = correct_command(ctx, headers, seqs, quals, clusters, split=40)
+want = orc_mod.Oracle().correct(headers, seqs, quals, hps.encode(clusters), split=40)
+assert (got[0], got[1], got[2]) == (want[0], want[1], want[2])
+print('same')
+""" % (root, root)
+    env = dict(os.environ, RATTLE_MAKE_ROOM_ALWAYS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("same"), r.stderr[-2000:]
+
+
 def test_identical_reverse_and_short_reads(gpu_ctx, oracle):
     rng = np.random.default_rng(3)
     base = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 600)].tobytes()
