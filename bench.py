@@ -33,29 +33,34 @@ VALU_PRACTICAL_TINSTR = 256 * 4 * 2.4e9 / 4.3 / 1e12      # ... at the issue rat
 SALU_PEAK_TINSTR = 256 * 2.4e9 / 1e12               # one scalar unit per CU, one instruction per cycle
 
 
-def device_state():
+def device_state(light=False):
     """What the box says about the device's clocks and power right now (sysfs; None where it says nothing): boxes and consecutive runs
-    differ by +-8 % for one binary, so the line carries the state it was measured in, before and after the timed region."""
+    differ by +-8 % for one binary, so the line carries the state it was measured in, before and after the timed region.
+    light = True: the clock and one power reading only (two files instead of six) -- what the sampler reads WHILE the timed region runs:
+    every one of these files is a query to the device's power-management firmware."""
     import glob
     st = {}
     try:
         for d in sorted(glob.glob("/sys/class/drm/card*/device")):
             if not os.path.exists(os.path.join(d, "pp_dpm_sclk")):
                 continue
-            for key, f in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+            for key, f in ((("sclk", "pp_dpm_sclk"),) if light else (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"))):
                 try:
                     cur = [l.split(":")[1].strip().rstrip("*").strip() for l in open(os.path.join(d, f)) if "*" in l]
                     st[key] = cur[0] if cur else None
                 except Exception:
                     st[key] = None
-            try:
-                st["busy_percent"] = int(open(os.path.join(d, "gpu_busy_percent")).read())
-            except Exception:
-                pass
+            if not light:
+                try:
+                    st["busy_percent"] = int(open(os.path.join(d, "gpu_busy_percent")).read())
+                except Exception:
+                    pass
             for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
                 for key, f, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+                    if key in st or (light and key != "power_w"):
+                        continue                                       # (one power file is enough: the second is the fallback)
                     try:
-                        st.setdefault(key, round(int(open(os.path.join(hw, f)).read()) * scale, 1))
+                        st[key] = round(int(open(os.path.join(hw, f)).read()) * scale, 1)
                     except Exception:
                         pass
             break
@@ -65,17 +70,23 @@ def device_state():
 
 
 class DeviceSampler:
-    """Samples device_state() every 100 ms on a thread while the timed region runs: the state before and after it is an idle device's
-    (sclk ~100 MHz) and says nothing about the clocks the kernels ran at.  summary(): mean / min / max of sclk, power, temperature."""
+    """Samples device_state() every 100 ms on a thread: the state before and after a run is an idle device's (sclk ~100 MHz) and says nothing
+    about the clocks the kernels ran at.  summary(): mean / min / max of sclk, power, temperature.
+    It runs during the WARM-UP steps only (same reads, same kernels as the timed ones).  Until round 6 it ran through the timed region --
+    six sysfs files ten times a second, each a query to the device's power-management firmware -- and the timed steps of a bench.py
+    process showed an intermittent slow stage 1: 4.5-4.9 s instead of 3.8 s at the same clock and LOWER power, 5 of 28 timed steps, which
+    26 steps of the same loop in processes without the sampler never showed (tools/step_spread_capture.py, tools/correct_repeat.py) and
+    16 timed steps with the sampler throttled to two files a second did not show either (profiles/round6zz_light_sampler.txt;
+    DESIGN.md section 5).  Throttled, the clock file mostly reads the idle value, so the timed region is not sampled at all."""
 
-    def __init__(self, period=0.1):
+    def __init__(self, period=0.1, light=False):
         import threading
-        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.period, self.light, self.samples, self._stop = period, light, [], threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
         while not self._stop.is_set():
-            st = device_state()
+            st = device_state(light=self.light)
             if st:
                 st["t"] = time.time()
                 self.samples.append(st)
@@ -562,10 +573,13 @@ def main():
     if not a.no_stage:     # inputs resident in HBM before the timed region (BASELINE metric definition)
         ctx.stage_reads(cat, qcat, off)
     warm = None
+    state0 = device_state() if rank == 0 else None
+    sampler = DeviceSampler().start() if rank == 0 and a.warmup else None       # (the warm-up steps only: see DeviceSampler)
     for _ in range(a.warmup):
         if warm is not None and not a.iso:
             warm[1].free()
         warm = step()
+    state_during = sampler.summary() if sampler is not None else None           # (stops the thread)
     ctx.reset_stats()
     PHASES["cluster"] = PHASES["correct"] = 0.0
     # A step returns the corrected reads as ~2 GB of host buffers the CALLER frees (the reference returns std::vectors).  Giving
@@ -580,8 +594,6 @@ def main():
             hold = psutil.virtual_memory().available > 3 * per * (a.steps + 2)
         except Exception:
             hold = False
-    state0 = device_state() if rank == 0 else None
-    sampler = DeviceSampler().start() if rank == 0 else None
     barrier()
     t0 = time.time()
     last = None
@@ -605,12 +617,8 @@ def main():
                             "correct_stage_ms": {} if a.iso else {k: round(v, 1) for k, v in ctx.stage_ms().items()}, "t": (ts, te)})
     barrier()
     dt = time.time() - t0
-    state_during = sampler.summary() if sampler is not None else None
     for d in step_detail:
-        ts, te = d.pop("t")
-        if sampler is not None:
-            sm = sampler.summary(ts, te, keys=("sclk", "power_w"))
-            d["sclk_mhz"], d["power_w"], d["samples"] = sm.get("sclk"), sm.get("power_w"), sm.get("samples")
+        d.pop("t")
     state1 = device_state() if rank == 0 else None
     tf = time.time()
     for h in held:
@@ -673,7 +681,8 @@ def main():
             # every timed step on its own (first-step vs steady state), the state of the device around the timed region, and what the
             # harness kept OUT of the timed region: a step's ~2 GB result is freed after the timer stops when the host has the memory
             # (`results_held`), which costs `result_free_ms` per step when it is done between steps instead
-            "step_ms": [round(x, 1) for x in step_ms], "step_detail": step_detail, "device_state": {"before": state0, "during": state_during, "after": state1},
+            "step_ms": [round(x, 1) for x in step_ms], "step_detail": step_detail, "device_state": {"before": state0, "during_warmup": state_during, "after": state1,
+                             "note": "sysfs is sampled during the warm-up steps only: polling it through the timed region slowed single steps by a second (DESIGN.md section 5)"},
             "results_held": bool(hold), "result_free_ms": free_ms,
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
             "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items() if v > 0},

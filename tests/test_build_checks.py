@@ -47,7 +47,7 @@ def test_poa_row_loops_keep_spills_and_scratch_out_of_their_hot_blocks(tmp_path)
 
 
 def test_bench_device_sampler_summarises_what_sysfs_says(monkeypatch):
-    """bench.py samples sysfs (clock lines like '2406Mhz', power in watts) on a thread during the timed region; the summary is part of the
+    """bench.py samples sysfs (clock lines like '2406Mhz', power in watts) on a thread during the warm-up steps; the summary is part of the
     driver's bench line, so the parsing must survive whatever the box says: strings with units, missing keys, nothing at all."""
     import importlib.util
     import time
@@ -59,12 +59,12 @@ def test_bench_device_sampler_summarises_what_sysfs_says(monkeypatch):
     finally:
         sys.argv = argv
     script = iter([{"sclk": "2406Mhz", "mclk": "2000Mhz", "power_w": 900.0}, {"sclk": "1800Mhz", "power_w": 700.0, "temp_c": None}, None, {"sclk": "N/A"}])
-    monkeypatch.setattr(bench, "device_state", lambda: next(script, None))
+    monkeypatch.setattr(bench, "device_state", lambda light=False: next(script, None))
     s = bench.DeviceSampler(period=0.01).start()
     time.sleep(0.15)
     out = s.summary()
     assert out["samples"] == 3                                   # the None sample is dropped
     assert out["sclk"] == {"mean": 2103.0, "min": 1800.0, "max": 2406.0}
     assert out["power_w"]["max"] == 900.0 and "temp_c" not in out
-    monkeypatch.setattr(bench, "device_state", lambda: None)
+    monkeypatch.setattr(bench, "device_state", lambda light=False: None)
     assert bench.DeviceSampler(period=0.01).start().summary() == {"samples": 0}
