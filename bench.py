@@ -72,12 +72,12 @@ def device_state(light=False):
 class DeviceSampler:
     """Samples device_state() every 100 ms on a thread: the state before and after a run is an idle device's (sclk ~100 MHz) and says nothing
     about the clocks the kernels ran at.  summary(): mean / min / max of sclk, power, temperature.
-    It runs during the WARM-UP steps only (same reads, same kernels as the timed ones).  Until round 6 it ran through the timed region --
-    six sysfs files ten times a second, each a query to the device's power-management firmware -- and the timed steps of a bench.py
-    process showed an intermittent slow stage 1: 4.5-4.9 s instead of 3.8 s at the same clock and LOWER power, 5 of 28 timed steps, which
-    26 steps of the same loop in processes without the sampler never showed (tools/step_spread_capture.py, tools/correct_repeat.py) and
-    16 timed steps with the sampler throttled to two files a second did not show either (profiles/round6zz_light_sampler.txt;
-    DESIGN.md section 5).  Throttled, the clock file mostly reads the idle value, so the timed region is not sampled at all."""
+    It runs during the WARM-UP steps only (same reads, same kernels as the timed ones): every one of these files is a query to the device's
+    power-management firmware, and the timed region is better left without them.  (Round 6 suspected this polling -- six files ten times a
+    second -- of the intermittent slow stage 1 of single steps, 4.5-4.9 s instead of 3.8 s at the same clock and lower power: 6 of 29 timed
+    steps with it, none in 26 steps of the same loop in processes without it, none in 16 steps with it throttled.  Then a step WITHOUT any
+    polling was slow on yet another box.  The slow steps follow the box, not the sampler; DESIGN.md section 5.  Note also that the first card
+    in sysfs is not always the device the process runs on.)"""
 
     def __init__(self, period=0.1, light=False):
         import threading
@@ -682,7 +682,7 @@ def main():
             # harness kept OUT of the timed region: a step's ~2 GB result is freed after the timer stops when the host has the memory
             # (`results_held`), which costs `result_free_ms` per step when it is done between steps instead
             "step_ms": [round(x, 1) for x in step_ms], "step_detail": step_detail, "device_state": {"before": state0, "during_warmup": state_during, "after": state1,
-                             "note": "sysfs is sampled during the warm-up steps only: polling it through the timed region slowed single steps by a second (DESIGN.md section 5)"},
+                             "note": "sysfs (first card that has a clock file: not necessarily this process's device) is sampled during the warm-up steps only; the timed region runs without firmware queries"},
             "results_held": bool(hold), "result_free_ms": free_ms,
             "kernels_ms_per_step": {k: v[0] / a.steps for k, v in kst.items()},
             "phases_ms_per_step": {k: v / a.steps * 1e3 for k, v in PHASES.items() if v > 0},
