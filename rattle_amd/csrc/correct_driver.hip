@@ -195,11 +195,12 @@ struct gather_part { uint32_t begin, count; const uint8_t *src_seq, *src_qual; }
 // base, + 25 % of dbuf's slack).  At 5e6 mixed reads (10 Gb) the corrected reads no longer fitted beside a 230 GB arena.  So before a
 // large allocation: if it does not fit into what is free, the idle arena goes (the next POA pass allocates one that fits; ~20 ms per GB).
 static void make_room(rattle_ctx *ctx, uint64_t bytes) {
+    static const bool always = getenv("RATTLE_MAKE_ROOM_ALWAYS") != nullptr;      // (tests: the arena goes at every such point)
+    if (!ctx->poa_arena || (!always && bytes < (4ull << 30))) return;             // (a job of the bench's size never asks the driver anything here)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
     const uint64_t need = bytes + bytes / 4 + (1ull << 30);
-    static const bool always = getenv("RATTLE_MAKE_ROOM_ALWAYS") != nullptr;      // (tests: the arena goes at every such point)
-    if ((free_b >= need && !always) || !ctx->poa_arena) return;
+    if (free_b >= need && !always) return;
     (void)hipDeviceSynchronize();
     (void)hipFree(ctx->poa_arena);
     ctx->poa_arena = nullptr; ctx->poa_arena_bytes = 0;
