@@ -108,6 +108,28 @@ def test_whole_fixture_consensi_and_uncorrected(oracle, toyset, toyset_clusters)
     assert ids == open(os.path.join(GOLDEN, "toyset_rna.uncorrected.ids")).read().split()
 
 
+def test_whole_fixture_with_simd_rows(oracle, toyset, toyset_clusters):
+    """The whole fixture by DEFAULT (round 6; until then only the HIP path ran all of it unasked): every cluster of the reference's
+    clusters.out through the oracle with its AVX2 int16 POA rows -- the same H / F / E values and traceback as the scalar rows
+    (test_avx2_row_fill_gives_the_scalar_alignments below checks that on whole packs), a quarter of the time -- must give the 175 consensi of
+    consensi.fq and the 739 records of uncorrected.fq, in order.  (The scalar-row run of the same check stays opt-in: RATTLE_SLOW=1.)"""
+    if not oracle.set_poa_simd(True):
+        pytest.skip("no AVX2 on this host: the scalar rows take 5 CPU-minutes (RATTLE_SLOW=1)")
+    want = fixture_consensi()
+    cids = list(range(len(toyset_clusters)))
+    oracle.set_cv_order(b"U-GTAC")
+    try:
+        got, unc, _ = run_subset(oracle, toyset, toyset_clusters, cids, PACK_ORDER)
+    finally:
+        oracle.set_cv_order(b"U-GTCA")
+        oracle.set_poa_simd(False)
+    assert len(want) == 175 and set(got) == set(want)
+    bad = [c for c in want if got[c] != want[c]]
+    assert not bad, bad
+    ids = [l.split(",")[0] for l in unc.split("\n")[0::4] if l]
+    assert ids == open(os.path.join(GOLDEN, "toyset_rna.uncorrected.ids")).read().split()
+
+
 def test_vote_order_is_libstdcxx_iteration_order(tmp_path):
     """correct.cpp:105-110 inserts A, C, T, U, G, '-' into an unordered_map<char, ...> and :174 iterates it:
     the tie order of the column vote is that container's iteration order.  Measured here with the host's
