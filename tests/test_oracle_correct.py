@@ -7,8 +7,9 @@ cluster's consensus is reproduced exactly; the 8 multi-pack clusters (> 200 read
 correct.cpp:489-556) depend on the order in which the fixture's worker threads finished their packs
 (correct.cpp:469): PACK_ORDER records, per cluster, the completion order under which the fixture's
 sequence is reproduced (found by search over the permutations; 2 of the 8 need none).  The whole-fixture
-check -- all 175 consensi and the 739 uncorrected records in order -- takes ~6 CPU-minutes and is opt-in
-here (RATTLE_SLOW=1); the same check runs through the HIP path by default (tests/test_gpu_correct.py).
+check -- all 175 consensi and the 739 uncorrected records in order -- runs by default with the oracle's AVX2 int16 POA rows
+(test_whole_fixture_with_simd_rows, ~90 s) and, opt-in, with the scalar rows (RATTLE_SLOW=1, ~5 CPU-minutes); the same check runs
+through the HIP path by default (tests/test_gpu_correct.py).
 """
 import gzip
 import os
